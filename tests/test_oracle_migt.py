@@ -1,0 +1,124 @@
+"""CPU: structural invariants that pin oracle/migt_oracle.py.
+The reference transformer is TensorFlow-only and cannot run here: parity unpinned,
+these are the known-answer properties derivable from branching_attention.py / migt.py."""
+import numpy as np
+import torch
+
+from conftest import TINY_MIGT
+from oracle import migt_oracle as mg
+from viewformer_amd.config import MIGTConfig
+from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+
+
+def _qkv(b=2, h=2, s=4, l=4, d=8, seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b, h, s, l, d, generator=g, dtype=dtype) * 2 for _ in range(3)]
+
+
+def _dense_loops(k, v, q):
+    """independent restatement: per query view, softmax over the explicitly masked key set."""
+    b, h, s, l, d = k.shape
+    out = torch.zeros_like(q)
+    kf, vf = k.reshape(b, h, s * l, d), v.reshape(b, h, s * l, d)
+    for i in range(s):
+        w = q[:, :, i] @ kf.transpose(-1, -2)                      # [b,h,l,s*l]
+        w[..., (i + 1) * l:] = -1e4
+        p = torch.softmax(w, -1)
+        out[:, :, i] = p @ vf
+    return out
+
+
+def test_single_stream_is_block_causal_dense_attention():
+    k, v, q = _qkv()
+    a = mg.compute_causal_block_multiend_attention([k], [v], [q])
+    assert len(a) == 1
+    assert torch.allclose(a[0], _dense_loops(k, v, q), atol=1e-12)
+    # masked keys really get zero weight: perturbing a future view leaves earlier outputs untouched
+    k2, v2 = k.clone(), v.clone()
+    k2[:, :, -1] += 3
+    v2[:, :, -1] -= 5
+    a2 = mg.compute_causal_block_multiend_attention([k2], [v2], [q])[0]
+    assert torch.equal(a2[:, :, :-1], a[0][:, :, :-1])
+
+
+def test_branch_equals_attention_over_past_main_views_plus_own_tokens():
+    k, v, q = _qkv(seed=1)
+    kb, vb, qb = _qkv(seed=2)
+    outs = mg.compute_causal_block_multiend_attention([k, kb], [v, vb], [q, qb])
+    b, h, s, l, d = k.shape
+    for i in range(s):
+        keys = torch.cat([k[:, :, :i].reshape(b, h, i * l, d), kb[:, :, i]], 2)
+        vals = torch.cat([v[:, :, :i].reshape(b, h, i * l, d), vb[:, :, i]], 2)
+        ref = torch.softmax(qb[:, :, i] @ keys.transpose(-1, -2), -1) @ vals
+        assert torch.allclose(outs[1][:, :, i], ref, atol=1e-12)
+
+
+def _setup(loc, seed=0, S=4, B=2):
+    cfg = MIGTConfig(**TINY_MIGT, localization_weight='1' if loc else '0', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=seed, std=0.08)
+    g = np.random.Generator(np.random.PCG64(seed + 11))
+    t = cfg.token_image_size
+    ids = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, t, t)))
+    _, cams = synthetic_scene_batch(B, S, 8, seed)
+    return cfg, sd, ids, torch.from_numpy(cams)
+
+
+def test_train_graph_stream1_equals_masked_inference():
+    """§8c(iii): MASK-stream logits of view i in the multi-stream graph == last-view
+    logits of a single-stream call on [views 0..i-1, MASK] (migt.py:392-396 vs
+    evaluate_transformer.py:120-122)."""
+    for loc in (False, True):
+        cfg, sd, ids, cams = _setup(loc)
+        full = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64, compute_losses=True)['logits']
+        for i in range(ids.shape[1]):
+            inp = torch.cat([ids[:, :i], torch.full_like(ids[:, :1], cfg.n_embeddings)], 1)
+            one = mg.migt_forward(sd, cfg, inp, cams[:, :i + 1], dtype=torch.float64)['logits']
+            assert torch.allclose(one[:, -1], full[:, i], atol=1e-9), (loc, i)
+
+
+def test_localization_stream_equals_localization_inference():
+    """3rd stream (tokens + LOC) of the training graph == the evaluator's second pass
+    (evaluate_transformer.py:134-136; migt.py:387-390,398-401)."""
+    cfg, sd, ids, cams = _setup(True, seed=3)
+    full = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64, compute_losses=True)['pose_prediction']
+    for i in range(1, ids.shape[1]):
+        one = mg.migt_forward(sd, cfg, ids[:, :i + 1], cams[:, :i], dtype=torch.float64)['pose_prediction']
+        assert torch.allclose(one[:, -1], full[:, i], atol=1e-9), i
+
+
+def test_fp32_arm_close_to_fp64_arm():
+    cfg, sd, ids, cams = _setup(True, seed=5)
+    a = mg.migt_forward(sd, cfg, ids, cams[:, :-1], dtype=torch.float32)
+    b = mg.migt_forward(sd, cfg, ids, cams[:, :-1], dtype=torch.float64)
+    assert a['logits'].dtype == torch.float32
+    assert (a['logits'].double() - b['logits']).abs().max() < 1e-4
+    assert (a['pose_prediction'].double() - b['pose_prediction']).abs().max() < 1e-4
+
+
+def test_vqk_split_order_and_no_scale_matter():
+    """Guards the two classic mistakes (Appendix C): (V,Q,K) thirds and no 1/sqrt(d)."""
+    cfg, sd, ids, cams = _setup(False, seed=7)
+    base = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)['logits']
+    sd2 = dict(sd)
+    w = sd['h.0.attn.c_attn.weight']
+    d = cfg.d_model
+    sd2['h.0.attn.c_attn.weight'] = np.concatenate([w[:, d:2 * d], w[:, 2 * d:], w[:, :d]], 1)   # as if (Q,K,V)
+    other = mg.migt_forward(sd2, cfg, ids, cams, dtype=torch.float64)['logits']
+    assert (base - other).abs().max() > 1e-3
+
+
+def test_relative_cameras_round_trip_and_reduce():
+    _, cams = synthetic_scene_batch(3, 5, 8, 2)
+    c = torch.from_numpy(cams).double()
+    rel, tr = mg.to_relative_cameras(c)
+    assert torch.allclose(rel[:, 0, :3], torch.zeros(3, 3, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(rel[:, 0, 3:].abs(), torch.tensor([1., 0, 0, 0], dtype=torch.float64).expand(3, 4), atol=1e-9)
+    back = mg.from_relative_cameras(rel, tr)
+    assert torch.allclose(back[..., :3], c[..., :3], atol=1e-9)
+    # quaternions equal up to sign
+    dot = (back[..., 3:] * c[..., 3:]).sum(-1).abs()
+    assert torch.allclose(dot, torch.ones_like(dot), atol=1e-9)
+    n = mg.normalize_cameras(rel)
+    assert (n[..., 3] >= 0).all() and torch.allclose(n[..., 3:].norm(dim=-1), torch.ones(3, 5, dtype=torch.float64))
+    r = mg.reduce_cameras(n.unsqueeze(2).expand(3, 5, 16, 7), -2)
+    assert torch.allclose(r, n, atol=1e-9)

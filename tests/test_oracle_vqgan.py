@@ -1,0 +1,78 @@
+"""CPU: pin oracle/vqgan_oracle.py against the golden vectors recorded from the
+reference's own VQGAN (tests/golden/make_golden.py)."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import vqgan_oracle as vq
+from viewformer_amd.weights import synthetic_scene_batch, make_vqgan_weights
+from viewformer_amd.config import VQGANConfig
+
+
+def _x(frames):
+    return vq.preprocess_u8(torch.from_numpy(frames))
+
+
+def test_tiny_encode_matches_reference(tiny_vq):
+    cfg, sd, g = tiny_vq
+    frames, _ = synthetic_scene_batch(1, 6, cfg.image_size, seed=int(g['input_seed']))
+    assert np.array_equal(frames[0], g['frames'])          # the input generator is portable
+    x = _x(frames[0])
+    z = vq.encode_z(sd, cfg, x)
+    assert np.allclose(z.numpy(), g['z'], atol=1e-5, rtol=1e-5)   # utils/testing.py:98 tolerance
+    quant, diff, codes = vq.encode(sd, cfg, x)
+    assert codes.dtype == torch.int64
+    assert np.array_equal(codes.numpy(), g['codes'])       # bit-exact indices
+    assert np.allclose(quant.numpy(), g['quant'], atol=1e-6)
+    assert abs(float(diff) - float(g['diff'])) < 1e-6
+
+
+def test_tiny_decode_matches_reference(tiny_vq):
+    cfg, sd, g = tiny_vq
+    dec = vq.decode_code(sd, cfg, torch.from_numpy(g['codes']))
+    assert np.allclose(dec.numpy(), g['decoded'], atol=1e-5, rtol=1e-5)
+    # VQGAN.forward == decode(quant) with the straight-through value == decode_code(codes)
+    assert np.allclose(dec.numpy(), g['forward'], atol=1e-5, rtol=1e-5)
+
+
+def test_full_encode_decode_matches_reference(full_vq):
+    cfg, sd, g = full_vq
+    frames, _ = synthetic_scene_batch(1, 4, 128, seed=int(g['input_seed']))
+    x = _x(frames[0])
+    z = vq.encode_z(sd, cfg, x)
+    assert np.allclose(z.numpy(), g['z'], atol=2e-5, rtol=1e-5)
+    codes = vq.quantize(sd, z)[-1]
+    assert np.array_equal(codes.numpy(), g['codes'])
+    assert len(np.unique(g['codes'])) > 20                 # the lookup is not degenerate
+    dec = vq.decode_code(sd, cfg, torch.from_numpy(g['codes'][:2]))
+    assert np.allclose(dec.numpy(), g['decoded'], atol=2e-5, rtol=1e-5)
+
+
+def test_lookup_matches_reference_including_ties():
+    g = load_golden('vq_lookup.npz')
+    sd = make_vqgan_weights(VQGANConfig(), seed=int(g['seed']), codebook_scale=float(g['codebook_scale']))
+    q, diff, idx = vq.quantize(sd, torch.from_numpy(g['z']))
+    assert np.array_equal(idx.numpy(), g['idx'])
+    assert idx.reshape(-1)[0] == 17                          # a row equal to code 17 maps to 17
+    assert np.allclose(q.numpy(), g['quant'])
+    assert abs(float(diff) - float(g['diff'])) < 1e-6
+
+
+def test_fp64_arm_agrees_where_margin_is_clear(full_vq):
+    """The fp64 arm may only disagree with the reference on near-ties."""
+    cfg, sd, g = full_vq
+    z = torch.from_numpy(g['z'])
+    idx64 = vq.quantize(sd, z, dtype=torch.float64)[-1].numpy().reshape(-1)
+    ref = g['codes'].reshape(-1)
+    bad = idx64 != ref
+    assert (g['margin'][bad] < 1e-4).all()
+
+
+def test_pre_post_process_semantics():
+    u8 = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16, 1).repeat(1, 1, 1, 3)
+    x = vq.preprocess_u8(u8)
+    assert x.shape == (1, 3, 16, 16) and x.min() == -1 and x.max() == 1
+    back = vq.postprocess_u8(x)
+    assert torch.equal(back, u8)                             # 255.5 scale + truncation round-trips every level
+    y = vq.postprocess_u8(torch.tensor([-3.0, -1.0, 0.0, 0.999, 1.0, 7.0]).reshape(1, 1, 1, 6).repeat(1, 3, 1, 1))
+    assert y[0, 0, :, 0].tolist() == [0, 0, 127, 255, 255, 255]
