@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py — novel views/sec of the ViewFormer hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of ``generate_batch_predictions`` (evaluate_transformer.py:97-146) over one
+batch of synthetic scenes already resident in HBM: uint8 frames [B,7,128,128,3] + cameras [B,7,7]
+-> encode all 7 views (target included, as the reference does) -> MIGT pass with the MASK view ->
+argmax -> decode -> uint8 novel view (+ the localization pass the SM7 model runs).
+Workload = BASELINE.json configs[1]: SM7 codebook + transformer, 6 context views -> 1 novel view.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N>1: one process per GPU, scenes sharded (weak scaling: --batch scenes per GPU per step), weights
+replicated, no data-path collective; barrier + max-over-ranks time; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, f32 in)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_models(dev, localization: bool):
+    from viewformer_amd.config import VQGANConfig, MIGTConfig
+    from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.migt import MIGT
+    vcfg = VQGANConfig()
+    # SM7 transformer (README.md:348-360): seq 6 (+ the generated view), pose-multiplier 0.2,
+    # localization schedule cosine(0,1,120000) => the localization head is on.
+    mcfg = MIGTConfig(sequence_size=6, n_loss_skip=1, pose_multiplier=0.2,
+                      localization_weight='cosine(0,1,120000)' if localization else '0')
+    vsd = make_vqgan_weights(vcfg, seed=0, codebook_scale=0.05)
+    msd = make_migt_weights(mcfg, seed=0)
+    vq = VQGAN(vcfg, data_format='NHWC').load_state_dict(vsd).to(dev)
+    tr = MIGT(mcfg).load_state_dict(msd).to(dev)
+    return vq, tr, (vcfg, vsd, mcfg, msd)
+
+
+def flops_per_view(S: int, localization: bool):
+    """algorithmic GFLOP per novel view, SURVEY.md §8(d)"""
+    enc, dec = 34.507, 63.053
+    gemm = 0.906 * S * 12
+    attn = 12.58e-3 * S * (S + 1) / 2 * 12
+    head = 0.101
+    tr = gemm + attn + head
+    return S * enc + dec + tr + ((gemm + attn) if localization else 0.0)
+
+
+class IgemmProfiler:
+    """HIP-event timing of every igemm launch (the dominant kernel) on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from viewformer_amd import ops
+        self._orig = ops.igemm
+        prof = self
+
+        def timed(x, w_packed, M, Cin, Cout, out, *a, **kw):
+            mode = kw.get('mode', ops.MODE_GEMM)
+            batch = kw.get('batch', 1)
+            taps = 1 if mode == ops.MODE_GEMM else 9
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = prof._orig(x, w_packed, M, Cin, Cout, out, *a, **kw)
+            e1.record()
+            prof.records.append((e0, e1, 2.0 * M * Cin * Cout * taps * batch, (mode, M, Cin, Cout, batch)))
+            return r
+        ops.igemm = timed
+        import viewformer_amd.vqgan as v
+        import viewformer_amd.migt as m
+        v.ops.igemm = timed
+        m.ops.igemm = timed
+
+    def uninstall(self):
+        from viewformer_amd import ops
+        ops.igemm = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_ms, tot_fl, by = 0.0, 0.0, {}
+        for e0, e1, fl, key in self.records:
+            ms = e0.elapsed_time(e1)
+            tot_ms += ms
+            tot_fl += fl
+            k = by.setdefault(key, [0.0, 0.0, 0])
+            k[0] += ms; k[1] += fl; k[2] += 1
+        top = sorted(by.items(), key=lambda kv: -kv[1][0])[:5]
+        return tot_ms, tot_fl, len(self.records), top
+
+
+def cpu_baseline(models_cfg, S, n_scenes, seed=123):
+    """the oracle (torch-CPU restatement of the reference path) timed on the host cores"""
+    from oracle import pipeline_oracle as po
+    from viewformer_amd.weights import synthetic_scene_batch
+    vcfg, vsd, mcfg, msd = models_cfg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    frames, cams = synthetic_scene_batch(n_scenes, S, 128, seed=seed)
+    po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames[:1], cams[:1])      # warm
+    t0 = time.time()
+    po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames, cams)
+    dt = time.time() - t0
+    return dict(value=round(n_scenes / dt, 4), unit='novel views/s', cores=cores, kind='port',
+                sample=f'{n_scenes} scenes x {S} views, fp32 torch-CPU restatement (oracle/), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=32, help='scenes per GPU per step')
+    ap.add_argument('--views', type=int, default=7, help='views per scene (6 context + 1 novel)')
+    ap.add_argument('--no-localization', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
+    args = ap.parse_args()
+
+    from viewformer_amd import sharding
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.weights import synthetic_scene_batch
+
+    rank, local, world = sharding.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback for the hot path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    localization = not args.no_localization
+    S, B = args.views, args.batch
+
+    vq, tr, models_cfg = build_models(dev, localization)
+    frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
+    frames_d = torch.from_numpy(frames).to(dev)
+    cams_d = torch.from_numpy(cams).to(dev)
+
+    def step():
+        return generate_batch_predictions(tr, vq, frames_d, cams_d)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt, dev)
+    views = sharding.sum_over_ranks(B * args.steps, dev)
+    assert out['generated_images'].dtype == torch.uint8
+
+    line = None
+    if rank == 0:
+        value = views / dt
+        gf = flops_per_view(S, localization)
+        line = {
+            'metric': 'novel views/sec (encode->AR transformer->decode), 128px 6-ctx',
+            'value': round(value, 3), 'unit': 'novel views/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SM7 codebook+transformer, 6 context views -> 1 novel view, 128x128 '
+                                   '(BASELINE.json configs[1])',
+                       'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'localization_pass': localization,
+                       'target_view_encoded': True, 'parallelism': f'scene-shard x{world}, no collective',
+                       'weights': 'random-init (deterministic generator), full-size VQGAN 67.9M + MIGT 88.4M',
+                       'algorithmic_gflop_per_view': round(gf, 1),
+                       'whole_path_tflops': round(value * gf / 1e3, 2)},
+        }
+    # ---- roofline of the dominant kernel (igemm_f32, all conv + dense layers), rank 0 only -----------
+    if rank == 0:
+        prof = IgemmProfiler()
+        prof.install()
+        step()
+        ms, fl, n, top = prof.summary()
+        prof.uninstall()
+        ach = fl / (ms * 1e-3) / 1e12
+        line['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_f32_kernel (conv3x3/1x1/dense, v_mfma_f32_32x32x2_f32)',
+                            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                            'launches_per_step': n, 'kernel_ms_per_step': round(ms, 3),
+                            'algorithmic_gflop_per_step': round(fl / 1e9, 1),
+                            'top_shapes_mode_M_Cin_Cout_batch': [
+                                {'shape': list(k), 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                 'launches': v[2]} for k, v in top]}
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = args.cpu_scenes or max(2, min(16, (os.cpu_count() or 8) // 4))
+            line['cpu_baseline'] = cpu_baseline(models_cfg, S, n_cpu)
+        print(json.dumps(line), flush=True)
+    sharding.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,160 @@
+/*
+ * vf_hip.h — C-ABI of libvf_hip.so: the MI355X (gfx950) kernels of the ViewFormer
+ * novel-view hot path (VQ-VAE codebook encode -> image-token transformer -> decode).
+ *
+ * The reference (jkulhanek/viewformer) has no FFI/plugin layer: its "operators" are
+ * PyTorch / TensorFlow framework calls.  Each entry point below replaces the framework
+ * op call site(s) cited next to it (paths relative to the reference root).  The Python
+ * host side (viewformer_amd/) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless it says host
+ *   - caller owns all buffers; no hidden allocation; workspaces are passed in and sized
+ *     by the matching *_workspace_bytes / *_packed_floats query (host-only, no GPU needed)
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *   - returns 0 (VF_OK) on success, <0 for argument errors, >0 = hipError_t of the launch;
+ *     never throws across the ABI; thread-safe for distinct streams
+ *   - activations are channels-last fp32 ("NHWC": [image][y][x][channel]); token rows are
+ *     [row][feature] fp32; codes are int64 like the reference's Torch path
+ *   - arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), so the
+ *     only difference from the fp32 reference is summation order
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_OK 0
+#define VF_ERR_BAD_ARG (-1)
+#define VF_ERR_UNSUPPORTED (-2)
+
+/* library / device introspection (host) */
+int vf_abi_version(void);                 /* bumps when a signature changes */
+const char* vf_build_arch(void);          /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM family: conv3x3 (stride 1 / stride-2 with (0,1,0,1) pad / nearest-x2
+ * upsample fused), conv1x1 and dense layers, all as
+ *     out[m][n] = epi( sum_{tap,c} pro(A_tap[m][c]) * W[tap][c][n] + bias[n] ) + res[m][n]
+ * Replaces: torch.nn.Conv2d call sites of viewformer/models/vqgan_th.py:23-27,39-49,
+ * 60-76,99-118,159,197,249,285,332-333 (F.pad :46-47 and F.interpolate :30 are folded
+ * into the gather), Conv1D.call viewformer/models/migt.py:89-96 (x @ W + b),
+ * SharedEmbeddings._linear migt.py:51-56 (h @ wte^T), tf.nn.gelu migt.py:13,70 (epilogue),
+ * residual adds vqgan_th.py:90,144 and migt.py:233,237, and — through the prologue —
+ * the GroupNorm(32, eps 1e-6)+swish of vqgan_th.py:11-17,80-85,122,222-223,315-316.
+ * ------------------------------------------------------------------------------------- */
+enum { VF_MODE_GEMM = 0, VF_MODE_CONV3_S1 = 1, VF_MODE_CONV3_S2PAD = 2, VF_MODE_CONV3_UP2 = 3 };
+enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1 };
+
+typedef struct vf_igemm_args {
+    const float* x;          /* GEMM: [M][lda]; conv: NHWC [Nimg][Hin][Win][Cin] */
+    const float* w_packed;   /* from vf_igemm_pack_f32 */
+    const float* bias;       /* [Cout] or NULL */
+    const float* res;        /* residual [M][ldr] added after the epilogue, or NULL */
+    float* out;              /* [M][ldc] (conv: NHWC [Nimg][Hout][Wout][Cout] with ldc=Cout) */
+    const float* pro_mean;   /* prologue (GroupNorm apply), all three NULL = off:          */
+    const float* pro_scale;  /*   a = (x - mean[img][c]) * scale[img][c] + beta[c]           */
+    const float* pro_beta;   /*   (mean/scale [Nimg][Cin] from vf_groupnorm_stats_f32)       */
+    int32_t pro_swish;       /* 1: a = a * sigmoid(a) after the affine                      */
+    int32_t pro_rows_per_img;/* GEMM mode: rows (pixels) per image for the prologue lookup   */
+    int32_t mode;            /* VF_MODE_*                                                   */
+    int32_t epilogue;        /* VF_EPI_*                                                    */
+    int32_t M;               /* output rows = Nimg*Hout*Wout (conv) */
+    int32_t Cin, Cout;       /* Cin must be a multiple of 32 */
+    int32_t Hin, Win, Hout, Wout;   /* conv modes only */
+    int32_t lda, ldc, ldr;   /* row strides in floats (conv: lda is ignored, = Cin) */
+    int32_t batch;           /* >=1: independent problems, pointer strides below (floats) */
+    int64_t stride_x, stride_w, stride_out, stride_res;
+} vf_igemm_args;
+
+/* floats needed for the packed form of a [taps][K][N] weight (K,N padded to the tile) */
+size_t vf_igemm_packed_floats(int K, int N, int taps);
+/* pack src (element (tap,k,n) at src[tap*st + k*sk + n*sn]) into the MFMA-fragment-major
+ * layout; OIHW conv weight: sk=taps, sn=K*taps, st=1; Conv1D [K][N]: sk=N, sn=1, st=0;
+ * transposed [N][K] (tied LM head): sk=1, sn=K, st=0.  batch>1 packs `batch` matrices
+ * (src stride src_bstride floats, dst stride = vf_igemm_packed_floats). */
+int vf_igemm_pack_f32(const float* src, float* dst, int K, int N, int taps,
+                      int64_t sk, int64_t sn, int64_t st, int batch, int64_t src_bstride, void* stream);
+int vf_igemm_f32(const vf_igemm_args* args /* host */, void* stream);
+
+/* conv_in special case: uint8 NHWC image -> x*(1/255)*2-1 -> conv3x3 (3 -> Cout), fp32 NHWC out.
+ * Replaces evaluate_transformer.py:105-108 (convert_image_dtype, *2-1) + vqgan_th.py:159,205.
+ * w is the plain OIHW [Cout][3][3][3] weight.  If img_f32 != NULL it is used instead of img_u8
+ * (already-normalised NHWC float input, the Torch-convention entry). */
+int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* w_oihw, const float* bias,
+                      float* out, int n_img, int H, int W, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) statistics.  Replaces torch.nn.GroupNorm vqgan_th.py:16-17.
+ * Produces mean_c/scale_c [Nimg][C] (scale = rstd*gamma) consumed by the igemm prologue or
+ * by vf_groupnorm_apply_f32.  ws: vf_groupnorm_workspace_bytes(...) bytes.
+ * ------------------------------------------------------------------------------------- */
+size_t vf_groupnorm_workspace_bytes(int n_img, int HW, int C);
+int vf_groupnorm_stats_f32(const float* x, const float* gamma, int n_img, int HW, int C, int groups, float eps,
+                           float* mean_c, float* scale_c, void* ws, void* stream);
+int vf_groupnorm_apply_f32(const float* x, const float* mean_c, const float* scale_c, const float* beta,
+                           float* out, int n_img, int HW, int C, int swish, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Codebook lookup.  Replaces QuantizeEMA.forward (eval) viewformer/models/utils_th.py:32-44:
+ *   dist = sum(z^2) - 2 z@E + sum(E^2);  idx = first argmax(-dist)  (ties -> lowest index)
+ * z [M][D] fp32 rows (the NHWC flatten of :34-35), E packed by vf_igemm_pack_f32(K=D, N=Kc,
+ * sk=Kc, sn=1) — use vf_vq_pack_codebook_f32 — from the reference's `embeddings` [D][Kc]; e_sq [Kc]
+ * from vf_colsumsq_f32.
+ * The [M][Kc] distance matrix is never written.  idx int64 [M].
+ * ------------------------------------------------------------------------------------- */
+size_t vf_vq_packed_floats(int D, int Kc);
+int vf_vq_pack_codebook_f32(const float* E /* [D][Kc] */, float* dst, int D, int Kc, void* stream);
+int vf_colsumsq_f32(const float* E /* [D][Kc] */, float* e_sq /* [Kc] */, int D, int Kc, void* stream);
+int vf_vq_argmin_f32(const float* z, const float* E_packed, const float* e_sq, int64_t M, int D, int Kc,
+                     int64_t* idx, void* stream);
+/* embed_code (utils_th.py:70-72): out[m][:] = E[:, idx[m]]  (NHWC rows) */
+int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, float* out /* [M][D] */,
+                           int64_t M, int D, int Kc, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Attention.
+ * vf_attn_blockcausal_f32 replaces compute_causal_block_attention + compute_attention
+ * (viewformer/models/branching_attention.py:41-61,5-18) as used by the single-stream
+ * inference graph (:82-92): scores q.k^T * scale (scale = 1: the reference has NO 1/sqrt(d)),
+ * masked entries (view(q) < view(k), view = token / L) take the value -1e4 exactly as
+ * `w*m - 1e4*(1-m)`, softmax over keys, times v.  q/k/v/out are [B][T][ld] rows with the head h
+ * at column offset h*64 (dh must be 64): it reads the fused c_attn output in place (V|Q|K thirds,
+ * migt.py:207-213) and writes merge_heads layout (migt.py:195-199).
+ * skip_masked=1 skips key tiles that are masked for the whole query tile (their softmax weight
+ * underflows to exactly 0.0f whenever the row max exceeds -1e4+104); 0 = dense reference form.
+ * L=0 disables the mask (plain softmax attention).
+ * ------------------------------------------------------------------------------------- */
+int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out,
+                            int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                            float scale, int skip_masked, void* stream);
+/* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
+int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Transformer glue.
+ * ------------------------------------------------------------------------------------- */
+/* LayerNormalization(eps) over the last dim (migt.py:225,227,292) */
+int vf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out,
+                     int64_t rows, int d, float eps, void* stream);
+/* h0[b][s][l][:] = wte[ids[b][s][l]] + wpe[l] + add[b][s][:]   (migt.py:358-368,392) */
+int vf_embed_sum_f32(const int32_t* ids, const float* wte, const float* wpe, const float* add,
+                     float* out, int64_t BS, int L, int d, int vocab, void* stream);
+/* pose MLP first layer, K=7: out[r][j] = gelu(sum_i x[r][i]*W[i][j] + b[j])  (migt.py:291,354,70) */
+int vf_dense_small_k_gelu_f32(const float* x, const float* W, const float* b, float* out,
+                              int64_t rows, int K, int N, int gelu, void* stream);
+/* first-max index over each row of n floats (tf.argmax, evaluate_transformer.py:123; ties -> lowest) */
+int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx, void* stream);
+/* clip[-1,1] -> /2+0.5 -> trunc(x*255.5) uint8  (evaluate_transformer.py:128-129, TF semantics) */
+int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

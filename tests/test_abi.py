@@ -1,0 +1,84 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/vf_hip.h declares;
+host-only queries and argument validation work without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from viewformer_amd import build, _lib
+    build.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _declared():
+    src = open(os.path.join(REPO, 'include', 'vf_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vf_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from viewformer_amd import _lib
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in vf_hip.h but not exported'
+    assert sorted(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ set(declared)
+
+
+def test_host_queries(lib):
+    assert lib.vf_abi_version() == 1
+    assert lib.vf_build_arch() == b'gfx950'
+    # [chunks=4][taps=9][nblk=1][32][128]
+    assert lib.vf_igemm_packed_floats(128, 128, 9) == 4 * 9 * 32 * 128
+    assert lib.vf_igemm_packed_floats(768, 3, 1) == 24 * 32 * 32          # N=3 padded to the 32-wide tile
+    assert lib.vf_igemm_packed_floats(0, 3, 1) == 0
+    assert lib.vf_vq_packed_floats(256, 1024) == 256 * 1024
+    assert lib.vf_vq_packed_floats(32, 64) == 32 * 128                     # codes padded to 128
+    assert lib.vf_groupnorm_workspace_bytes(4, 16384, 128) == 4 * 64 * 256 * 2 * 4
+
+
+def test_argument_validation_without_gpu(lib):
+    from viewformer_amd._lib import VfIgemmArgs
+    P = ctypes.c_void_p
+    d = P(4096)            # never dereferenced: validation happens before any launch
+    assert lib.vf_igemm_f32(None, None) == -1
+    a = VfIgemmArgs()
+    assert lib.vf_igemm_f32(ctypes.byref(a), None) == -1
+    a.x = a.w_packed = a.out = 4096
+    a.M, a.Cin, a.Cout, a.lda, a.ldc = 8, 30, 8, 32, 8
+    assert lib.vf_igemm_f32(ctypes.byref(a), None) == -2                  # Cin % 32 != 0 -> unsupported
+    a.Cin, a.mode = 32, 7
+    assert lib.vf_igemm_f32(ctypes.byref(a), None) == -1
+    assert lib.vf_layernorm_f32(d, d, d, d, 4, 6, 1e-5, None) == -2
+    assert lib.vf_layernorm_f32(None, d, d, d, 4, 8, 1e-5, None) == -1
+    assert lib.vf_vq_argmin_f32(d, d, d, 10, 30, 64, d, None) == -2       # D % 32
+    assert lib.vf_vq_argmin_f32(d, d, d, 0, 32, 64, d, None) == 0         # empty input is a no-op
+    assert lib.vf_argmax_rows_f32(d, 0, 16, 16, d, None) == 0
+    assert lib.vf_argmax_rows_f32(d, 4, 16, 8, d, None) == -1             # ld < n
+    assert lib.vf_groupnorm_stats_f32(d, d, 1, 64, 48, 32, 1e-6, d, d, d, None) == -2
+    assert lib.vf_attn_blockcausal_f32(d, d, d, d, 1, 2, 64, 64, 64, 128, 128, 128, 1.0, 1, None) == -1   # ldq < H*64
+    assert lib.vf_dense_small_k_gelu_f32(d, d, d, d, 4, 32, 8, 1, None) == -2
+    assert lib.vf_conv_in_u8_f32(None, None, d, d, d, 1, 8, 8, 32, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from viewformer_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.VfError, match='no CPU/PyTorch fallback'):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    import torch
+    from viewformer_amd import ops, _lib
+    with pytest.raises(_lib.VfError):
+        ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), 4, 128)
+    with pytest.raises(_lib.VfError):
+        ops.vq_argmin(torch.zeros(4, 32), torch.zeros(8), torch.zeros(8), 32, 64)

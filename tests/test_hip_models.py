@@ -1,0 +1,190 @@
+"""GPU: the model objects (VQGAN / MIGT / generate_batch_predictions) against the golden vectors
+recorded from the reference and against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY_MIGT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+def _vq_model(cfg, sd, dev, fmt='NCHW'):
+    from viewformer_amd.vqgan import VQGAN
+    return VQGAN(cfg, data_format=fmt).load_state_dict(sd).to(dev)
+
+
+def _maxerr(a, b):
+    return (a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ VQGAN
+def test_vqgan_tiny_matches_reference_golden(dev, tiny_vq):
+    from oracle import vqgan_oracle as vq
+    cfg, sd, g = tiny_vq
+    m = _vq_model(cfg, sd, dev)
+    x = vq.preprocess_u8(torch.from_numpy(g['frames']))
+    quant, diff, codes = m.encode(x.to(dev))
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == g['codes'].shape
+    bad = codes.cpu().numpy() != g['codes']
+    assert bad.sum() == 0, f'{bad.sum()} code mismatches; margins {g["margin"][bad.reshape(-1)]}'
+    assert _maxerr(quant, g['quant']) < 1e-5
+    assert abs(float(diff) - float(g['diff'])) < 1e-6
+    dec = m.decode_code(torch.from_numpy(g['codes']).to(dev))
+    assert _maxerr(dec, g['decoded']) < 2e-5                  # utils/testing.py tolerance class (1e-5)
+    # uint8 NHWC entry == float entry (the fused TF-style preprocess is bit-identical)
+    codes_u8 = m.encode(torch.from_numpy(g['frames']).to(dev))[-1]
+    assert torch.equal(codes_u8, codes)
+
+
+def test_vqgan_full_matches_reference_golden(dev, full_vq):
+    from viewformer_amd.weights import synthetic_scene_batch
+    cfg, sd, g = full_vq
+    m = _vq_model(cfg, sd, dev, 'NHWC')
+    frames, _ = synthetic_scene_batch(1, 4, 128, seed=int(g['input_seed']))
+    res = m.encode(torch.from_numpy(frames[0]).to(dev))
+    codes = res[-1].cpu().numpy()
+    bad = codes != g['codes']
+    assert bad.sum() == 0, f'{bad.sum()} / {bad.size} code mismatches; margins {g["margin"][bad.reshape(-1)]}'
+    z = res._z.view(4, 8, 8, 256).permute(0, 3, 1, 2)
+    assert _maxerr(z, g['z']) < 5e-5
+    dec = m.decode_code(torch.from_numpy(g['codes'][:2]).to(dev))            # NHWC out
+    assert tuple(dec.shape) == (2, 128, 128, 3)
+    assert _maxerr(dec.permute(0, 3, 1, 2), g['decoded']) < 5e-5
+
+
+def test_vqgan_batch_and_chunk_invariance(dev, full_vq):
+    """size-independent property: an image's codes / pixels do not depend on its batch-mates
+    (bit-exact), nor on max_images_per_call chunking."""
+    from viewformer_amd.weights import synthetic_scene_batch
+    cfg, sd, g = full_vq
+    m = _vq_model(cfg, sd, dev, 'NHWC')
+    frames, _ = synthetic_scene_batch(2, 5, 128, seed=9)
+    imgs = torch.from_numpy(frames.reshape(10, 128, 128, 3)).to(dev)
+    all_codes = m.encode(imgs)[-1]
+    m.max_images_per_call = 3
+    assert torch.equal(m.encode(imgs)[-1], all_codes)
+    assert torch.equal(m.encode(imgs[4:7])[-1], all_codes[4:7])
+    m.max_images_per_call = 256
+    dec = m.decode_code(all_codes)
+    assert torch.equal(m.decode_code(all_codes[7:9]), dec[7:9])
+    assert len(torch.unique(all_codes)) > 30
+
+
+def test_vqgan_load_state_dict_contract(dev, tiny_vq):
+    from viewformer_amd.vqgan import VQGAN
+    cfg, sd, _ = tiny_vq
+    m = VQGAN(cfg)
+    extra = dict(sd)
+    extra['perceptual_loss.net.weight'] = np.zeros(3, np.float32)         # ignored like vqgan_th.py:322
+    m.load_state_dict(extra)
+    missing = dict(sd)
+    del missing['quant_conv.bias']
+    with pytest.raises(RuntimeError, match='Missing keys'):
+        VQGAN(cfg).load_state_dict(missing)
+    bad = dict(sd)
+    bad['encoder.bogus'] = np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError, match='Unexpected keys'):
+        VQGAN(cfg).load_state_dict(bad)
+
+
+# ------------------------------------------------------------------------------------------------ MIGT
+def _migt(cfg, sd, dev):
+    from viewformer_amd.migt import MIGT
+    return MIGT(cfg).load_state_dict(sd).to(dev)
+
+
+@pytest.mark.parametrize('loc', [False, True])
+def test_migt_tiny_matches_oracle(dev, loc):
+    from oracle import migt_oracle as mg
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    cfg = MIGTConfig(**TINY_MIGT, localization_weight='1' if loc else '0', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=2, std=0.08)
+    g = np.random.Generator(np.random.PCG64(13))
+    B, S, t = 3, 4, cfg.token_image_size
+    ids = torch.from_numpy(g.integers(0, cfg.n_embeddings + 1, size=(B, S, t, t)))
+    _, cams = synthetic_scene_batch(B, S, 8, 4)
+    cams = mg.normalize_cameras(torch.from_numpy(cams))
+    m = _migt(cfg, sd, dev)
+    poses = cams[:, :-1] if loc else cams
+    out = m(dict(input_ids=ids.to(dev), poses=poses.to(dev)))
+    ref = mg.migt_forward(sd, cfg, ids, poses, dtype=torch.float64)
+    assert tuple(out['logits'].shape) == (B, S, t, t, cfg.n_embeddings)
+    assert _maxerr(out['logits'], ref['logits']) < 2e-4
+    assert _maxerr(out['hidden_states'][0], ref['hidden_states'][0]) < 2e-4
+    if loc:
+        assert _maxerr(out['pose_prediction'], ref['pose_prediction']) < 2e-4
+        rc = m.reduce_cameras(out['pose_prediction'][:, -1:], -2)
+        assert _maxerr(rc, mg.reduce_cameras(ref['pose_prediction'][:, -1:], -2)) < 2e-4
+
+
+def test_migt_full_config_matches_oracle(dev):
+    """BASELINE config #2 shape: 12 layers, d=768, 12 heads, 6 context views + MASK view."""
+    from oracle import migt_oracle as mg
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    cfg = MIGTConfig(sequence_size=7, localization_weight='0', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=0)
+    g = np.random.Generator(np.random.PCG64(17))
+    B, S = 2, 7
+    ids = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    ids[:, -1] = cfg.n_embeddings                       # MASK view
+    _, cams = synthetic_scene_batch(B, S, 8, 6)
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    m = _migt(cfg, sd, dev)
+    out = m(dict(input_ids=ids.to(dev), poses=cams.to(dev)))
+    ref64 = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)['logits']
+    ref32 = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float32)['logits']
+    e_hip = _maxerr(out['logits'], ref64)
+    e_cpu = _maxerr(ref32, ref64)
+    print(f'logit err vs fp64: hip {e_hip:.3e}, torch-cpu fp32 {e_cpu:.3e}; |logit| max {ref64.abs().max():.3f}')
+    assert e_hip < 1e-3                                  # stated fp32 tolerance for logits
+    assert e_hip < 20 * e_cpu + 1e-5                     # same error class as the fp32 reference arm
+    last = m(dict(input_ids=ids.to(dev), poses=cams.to(dev)), last_view_logits_only=True)['logits_last']
+    assert torch.equal(last, out['logits'][:, -1])
+    agree = (out['logits'][:, -1].argmax(-1).cpu() == ref64[:, -1].argmax(-1)).float().mean().item()
+    assert agree > 0.98, agree
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+def test_generate_batch_predictions_matches_oracle(dev, full_vq):
+    from oracle import pipeline_oracle as po
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    vcfg, vsd, _ = full_vq
+    mcfg = MIGTConfig(sequence_size=3, localization_weight='1', pose_multiplier=0.2, n_layer=4)
+    msd = make_migt_weights(mcfg, seed=1, std=0.05)
+    frames, cams = synthetic_scene_batch(2, 3, 128, seed=3)
+    ref = po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames, cams, return_intermediates=True)
+    vq_m = _vq_model(vcfg, vsd, dev, 'NHWC')
+    tr_m = _migt(mcfg, msd, dev)
+    got = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True)
+    assert got['generated_images'].dtype == torch.uint8 and tuple(got['generated_images'].shape) == (2, 128, 128, 3)
+    assert torch.equal(got['codes'].cpu(), ref['codes'])                         # context tokens bit-exact
+    assert _maxerr(got['logits_last'], ref['logits_last']) < 1e-3
+    same = got['generated_codes'].cpu() == ref['generated_codes']
+    print('generated-code agreement', same.float().mean().item())
+    assert same.float().mean() > 0.97
+    if bool(same.all()):
+        diff = (got['generated_images'].cpu().int() - ref['generated_images'].int()).abs()
+        assert diff.max() <= 1 and (diff > 0).float().mean() < 0.01         # truncation flips only
+    assert _maxerr(got['generated_cameras'], ref['generated_cameras']) < 1e-3
+    assert torch.equal(got['ground_truth_images'].cpu(), torch.from_numpy(frames[:, -1]))
+
+
+def test_no_cpu_fallback(dev, tiny_vq):
+    from viewformer_amd import ops, _lib
+    from viewformer_amd.vqgan import VQGAN
+    cfg, sd, _ = tiny_vq
+    with pytest.raises(_lib.VfError):
+        VQGAN(cfg).load_state_dict(sd).to('cpu')
+    with pytest.raises(_lib.VfError):
+        ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), 4, 128)

@@ -1,0 +1,85 @@
+"""ctypes binding of libvf_hip.so (C-ABI declared in include/vf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing/using the ops raises.  ``EXPORTS`` is the single list of symbols
+the header declares; tests check the library exports every one of them.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_float, c_void_p, c_size_t, c_char_p, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libvf_hip.so')
+
+
+class VfIgemmArgs(ctypes.Structure):
+    """mirror of ``vf_igemm_args`` (include/vf_hip.h)"""
+    _fields_ = [
+        ('x', c_void_p), ('w_packed', c_void_p), ('bias', c_void_p), ('res', c_void_p), ('out', c_void_p),
+        ('pro_mean', c_void_p), ('pro_scale', c_void_p), ('pro_beta', c_void_p),
+        ('pro_swish', c_int32), ('pro_rows_per_img', c_int32), ('mode', c_int32), ('epilogue', c_int32),
+        ('M', c_int32), ('Cin', c_int32), ('Cout', c_int32),
+        ('Hin', c_int32), ('Win', c_int32), ('Hout', c_int32), ('Wout', c_int32),
+        ('lda', c_int32), ('ldc', c_int32), ('ldr', c_int32), ('batch', c_int32),
+        ('stride_x', c_int64), ('stride_w', c_int64), ('stride_out', c_int64), ('stride_res', c_int64),
+    ]
+
+
+P = c_void_p
+# name -> (restype, argtypes)
+EXPORTS = {
+    'vf_abi_version': (c_int, []),
+    'vf_build_arch': (c_char_p, []),
+    'vf_igemm_packed_floats': (c_size_t, [c_int, c_int, c_int]),
+    'vf_igemm_pack_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int64, P]),
+    'vf_igemm_f32': (c_int, [POINTER(VfIgemmArgs), P]),
+    'vf_conv_in_u8_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_groupnorm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vf_groupnorm_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
+    'vf_groupnorm_apply_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_vq_packed_floats': (c_size_t, [c_int, c_int]),
+    'vf_vq_pack_codebook_f32': (c_int, [P, P, c_int, c_int, P]),
+    'vf_colsumsq_f32': (c_int, [P, P, c_int, c_int, P]),
+    'vf_vq_argmin_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),
+    'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_float, c_int, P]),
+    'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
+    'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
+    'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),
+    'vf_postprocess_u8': (c_int, [P, P, c_int64, P]),
+}
+
+_lib = None
+
+
+class VfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvf_hip.so (building nothing: see viewformer_amd.build).  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VfError(f'{LIB_PATH} not found — run `python -m viewformer_amd.build` (hipcc --offload-arch=gfx950). '
+                      'There is no CPU/PyTorch fallback for the hot path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status == 0:
+        return
+    if status < 0:
+        msg = {-1: 'bad argument', -2: 'unsupported shape'}.get(status, 'error')
+        raise VfError(f'{what}: {msg} ({status})')
+    raise VfError(f'{what}: HIP error {status}')

@@ -1,0 +1,58 @@
+"""Build libvf_hip.so (gfx950) in-tree with hipcc.  ``python -m viewformer_amd.build [--force]``.
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to this file so that it
+travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libvf_hip.so')
+ARCH = 'gfx950'
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'vf_hip.h'))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(HERE, 'build', os.path.basename(src)[:-4] + '.o')
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
+               '-Wall', '-Wno-unused-function']
+        if verbose:
+            cmd.append('-Rpass-analysis=kernel-resource-usage')
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or verbose:
+            sys.stderr.write(f'--- {os.path.basename(src)}\n{out}\n')
+        failed |= p.returncode != 0
+    if failed:
+        raise RuntimeError('hipcc failed')
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

@@ -1,0 +1,210 @@
+// Block-causal, un-scaled, "-1e4 masked" attention of the MIGT transformer on exact-f32 MFMA (gfx950).
+//
+// Replaces compute_causal_block_attention + compute_attention
+// (viewformer/models/branching_attention.py:41-61,5-18) reached through the single-stream branch of
+// compute_causal_block_multiend_attention (:82-92).  Semantics kept bit-for-bit in structure:
+//   w = q.k^T (NO 1/sqrt(d));  w = w*m - 1e4*(1-m) with m[i][j] = view(i) >= view(j), view = token / L;
+//   softmax over keys;  out = w.v.   The [T][T] score matrix is never materialised.
+//
+// One 256-thread workgroup = 128 query rows of one (batch, head) sharing each 64-key K/V tile through
+// LDS; with L = 64 a wave's 32 queries lie inside one view, so a key tile is either fully visible or
+// fully masked for the wave and masked tiles are skipped wave-uniformly.  Each wave owns 32 queries and
+// computes the TRANSPOSED score tile S^T[key][query] = K.Q^T (MFMA A = K tile from LDS, B = Q held
+// in 32 VGPRs), so that a lane owns one query column: the row max / row sum are in-lane over 32
+// values plus ONE cross-half shuffle, and the probabilities sit exactly in the B-operand layout of
+// the second MFMA  O^T[d][query] += V^T[d][key] . P^T[key][query]  (32x32x2: lanes 0-31 feed key a,
+// lanes 32-63 key a+4 — the C layout of S^T).  No LDS round trip or permute for P.
+// Per 64-key tile and wave: 64 + 64 MFMAs (8192 MFMA cycles) against ~200 VALU ops of softmax.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int QT = 128;     // queries per workgroup
+constexpr int KT = 64;      // keys per tile
+constexpr int K_LD = 68;    // LDS row stride of the K tile (conflict-free ds_read_b128)
+constexpr int V_LD = 64;
+
+__global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, float* __restrict__ out,
+                                                                  int T, int L, int ldq, int ldk, int ldv, int ldo,
+                                                                  float scale, int skip_masked) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int h = blockIdx.y;
+    const size_t b = blockIdx.z;
+    const int q0 = blockIdx.x * QT;
+
+    const float* qb = q + b * (size_t)T * ldq + h * DH;
+    const float* kb = k + b * (size_t)T * ldk + h * DH;
+    const float* vb = v + b * (size_t)T * ldv + h * DH;
+    float* ob = out + b * (size_t)T * ldo + h * DH;
+
+    // ---- Q fragment: qreg[g*4+e] = Q[qrow][8g + 4*half + e] ---------------------------------
+    const int qrow = q0 + wave * 32 + l31;
+    const bool qvalid = qrow < T;
+    float qreg[32];
+    {
+        const float* src = qb + (size_t)(qvalid ? qrow : 0) * ldq + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qreg[g * 4 + e] = t[e];
+        }
+    }
+    const int qview = (L > 0) ? qrow / L : 0;
+
+    // number of key tiles the workgroup / this wave must visit
+    int kmax = T, kmax_w = T;   // exclusive
+    if (L > 0 && skip_masked) {
+        const int last_q = min(q0 + QT, T) - 1;
+        kmax = min(T, (last_q / L + 1) * L);
+        const int last_qw = min(q0 + wave * 32 + 32, T) - 1;
+        kmax_w = last_qw < 0 ? 0 : min(T, (last_qw / L + 1) * L);
+        if (q0 + wave * 32 >= T) kmax_w = 0;
+    }
+    const int ntiles = (kmax + KT - 1) / KT;
+    const int ntiles_w = __builtin_amdgcn_readfirstlane((kmax_w + KT - 1) / KT);
+
+    // staging map: thread -> rows (tid>>4) + 16*i, float4 column tid&15
+    const int s_col4 = tid & 15;
+    const int s_row0 = tid >> 4;
+    f32x4 kreg[4], vreg[4];
+    auto prefetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = kt * KT + s_row0 + 16 * i;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            if (key < T) {
+                a = *reinterpret_cast<const f32x4*>(kb + (size_t)key * ldk + s_col4 * 4);
+                c = *reinterpret_cast<const f32x4*>(vb + (size_t)key * ldv + s_col4 * 4);
+            }
+            kreg[i] = a;
+            vreg[i] = c;
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+
+    prefetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(Ks + (s_row0 + 16 * i) * K_LD + s_col4 * 4) = kreg[i];
+            *reinterpret_cast<f32x4*>(Vs + (s_row0 + 16 * i) * V_LD + s_col4 * 4) = vreg[i];
+        }
+        __syncthreads();
+        if (kt + 1 < ntiles) prefetch(kt + 1);
+        if (kt >= ntiles_w) continue;   // every key of this tile is masked for this wave's 32 queries
+
+        // ---- S^T = K . Q^T ----------------------------------------------------------------
+        f32x16 st[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 a[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+                a[t2] = *reinterpret_cast<const f32x4*>(Ks + (t2 * 32 + l31) * K_LD + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+                    st[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t2][e], qreg[g * 4 + e], st[t2], 0, 0, 0);
+        }
+
+        // ---- mask + online softmax (lane = one query; its 32 keys of this tile) ----------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float s = st[t2][r] * scale;
+                if (L > 0 && (key / L) > qview) s = -1e4f;     // w*m - 1e4*(1-m)
+                if (key >= T) s = -INFINITY;                   // padding keys do not exist
+                st[t2][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);     // 0 on the first tile (m_run = -inf)
+        float psum = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(st[t2][r] - m_new);
+                st[t2][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+
+        // ---- O^T += V^T . P^T -------------------------------------------------------------
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float* vrow = Vs + key * V_LD + l31;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[d * 32], st[t2][r], ot[d], 0, 0, 0);
+            }
+    }
+
+    // ---- normalise and store: lane = query, regs 4j..4j+3 = 4 consecutive features -------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qvalid) {
+        float* orow = ob + (size_t)qrow * ldo + 4 * half;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ot[d][4 * j + e] / l_tot;
+                *reinterpret_cast<f32x4*>(orow + d * 32 + 8 * j) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int T, int L,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
+    if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
+    if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
+    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
+                       ldv, ldo, scale, skip_masked);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+// HBM-bound glue kernels of the hot path (gfx950): LayerNorm, embedding sum, tiny dense, row
+// argmax / softmax, uint8 pre/post-processing and the 3-channel conv_in.  One wave per row where a
+// row reduction is needed (64-lane shuffle reductions), float4 accesses, grid-stride loops.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm (migt.py:225,227,292)
+// one wave per row; two-pass (mean, then centred variance) on register-resident data; d <= 64*4*MAXV
+constexpr int LN_MAXV = 8;   // up to 2048 features
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out,
+                                                        long long rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = d >> 2;   // float4 per row
+    const float* xr = x + (size_t)row * d;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = vf_wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mean; q += t * t; }
+        }
+    }
+    const float var = vf_wave_sum(q) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* orow = out + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            *reinterpret_cast<f32x4*>(orow + c * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- embedding sum (migt.py:358-368,392)
+__global__ __launch_bounds__(256) void embed_sum_kernel(const int* __restrict__ ids, const float* __restrict__ wte,
+                                                        const float* __restrict__ wpe, const float* __restrict__ add,
+                                                        float* __restrict__ out, long long BS, int L, int d, int vocab) {
+    const int dq = d >> 2;
+    const long long total = BS * L * dq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dq);
+        const long long tok = i / dq;
+        const int l = (int)(tok % L);
+        const long long bs = tok / L;
+        int id = ids[tok];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wte + (size_t)id * d + c * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(wpe + (size_t)l * d + c * 4);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(add + (size_t)bs * d + c * 4);
+        // reference order: sum([tok, pos, pose]) = (tok + pos) + pose   (migt.py:332-333)
+        *reinterpret_cast<f32x4*>(out + i * 4) = (a + b) + p;
+    }
+}
+
+// ---------------------------------------------------------------- tiny dense, K <= 16 (pose c_fc, K=7)
+__global__ __launch_bounds__(256) void dense_small_k_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ b, float* __restrict__ out,
+                                                            long long rows, int K, int N, int gelu) {
+    const long long total = rows * N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const long long r = i / N;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[r * K + k], W[(size_t)k * N + n], acc);
+        acc += b ? b[n] : 0.f;
+        out[i] = gelu ? vf_gelu_erf(acc) : acc;
+    }
+}
+
+// ---------------------------------------------------------------- first-max argmax, one wave per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long long rows, int n, int ld,
+                                                          long long* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+        const float v = xr[c];
+        if (v > bv || bi == 0x7fffffff) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) idx[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+// ---------------------------------------------------------------- row softmax (in place), one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long long rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * n;
+    float mx = -INFINITY;
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c] * scale);
+    mx = vf_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) { const float e = expf(xr[c] * scale - mx); xr[c] = e; s += e; }
+    s = vf_wave_sum(s);
+    for (int c = lane; c < n; c += 64) xr[c] = xr[c] / s;
+}
+
+// ---------------------------------------------------------------- uint8 post-process
+__global__ void postprocess_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = fminf(fmaxf(x[i], -1.0f), 1.0f);   // tf.clip_by_value
+        v = v / 2.0f + 0.5f;                          // :129
+        int q = (int)(v * 255.5f);                    // convert_image_dtype: scale = max + 0.5, truncating cast
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        out[i] = (unsigned char)q;
+    }
+}
+
+// ---------------------------------------------------------------- conv_in: u8/f32 NHWC(3) -> 3x3 pad1 -> Cout
+// thread = (pixel, 4 output channels); weights [27][Cout] + bias in LDS.  Write-bound (Cout*4 B / pixel).
+__global__ __launch_bounds__(256) void conv_in_kernel(const unsigned char* __restrict__ img_u8,
+                                                      const float* __restrict__ img_f32, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int n_img, int H, int W, int Cout) {
+    extern __shared__ float sw[];   // [27][Cout] then [Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
+        const int co = i % Cout, t = i / Cout;           // t = ci*9 + ky*3 + kx  (OIHW inner order)
+        sw[i] = w[(size_t)co * 27 + t];
+    }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[27 * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int cq = Cout >> 2;
+    const long long total = (long long)n_img * H * W * cq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cq) * 4;
+        const long long pix = i / cq;
+        const int ox = (int)(pix % W);
+        const int oy = (int)((pix / W) % H);
+        const long long img = pix / ((long long)W * H);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(sw + 27 * Cout + c4);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const size_t p = ((size_t)img * H + iy) * W + ix;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    float v;
+                    if (img_f32) v = img_f32[p * 3 + ci];
+                    else v = ((float)img_u8[p * 3 + ci] * (1.0f / 255.0f)) * 2.0f - 1.0f;   // TF convert_image_dtype, *2-1
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + (ci * 9 + ky * 3 + kx) * Cout + c4);
+                    acc += v * wv;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * Cout + c4) = acc;
+    }
+}
+
+inline unsigned grid_for(long long total, int per_block, unsigned cap = 16384) {
+    long long b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int d, float eps,
+                     void* stream) {
+    if (!x || !gamma || !beta || !out || rows < 0 || d <= 0) return VF_ERR_BAD_ARG;
+    if ((d & 3) || d > 64 * 4 * LN_MAXV) return VF_ERR_UNSUPPORTED;
+    if (rows == 0) return VF_OK;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (d <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
+    else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
+    return vf_last_status();
+}
+
+int vf_embed_sum_f32(const int32_t* ids, const float* wte, const float* wpe, const float* add, float* out, int64_t BS,
+                     int L, int d, int vocab, void* stream) {
+    if (!ids || !wte || !wpe || !add || !out || BS < 0 || L <= 0 || d <= 0 || (d & 3) || vocab <= 0) return VF_ERR_BAD_ARG;
+    if (BS == 0) return VF_OK;
+    const long long total = (long long)BS * L * (d >> 2);
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, ids, wte, wpe,
+                       add, out, (long long)BS, L, d, vocab);
+    return vf_last_status();
+}
+
+int vf_dense_small_k_gelu_f32(const float* x, const float* W, const float* b, float* out, int64_t rows, int K, int N,
+                              int gelu, void* stream) {
+    if (!x || !W || !out || rows < 0 || K <= 0 || N <= 0) return VF_ERR_BAD_ARG;
+    if (K > 16) return VF_ERR_UNSUPPORTED;
+    if (rows == 0) return VF_OK;
+    hipLaunchKernelGGL(dense_small_k_kernel, dim3(grid_for((long long)rows * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, W, b, out, (long long)rows, K, N, gelu);
+    return vf_last_status();
+}
+
+int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx, void* stream) {
+    if (!x || !idx || rows < 0 || n <= 0 || ld < n) return VF_ERR_BAD_ARG;
+    if (rows == 0) return VF_OK;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)rows, n, ld, reinterpret_cast<long long*>(idx));
+    return vf_last_status();
+}
+
+int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream) {
+    if (!x || rows < 0 || n <= 0) return VF_ERR_BAD_ARG;
+    if (rows == 0) return VF_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)rows, n, scale);
+    return vf_last_status();
+}
+
+int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream) {
+    if (!x || !out || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       (long long)n);
+    return vf_last_status();
+}
+
+int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* w_oihw, const float* bias, float* out,
+                      int n_img, int H, int W, int Cout, void* stream) {
+    if ((!img_u8 && !img_f32) || !w_oihw || !out || n_img <= 0 || H <= 0 || W <= 0 || Cout <= 0) return VF_ERR_BAD_ARG;
+    if (Cout & 3) return VF_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)28 * Cout * sizeof(float);
+    if (smem > 64 * 1024) return VF_ERR_UNSUPPORTED;
+    const long long total = (long long)n_img * H * W * (Cout >> 2);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), smem, (hipStream_t)stream, img_u8,
+                       img_f32, w_oihw, bias, out, n_img, H, W, Cout);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""The evaluator's per-batch hot loop on MI355X.
+
+Drop-in for ``generate_batch_predictions(transformer_model, codebook_model, images, cameras)``
+(viewformer/evaluate/evaluate_transformer.py:97-146) and the codebook-only variant
+(viewformer/evaluate/evaluate_codebook.py:67-77): same argument meaning, same result keys.
+``images`` uint8 [B,S,H,W,3], ``cameras`` float32 [B,S,7]; tensors may be on the host or on the GPU.
+"""
+import torch
+
+from . import geometry
+from . import ops
+
+
+def generate_batch_predictions(transformer_model, codebook_model, images, cameras, return_codes: bool = False):
+    dev = codebook_model.device
+    images = torch.as_tensor(images).to(dev)
+    cameras = torch.as_tensor(cameras, dtype=torch.float32).to(dev)
+    ground_truth_cameras = cameras[:, -1]
+    transform = None
+    if transformer_model.config.augment_poses == 'relative':            # :99-101
+        cameras, transform = geometry.to_relative_cameras(cameras)
+    cameras = geometry.normalize_cameras(cameras)                       # :102
+
+    B, S = images.shape[:2]
+    t = transformer_model.config.token_image_size
+    if images.shape[2] != codebook_model.config.image_size:
+        raise NotImplementedError('resize (data/_common.py:47-61) is not on the MI355X path; feed image_size frames')
+    # encode every view, target included, exactly as the reference does (:114-116)
+    codes = codebook_model.encode(images.reshape(B * S, *images.shape[2:]))[-1]
+    codes = codes.to(torch.int32).view(B, S, t, t)                      # :110,116
+
+    ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], transformer_model.mask_token)], 1)   # :120-121
+    out = transformer_model(dict(input_ids=ids, poses=cameras), training=False, last_view_logits_only=True)
+    lg = out['logits_last']                                             # == output['logits'][:, -1]
+    nE = lg.shape[-1]
+    generated_codes = ops.argmax_rows(lg.view(-1, nE), B * t * t, nE).view(B, t, t)   # :123 (ties -> lowest index)
+
+    dec = codebook_model.decode_code(generated_codes)                   # :127
+    if codebook_model.data_format == 'NCHW':
+        dec = dec.permute(0, 2, 3, 1)
+    generated_images = ops.postprocess_u8(dec.contiguous())             # :128-129
+
+    if transformer_model.use_localization:                              # :134-136
+        out2 = transformer_model(dict(input_ids=codes, poses=cameras[:, :-1]), training=False,
+                                 last_view_logits_only=True)
+        generated_cameras = transformer_model.reduce_cameras(out2['pose_prediction'][:, -1:], -2)
+    else:
+        generated_cameras = cameras[:, :1]                              # :138
+    if transformer_model.config.augment_poses == 'relative':            # :139-140
+        generated_cameras = geometry.from_relative_cameras(generated_cameras, transform)
+    res = dict(ground_truth_images=images[:, -1], generated_images=generated_images,
+               ground_truth_cameras=ground_truth_cameras, generated_cameras=generated_cameras[:, -1])
+    if return_codes:
+        res.update(codes=codes, generated_codes=generated_codes, logits_last=lg, decoded=dec)
+    return res
+
+
+def codebook_batch_predictions(codebook_model, images):
+    """evaluate_codebook.py:67-77 — encode -> decode round trip (BASELINE config #1)."""
+    dev = codebook_model.device
+    images = torch.as_tensor(images).to(dev)
+    codes = codebook_model.encode(images)[-1]
+    dec = codebook_model.decode_code(codes)
+    if codebook_model.data_format == 'NCHW':
+        dec = dec.permute(0, 2, 3, 1)
+    return dict(ground_truth_images=images, generated_images=ops.postprocess_u8(dec.contiguous()), codes=codes)

@@ -1,0 +1,204 @@
+"""MIGT image-token transformer on MI355X — host-side mirror of the reference model object.
+
+Protocol (reference viewformer/models/migt.py:241-455):
+``model(dict(input_ids=[B,S,t,t] int, poses=[B,S or S-1,7] f32), training=False)
+  -> dict(logits=[B,S,t,t,n_embeddings] f32, pose_prediction=[B,S,L,7] (if use_localization),
+          hidden_states=[...])``, attributes ``mask_token``, ``use_localization``, ``config``,
+``reduce_cameras(x, axis)``.  Inference graph only in this file (single stream:
+evaluate_transformer.py:119-123,134-136); the multi-stream training/multictx graph is a
+"next" row.
+
+All arithmetic runs in libvf_hip.so: embedding-sum, LayerNorm, fused c_attn GEMM whose V|Q|K
+thirds are read in place by the block-causal attention kernel, c_proj/MLP GEMMs with fused
+bias / exact-erf GELU / residual epilogues, tied LM head.  torch = memory + stream only
+(plus O(B*S) pose bookkeeping on [B,S,7] tensors).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from . import geometry
+from .config import MIGTConfig
+
+
+class _Dense:
+    __slots__ = ('wp', 'bias', 'k', 'n', 'w_raw')
+
+
+class MIGT:
+    def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True):
+        self.config = config or MIGTConfig()
+        c = self.config
+        self.n_image_tokens = c.token_image_size ** 2
+        self.mask_token = c.n_embeddings                      # migt.py:256
+        self.localization_token = c.n_embeddings + 1          # migt.py:257
+        self.use_localization = c.use_localization            # migt.py:269
+        self.device = torch.device(device) if device is not None else None
+        self.skip_masked = skip_masked
+        self._sd_host = None
+        self._dense = {}
+        self._ln = {}
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ops._lib.VfError('viewformer_amd.MIGT runs on the GPU only (no CPU fallback)')
+        self.device = device
+        if self._sd_host is not None:
+            self._upload()
+        return self
+
+    def expected_keys(self):
+        c = self.config
+        keys = ['wte.weight', 'wpe.embeddings']
+        dense = ['pose_embedding.c_fc', 'pose_embedding.c_proj',
+                 'pose_criterion.pose_classifier.c_fc', 'pose_criterion.pose_classifier.c_proj']
+        lns = ['ln_f']
+        for i in range(c.n_layer):
+            dense += [f'h.{i}.attn.c_attn', f'h.{i}.attn.c_proj', f'h.{i}.mlp.c_fc', f'h.{i}.mlp.c_proj']
+            lns += [f'h.{i}.ln_1', f'h.{i}.ln_2']
+        for d in dense:
+            keys += [d + '.weight', d + '.bias']
+        for l in lns:
+            keys += [l + '.gamma', l + '.beta']
+        return keys
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        if strict:
+            want, have = set(self.expected_keys()), set(state_dict.keys())
+            if want - have:
+                raise RuntimeError(f'Missing keys: {want - have}')
+            if have - want:
+                raise RuntimeError(f'Unexpected keys: {have - want}')
+        host = OrderedDict()
+        for k, v in state_dict.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            host[k] = np.ascontiguousarray(v).reshape(-1) if k.endswith('.bias') else np.ascontiguousarray(v)
+        self._sd_host = host
+        if self.device is not None:
+            self._upload()
+        return self
+
+    def _upload(self):
+        dev, h, c = self.device, self._sd_host, self.config
+
+        def dev_t(name):
+            return torch.from_numpy(h[name]).to(dev, torch.float32).contiguous()
+
+        def dense(name, pack=True):
+            d = _Dense()
+            w = dev_t(name + '.weight')
+            d.k, d.n = w.shape
+            d.bias = dev_t(name + '.bias')
+            d.w_raw = w
+            d.wp = ops.pack_dense_kn(w) if (pack and d.k % 32 == 0) else None
+            self._dense[name] = d
+
+        def ln(name):
+            self._ln[name] = (dev_t(name + '.gamma'), dev_t(name + '.beta'))
+
+        self._wte = dev_t('wte.weight')
+        self._wpe = dev_t('wpe.embeddings')
+        self._lm_head = ops.pack_dense_nk(self._wte, n_rows=c.n_embeddings)    # logits sliced to n_embeddings (migt.py:417)
+        dense('pose_embedding.c_fc', pack=False)
+        dense('pose_embedding.c_proj')
+        dense('pose_criterion.pose_classifier.c_fc')
+        dense('pose_criterion.pose_classifier.c_proj')
+        for i in range(c.n_layer):
+            ln(f'h.{i}.ln_1'); ln(f'h.{i}.ln_2')
+            for p in ('attn.c_attn', 'attn.c_proj', 'mlp.c_fc', 'mlp.c_proj'):
+                dense(f'h.{i}.{p}')
+        ln('ln_f')
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------ helpers
+    def _gemm(self, x, name, M, epilogue=ops.EPI_NONE, res=None):
+        d = self._dense[name]
+        out = torch.empty((M, d.n), dtype=torch.float32, device=x.device)
+        ops.igemm(x, d.wp, M, d.k, d.n, out, bias=d.bias, res=res, epilogue=epilogue)
+        return out
+
+    def _pose_embed(self, poses):
+        """pose_embedding(get_model_input(poses)) — migt.py:139-145,291,354 (fp32; multiplier 1 at inference)"""
+        B, Sp, _ = poses.shape
+        c = self.config
+        pin = geometry.pose_model_input(poses, c.pose_multiplier).reshape(B * Sp, 7).contiguous()
+        fc = self._dense['pose_embedding.c_fc']
+        h1 = ops.dense_small_k(pin, fc.w_raw, fc.bias, B * Sp, 7, fc.n, gelu=True)
+        return self._gemm(h1, 'pose_embedding.c_proj', B * Sp).view(B, Sp, c.d_model)
+
+    def reduce_cameras(self, cameras, axis=-2):
+        """MIGT.reduce_cameras, migt.py:532-533"""
+        return geometry.reduce_cameras(cameras, axis)
+
+    # ------------------------------------------------------------------ forward (single stream, inference)
+    def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False):
+        if training or compute_losses:
+            raise NotImplementedError('training / multi-stream graph is not built yet (SURVEY.md §8 row a18)')
+        if inputs.get('localization_tokens') is not None or inputs.get('output_poses') is not None:
+            raise NotImplementedError('multi-context streams (output_poses / localization_tokens) are a "next" row')
+        if self._sd_host is None or self.device is None:
+            raise RuntimeError('MIGT: load_state_dict() and .to("cuda") first')
+        c, dev = self.config, self.device
+        ids = inputs['input_ids'].to(dev)
+        poses = inputs['poses'].to(dev)
+        if poses.dtype != torch.float32:
+            raise TypeError('poses must be float32 (migt.py:346)')
+        orig_shape = tuple(ids.shape)
+        B, S = orig_shape[:2]
+        L = int(np.prod(orig_shape[2:]))
+        d, H = c.d_model, c.n_head
+        T, M = S * L, B * S * L
+        if d // H != 64:
+            raise ops._lib.VfError('attention kernel supports head dim 64 only')
+
+        pose_emb = self._pose_embed(poses)                                   # [B,Sp,d]
+        Sp = pose_emb.shape[1]
+        if self.use_localization and S - Sp > 0:                             # migt.py:387-390
+            lpe = self._wte[self.localization_token].view(1, 1, d).expand(B, S - Sp, d)
+            pose_emb = torch.cat([pose_emb, lpe], 1)
+        elif Sp != S:
+            raise ValueError(f'poses has {Sp} views but input_ids has {S}')
+        add = pose_emb.contiguous().view(B * S, d)
+        ids32 = ids.reshape(B * S * L).to(torch.int32).contiguous()
+        h = ops.embed_sum(ids32, self._wte, self._wpe, add, B * S, L, d, c.n_embeddings + 2)   # migt.py:392
+
+        qkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
+        att = torch.empty((M, d), dtype=torch.float32, device=dev)
+        for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
+            p = f'h.{i}'
+            a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d)
+            ca = self._dense[p + '.attn.c_attn']
+            ops.igemm(a, ca.wp, M, d, 3 * d, qkv, bias=ca.bias)
+            # thirds are (V, Q, K): migt.py:207-213
+            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
+                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked)
+            h = self._gemm(att, p + '.attn.c_proj', M, res=h)
+            m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
+            f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
+            h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
+        hf = ops.layernorm(h, *self._ln['ln_f'], M, d)                      # migt.py:408
+
+        out = dict(hidden_states=[hf.view(B, S, L, d)])
+        nE = c.n_embeddings
+        if last_view_logits_only:
+            hl = hf.view(B, S, L, d)[:, -1].contiguous().view(B * L, d)
+            lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
+            ops.igemm(hl, self._lm_head, B * L, d, nE, lg)
+            out['logits_last'] = lg.view(B, *orig_shape[2:], nE)
+        else:
+            lg = torch.empty((M, nE), dtype=torch.float32, device=dev)
+            ops.igemm(hf, self._lm_head, M, d, nE, lg)                       # migt.py:417,51-56
+            out['logits'] = lg.view(*orig_shape, nE)
+        if self.use_localization:                                            # migt.py:430-451
+            p1 = self._gemm(hf, 'pose_criterion.pose_classifier.c_fc', M, epilogue=ops.EPI_GELU)
+            p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', M)
+            out['pose_prediction'] = geometry.pose_head_postprocess(p2.view(B, S, L, 7), c.pose_multiplier)
+        out['loss'] = 0
+        return out

@@ -1,0 +1,220 @@
+"""Thin tensor-level wrappers over the C-ABI (include/vf_hip.h).
+
+PyTorch is used for device memory and the stream handle only: every wrapper hands raw
+device pointers to libvf_hip.so and launches on torch's current HIP stream.  Nothing here
+computes with torch ops, and nothing falls back to them.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import VfIgemmArgs, check
+
+MODE_GEMM, MODE_CONV3_S1, MODE_CONV3_S2PAD, MODE_CONV3_UP2 = 0, 1, 2, 3
+EPI_NONE, EPI_GELU = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name='tensor'):
+    if not t.is_cuda:
+        raise _lib.VfError(f'{name} must live on the GPU (no CPU fallback for the hot path)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    return t
+
+
+def _f32(t, name='tensor'):
+    return _chk(t, torch.float32, name)
+
+
+# ------------------------------------------------------------------ weight packing
+def packed_floats(K, N, taps=1):
+    return int(_lib.load().vf_igemm_packed_floats(K, N, taps))
+
+
+def pack(src, K, N, taps, sk, sn, st, batch=1, src_bstride=0, out=None):
+    """pack element (tap,k,n) = src[tap*st + k*sk + n*sn] into the fragment-major layout"""
+    lib = _lib.load()
+    n = packed_floats(K, N, taps)
+    if out is None:
+        out = torch.empty(batch * n, dtype=torch.float32, device=src.device)
+    check(lib.vf_igemm_pack_f32(_p(_f32(src)), _p(out), K, N, taps, sk, sn, st, batch, src_bstride, _stream()),
+          'vf_igemm_pack_f32')
+    return out
+
+
+def pack_conv_oihw(w):
+    """torch Conv2d weight [Cout][Cin][kh][kw], kh=kw in {1,3}"""
+    w = _f32(w).contiguous()
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    return pack(w, cin, cout, taps, sk=taps, sn=cin * taps, st=1)
+
+
+def pack_dense_kn(w):
+    """Conv1D weight [nx][nf] (x @ W)"""
+    w = _f32(w).contiguous()
+    k, n = w.shape
+    return pack(w, k, n, 1, sk=n, sn=1, st=0)
+
+
+def pack_dense_nk(w, n_rows=None):
+    """transposed weight [N][K] (x @ W^T), optionally only the first n_rows rows"""
+    w = _f32(w).contiguous()
+    n, k = w.shape
+    n = n if n_rows is None else n_rows
+    return pack(w, k, n, 1, sk=1, sn=k, st=0)
+
+
+# ------------------------------------------------------------------ implicit GEMM
+def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
+          pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0):
+    lib = _lib.load()
+    a = VfIgemmArgs()
+    a.x = x.data_ptr()
+    a.w_packed = w_packed.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.out = out.data_ptr()
+    if pro is not None:
+        mean_c, scale_c, beta = pro
+        a.pro_mean, a.pro_scale, a.pro_beta = mean_c.data_ptr(), scale_c.data_ptr(), beta.data_ptr()
+    a.pro_swish = 1 if pro_swish else 0
+    a.pro_rows_per_img = pro_rows_per_img
+    a.mode, a.epilogue = mode, epilogue
+    a.M, a.Cin, a.Cout = M, Cin, Cout
+    a.Hin, a.Win, a.Hout, a.Wout = Hin, Win, Hout, Wout
+    a.lda = Cin if lda is None else lda
+    a.ldc = Cout if ldc is None else ldc
+    a.ldr = (Cout if ldr is None else ldr)
+    a.batch = batch
+    a.stride_x, a.stride_w, a.stride_out, a.stride_res = stride_x, stride_w, stride_out, stride_res
+    for t in (x, w_packed, out, bias, res):
+        if t is not None:
+            _f32(t)
+    check(lib.vf_igemm_f32(ctypes.byref(a), _stream()), 'vf_igemm_f32')
+    return out
+
+
+def conv_in(img, w_oihw, bias, n_img, H, W, Cout, out=None):
+    """img: uint8 NHWC [n,H,W,3] (TF evaluator entry) or float32 NHWC already in [-1,1]"""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((n_img, H, W, Cout), dtype=torch.float32, device=img.device)
+    if img.dtype == torch.uint8:
+        u8, f32 = _p(_chk(img, torch.uint8)), None
+    else:
+        u8, f32 = None, _p(_f32(img))
+    check(lib.vf_conv_in_u8_f32(u8, f32, _p(_f32(w_oihw)), _p(bias), _p(out), n_img, H, W, Cout, _stream()),
+          'vf_conv_in_u8_f32')
+    return out
+
+
+# ------------------------------------------------------------------ GroupNorm
+def groupnorm_stats(x, gamma, n_img, HW, C, groups=32, eps=1e-6):
+    lib = _lib.load()
+    mean_c = torch.empty((n_img, C), dtype=torch.float32, device=x.device)
+    scale_c = torch.empty((n_img, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(lib.vf_groupnorm_workspace_bytes(n_img, HW, C)), dtype=torch.uint8, device=x.device)
+    check(lib.vf_groupnorm_stats_f32(_p(_f32(x)), _p(_f32(gamma)), n_img, HW, C, groups, eps, _p(mean_c), _p(scale_c),
+                                     _p(ws), _stream()), 'vf_groupnorm_stats_f32')
+    return mean_c, scale_c
+
+
+def groupnorm_apply(x, mean_c, scale_c, beta, n_img, HW, C, swish, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vf_groupnorm_apply_f32(_p(_f32(x)), _p(mean_c), _p(scale_c), _p(_f32(beta)), _p(out), n_img, HW, C,
+                                     1 if swish else 0, _stream()), 'vf_groupnorm_apply_f32')
+    return out
+
+
+# ------------------------------------------------------------------ codebook
+def vq_pack_codebook(E):
+    lib = _lib.load()
+    E = _f32(E).contiguous()
+    D, Kc = E.shape
+    out = torch.empty(int(lib.vf_vq_packed_floats(D, Kc)), dtype=torch.float32, device=E.device)
+    check(lib.vf_vq_pack_codebook_f32(_p(E), _p(out), D, Kc, _stream()), 'vf_vq_pack_codebook_f32')
+    e_sq = torch.empty(Kc, dtype=torch.float32, device=E.device)
+    check(lib.vf_colsumsq_f32(_p(E), _p(e_sq), D, Kc, _stream()), 'vf_colsumsq_f32')
+    return out, e_sq
+
+
+def vq_argmin(z_rows, E_packed, e_sq, D, Kc):
+    lib = _lib.load()
+    z_rows = _f32(z_rows)
+    M = z_rows.numel() // D
+    idx = torch.empty(M, dtype=torch.int64, device=z_rows.device)
+    check(lib.vf_vq_argmin_f32(_p(z_rows), _p(E_packed), _p(e_sq), M, D, Kc, _p(idx), _stream()), 'vf_vq_argmin_f32')
+    return idx
+
+
+def codebook_gather(E, idx, D, Kc):
+    lib = _lib.load()
+    idx = _chk(idx, torch.int64, 'codes').contiguous()
+    M = idx.numel()
+    out = torch.empty((M, D), dtype=torch.float32, device=idx.device)
+    check(lib.vf_codebook_gather_f32(_p(_f32(E)), _p(idx), _p(out), M, D, Kc, _stream()), 'vf_codebook_gather_f32')
+    return out
+
+
+# ------------------------------------------------------------------ attention / transformer glue
+def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True):
+    lib = _lib.load()
+    check(lib.vf_attn_blockcausal_f32(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
+                                      ldo, scale, 1 if skip_masked else 0, _stream()), 'vf_attn_blockcausal_f32')
+    return out
+
+
+def softmax_rows_(x, rows, n, scale=1.0):
+    check(_lib.load().vf_softmax_rows_f32(_p(_f32(x)), rows, n, scale, _stream()), 'vf_softmax_rows_f32')
+    return x
+
+
+def layernorm(x, gamma, beta, rows, d, eps=1e-5, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vf_layernorm_f32(_p(_f32(x)), _p(_f32(gamma)), _p(_f32(beta)), _p(out), rows, d, eps, _stream()),
+          'vf_layernorm_f32')
+    return out
+
+
+def embed_sum(ids_i32, wte, wpe, add, BS, L, d, vocab):
+    out = torch.empty((BS * L, d), dtype=torch.float32, device=wte.device)
+    check(_lib.load().vf_embed_sum_f32(_p(_chk(ids_i32, torch.int32, 'ids')), _p(_f32(wte)), _p(_f32(wpe)),
+                                       _p(_f32(add)), _p(out), BS, L, d, vocab, _stream()), 'vf_embed_sum_f32')
+    return out
+
+
+def dense_small_k(x, W, b, rows, K, N, gelu):
+    out = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_dense_small_k_gelu_f32(_p(_f32(x)), _p(_f32(W)), _p(b), _p(out), rows, K, N,
+                                                1 if gelu else 0, _stream()), 'vf_dense_small_k_gelu_f32')
+    return out
+
+
+def argmax_rows(x, rows, n, ld=None):
+    idx = torch.empty(rows, dtype=torch.int64, device=x.device)
+    check(_lib.load().vf_argmax_rows_f32(_p(_f32(x)), rows, n, n if ld is None else ld, _p(idx), _stream()),
+          'vf_argmax_rows_f32')
+    return idx
+
+
+def postprocess_u8(x):
+    x = _f32(x).contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.load().vf_postprocess_u8(_p(x), _p(out), x.numel(), _stream()), 'vf_postprocess_u8')
+    return out

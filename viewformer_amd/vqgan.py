@@ -1,0 +1,341 @@
+"""VQGAN codebook model on MI355X — host-side mirror of the reference's model object.
+
+Mirrors the duck-typed protocol every reference caller uses:
+``.config``, ``.encode(x) -> (quant, diff, codes[int64])``, ``.decode(quant)``,
+``.decode_code(codes)``, ``.to(device)``, ``load_state_dict`` with the reference's key set
+(viewformer/models/vqgan_th.py:321-398, utils_th.py:8-72).  Two calling conventions:
+``data_format='NCHW'`` = the Torch model (vqgan_th.py), ``'NHWC'`` = its TF twin
+(viewformer/models/vqgan.py:291-301) that the evaluators call.
+
+All arithmetic runs in libvf_hip.so (channels-last fp32, exact-f32 MFMA implicit GEMM, GroupNorm
+statistics + apply fused into the consuming conv, on-chip codebook argmin).  torch is used for
+device allocations, views and the stream only.
+"""
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import VQGANConfig
+from .weights import vqgan_layout
+
+_IGNORED = re.compile(r'(perceptual_loss\..*)|(loss\..*)')     # vqgan_th.py:322
+
+
+class _Conv:
+    __slots__ = ('wp', 'bias', 'cin', 'cout', 'k', 'w_raw')
+
+
+class VQGAN:
+    def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 256):
+        self.config = config or VQGANConfig()
+        assert data_format in ('NCHW', 'NHWC')
+        self.data_format = data_format
+        self.device = torch.device(device) if device is not None else None
+        self.max_images_per_call = max_images_per_call
+        self._enc_plan, self._dec_plan = vqgan_layout(self.config)
+        self._sd = None          # reference-keyed fp32 tensors on the device
+        self._conv = {}
+        self._norm = {}
+        self._qkv = {}
+        self.training = False
+
+    # ------------------------------------------------------------------ module-ish API
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ops._lib.VfError('viewformer_amd.VQGAN runs on the GPU only (no CPU fallback)')
+        self.device = device
+        if self._sd_host is not None:
+            self._upload()
+        return self
+
+    _sd_host = None
+
+    def expected_keys(self):
+        keys = []
+        for kind, name, args in self._enc_plan + self._dec_plan:
+            if kind in ('conv3', 'down', 'up'):
+                keys += [name + '.weight', name + '.bias']
+            elif kind == 'res':
+                for p in ('norm1', 'conv1', 'norm2', 'conv2'):
+                    keys += [f'{name}.{p}.weight', f'{name}.{p}.bias']
+                if args[0] != args[1]:
+                    keys += [f'{name}.nin_shortcut.weight', f'{name}.nin_shortcut.bias']
+            elif kind == 'attn':
+                for p in ('norm', 'q', 'k', 'v', 'proj_out'):
+                    keys += [f'{name}.{p}.weight', f'{name}.{p}.bias']
+            elif kind == 'norm_swish':
+                keys += [name + '.weight', name + '.bias']
+        keys += ['quant_conv.weight', 'quant_conv.bias', 'post_quant_conv.weight', 'post_quant_conv.bias',
+                 'quantize.embeddings', 'quantize.ema_cluster_size_hidden', 'quantize.ema_dw_hidden', 'quantize.counter']
+        return keys
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Same contract as vqgan_th.py:346-359: metric/loss keys are ignored, otherwise
+        missing / unexpected keys raise RuntimeError."""
+        sd = {k: v for k, v in state_dict.items() if not _IGNORED.match(k)}
+        if strict:
+            want = set(self.expected_keys())
+            have = set(sd.keys())
+            if want - have:
+                raise RuntimeError(f'Missing keys: {want - have}')
+            if have - want:
+                raise RuntimeError(f'Unexpected keys: {have - want}')
+        host = OrderedDict()
+        for k, v in sd.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            host[k] = np.ascontiguousarray(v)
+        self._sd_host = host
+        if self.device is not None:
+            self._upload()
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(v)) for k, v in self._sd_host.items())
+
+    # ------------------------------------------------------------------ weight upload / packing
+    def _upload(self):
+        dev = self.device
+        h = self._sd_host
+        self._conv, self._norm, self._qkv = {}, {}, {}
+
+        def dev_t(name):
+            return torch.from_numpy(h[name]).to(dev, torch.float32).contiguous()
+
+        def conv(name):
+            w = dev_t(name + '.weight')
+            c = _Conv()
+            c.cout, c.cin, c.k = w.shape[0], w.shape[1], w.shape[2]
+            c.bias = dev_t(name + '.bias')
+            c.w_raw = w
+            c.wp = ops.pack_conv_oihw(w) if c.cin % 32 == 0 else None
+            self._conv[name] = c
+
+        def norm(name):
+            self._norm[name] = (dev_t(name + '.weight'), dev_t(name + '.bias'))
+
+        for kind, name, args in self._enc_plan + self._dec_plan:
+            if kind in ('conv3', 'down', 'up'):
+                conv(name)
+            elif kind == 'res':
+                norm(name + '.norm1'); conv(name + '.conv1'); norm(name + '.norm2'); conv(name + '.conv2')
+                if args[0] != args[1]:
+                    conv(name + '.nin_shortcut')
+            elif kind == 'attn':
+                norm(name + '.norm')
+                c = args[0]
+                # fused q|k|v projection: one [C][3C] GEMM
+                w = torch.cat([dev_t(f'{name}.{p}.weight').reshape(c, c) for p in ('q', 'k', 'v')], 0)   # [3C][C] (out,in)
+                b = torch.cat([dev_t(f'{name}.{p}.bias') for p in ('q', 'k', 'v')], 0)
+                self._qkv[name] = (ops.pack_dense_nk(w), b)
+                conv(name + '.proj_out')
+            elif kind == 'norm_swish':
+                norm(name)
+        conv('quant_conv')
+        conv('post_quant_conv')
+        self._E = dev_t('quantize.embeddings')                      # [D][Kc]
+        self._E_packed, self._e_sq = ops.vq_pack_codebook(self._E)
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------ building blocks (NHWC rows)
+    def _conv3(self, x, name, n, H, W, mode=ops.MODE_CONV3_S1, pro=None, pro_swish=True, res=None):
+        c = self._conv[name]
+        if mode == ops.MODE_CONV3_S2PAD:
+            Ho, Wo = H // 2, W // 2
+        elif mode == ops.MODE_CONV3_UP2:
+            Ho, Wo = H * 2, W * 2
+        else:
+            Ho, Wo = H, W
+        out = torch.empty((n * Ho * Wo, c.cout), dtype=torch.float32, device=x.device)
+        ops.igemm(x, c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode, pro=pro,
+                  pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo)
+        return out, Ho, Wo
+
+    def _conv1(self, x, name, M, pro=None, pro_swish=False, rows_per_img=0, res=None):
+        c = self._conv[name]
+        out = torch.empty((M, c.cout), dtype=torch.float32, device=x.device)
+        ops.igemm(x, c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro, pro_swish=pro_swish,
+                  pro_rows_per_img=rows_per_img)
+        return out
+
+    def _gn(self, x, name, n, HW, C):
+        gamma, beta = self._norm[name]
+        mean_c, scale_c = ops.groupnorm_stats(x, gamma, n, HW, C, 32, 1e-6)
+        return (mean_c, scale_c, beta)
+
+    def _res(self, x, name, n, H, W, cin, cout):
+        """ResnetBlock.forward, vqgan_th.py:78-90"""
+        p1 = self._gn(x, name + '.norm1', n, H * W, cin)
+        h, _, _ = self._conv3(x, name + '.conv1', n, H, W, pro=p1)
+        p2 = self._gn(h, name + '.norm2', n, H * W, cout)
+        sc = x if cin == cout else self._conv1(x, name + '.nin_shortcut', n * H * W)
+        out, _, _ = self._conv3(h, name + '.conv2', n, H, W, pro=p2, res=sc)
+        return out
+
+    def _attn(self, x, name, n, H, W, C):
+        """AttnBlock.forward, vqgan_th.py:120-144"""
+        HW = H * W
+        M = n * HW
+        pro = self._gn(x, name + '.norm', n, HW, C)
+        wp, b = self._qkv[name]
+        qkv = torch.empty((M, 3 * C), dtype=torch.float32, device=x.device)
+        ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        # scores[b] = q_b @ k_b^T : B[kk=c][nn=key] = k[key][c]
+        kp = ops.pack(k, C, HW, 1, sk=1, sn=3 * C, st=0, batch=n, src_bstride=HW * 3 * C)
+        S = torch.empty((n, HW, HW), dtype=torch.float32, device=x.device)
+        ops.igemm(q, kp, HW, C, HW, S, lda=3 * C, batch=n, stride_x=HW * 3 * C,
+                  stride_w=ops.packed_floats(C, HW), stride_out=HW * HW)
+        ops.softmax_rows_(S, n * HW, HW, float(int(C) ** (-0.5)))
+        # out[b] = P_b @ v_b : B[kk=key][nn=c] = v[key][c]
+        vp = ops.pack(v, HW, C, 1, sk=3 * C, sn=1, st=0, batch=n, src_bstride=HW * 3 * C)
+        a = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        ops.igemm(S, vp, HW, HW, C, a, lda=HW, batch=n, stride_x=HW * HW, stride_w=ops.packed_floats(HW, C),
+                  stride_out=HW * C)
+        return self._conv1(a, name + '.proj_out', M, res=x)
+
+    def _run_plan(self, plan, x, n, H, W, first_is_image=False):
+        for kind, name, args in plan:
+            if kind == 'conv3':
+                c = self._conv[name]
+                if c.wp is None:      # 3-channel conv_in (fused uint8 -> [-1,1])
+                    x = ops.conv_in(x, c.w_raw, c.bias, n, H, W, c.cout).view(n * H * W, c.cout)
+                else:
+                    x, H, W = self._conv3(x, name, n, H, W, pro=self._pending_pro, pro_swish=True)
+                self._pending_pro = None
+            elif kind == 'res':
+                x = self._res(x, name, n, H, W, args[0], args[1])
+            elif kind == 'attn':
+                x = self._attn(x, name, n, H, W, args[0])
+            elif kind == 'down':
+                x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_S2PAD)
+            elif kind == 'up':
+                x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_UP2)
+            elif kind == 'norm_swish':
+                self._pending_pro = self._gn(x, name, n, H * W, args[0])   # folded into the next conv
+        return x, H, W
+
+    _pending_pro = None
+
+    # ------------------------------------------------------------------ encoder / decoder on NHWC
+    def _encode_nhwc(self, img):
+        """img: [n,H,W,3] uint8 or float32 in [-1,1] -> (z rows [n*h*w, D], codes [n,h,w] int64)"""
+        n, H, W, _ = img.shape
+        x, h, w = self._run_plan(self._enc_plan, img.contiguous(), n, H, W)
+        z = self._conv1(x, 'quant_conv', n * h * w)                     # vqgan_th.py:381
+        cfg = self.config
+        codes = ops.vq_argmin(z, self._E_packed, self._e_sq, cfg.embed_dim, cfg.n_embed)
+        return z, codes.view(n, h, w)
+
+    def _decode_rows(self, q_rows, n, h, w):
+        """q_rows [n*h*w, D] -> NHWC float [n,H,W,out_ch]"""
+        x = self._conv1(q_rows, 'post_quant_conv', n * h * w)            # vqgan_th.py:386
+        x, H, W = self._run_plan(self._dec_plan, x, n, h, w)
+        return x.view(n, H, W, self.config.out_ch)
+
+    def _chunks(self, n):
+        m = self.max_images_per_call
+        return [(i, min(n, i + m)) for i in range(0, n, m)]
+
+    # ------------------------------------------------------------------ public protocol
+    def _to_nhwc(self, x):
+        if x.dtype == torch.uint8:
+            return x                                                    # evaluator entry: NHWC uint8
+        return x.permute(0, 2, 3, 1) if self.data_format == 'NCHW' else x
+
+    def encode(self, x):
+        """VQGAN.encode (vqgan_th.py:379-383 / vqgan.py:291-295): -> (quant, diff, codes int64)."""
+        self._require_ready()
+        x = self._to_nhwc(x.to(self.device))
+        n = x.shape[0]
+        zs, cs = [], []
+        for a, b in self._chunks(n):
+            z, c = self._encode_nhwc(x[a:b])
+            zs.append(z)
+            cs.append(c)
+        z = torch.cat(zs, 0) if len(zs) > 1 else zs[0]
+        codes = torch.cat(cs, 0) if len(cs) > 1 else cs[0]
+        return _LazyEncodeResult(self, z, codes)
+
+    def encode_codes(self, x):
+        """codes only (what every hot-path caller takes: ``encode(x)[-1]``)."""
+        return self.encode(x)[-1]
+
+    def decode_code(self, code_b):
+        """VQGAN.decode_code (vqgan_th.py:390-393 / vqgan.py:297-301)."""
+        self._require_ready()
+        cfg = self.config
+        codes = code_b.to(self.device).to(torch.int64).contiguous()
+        n, h, w = codes.shape
+        outs = []
+        for a, b in self._chunks(n):
+            q = ops.codebook_gather(self._E, codes[a:b], cfg.embed_dim, cfg.n_embed)   # embed_code, utils_th.py:70-72
+            outs.append(self._decode_rows(q, b - a, h, w))
+        out = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        return out.permute(0, 3, 1, 2) if self.data_format == 'NCHW' else out
+
+    def decode(self, quant):
+        """VQGAN.decode (vqgan_th.py:385-388); quant in the model's data_format."""
+        self._require_ready()
+        q = quant.to(self.device)
+        q = q.permute(0, 2, 3, 1) if self.data_format == 'NCHW' else q
+        n, h, w, d = q.shape
+        out = self._decode_rows(q.contiguous().view(n * h * w, d), n, h, w)
+        return out.permute(0, 3, 1, 2) if self.data_format == 'NCHW' else out
+
+    def __call__(self, x):
+        """VQGAN.forward (vqgan_th.py:395-398): (dec, diff, quant, codes)."""
+        quant, diff, codes = self.encode(x)
+        return self.decode(quant), diff, quant, codes
+
+    forward = __call__
+
+    def _require_ready(self):
+        if self._sd_host is None:
+            raise RuntimeError('VQGAN: load_state_dict() first')
+        if self.device is None:
+            raise RuntimeError('VQGAN: .to("cuda") first (GPU only)')
+
+
+class _LazyEncodeResult(tuple):
+    """``(quant, diff, codes)`` — indexable like the reference's tuple; ``quant``/``diff`` are
+    materialised only when actually read (hot-path callers take ``[-1]``)."""
+
+    def __new__(cls, model, z, codes):
+        self = super().__new__(cls, (None, None, codes))
+        self._model, self._z, self._codes = model, z, codes
+        self._qd = None
+        return self
+
+    def _quant_diff(self):
+        if self._qd is None:
+            m, cfg = self._model, self._model.config
+            n, h, w = self._codes.shape
+            q = ops.codebook_gather(m._E, self._codes, cfg.embed_dim, cfg.n_embed)
+            z = self._z
+            diff = (q - z).pow(2).mean()                 # utils_th.py:66  (reporting value, not on the hot path)
+            quant = (z + (q - z)).view(n, h, w, cfg.embed_dim)          # straight-through value, utils_th.py:67
+            if m.data_format == 'NCHW':
+                quant = quant.permute(0, 3, 1, 2)
+            self._qd = (quant, diff)
+        return self._qd
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(3)))
+        i = i if i >= 0 else 3 + i
+        if i == 2:
+            return self._codes
+        return self._quant_diff()[i]
+
+    def __iter__(self):
+        yield self[0]
+        yield self[1]
+        yield self[2]
