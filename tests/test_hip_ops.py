@@ -75,7 +75,10 @@ def test_gemm_strided_views_and_batch(dev):
 
 
 @pytest.mark.parametrize('mode,cin,cout,H', [('s1', 32, 32, 8), ('s1', 128, 128, 16), ('s2', 64, 64, 16),
-                                              ('up', 64, 32, 8), ('s1', 64, 3, 16), ('s1', 256, 512, 8)])
+                                              ('up', 64, 32, 8), ('s1', 64, 3, 16), ('s1', 256, 512, 8),
+                                              # halo-tile kernel shapes (Cout % 128 == 0, W % 16 == 0, H % 8 == 0)
+                                              ('s1', 64, 256, 32), ('up', 128, 128, 8), ('up', 32, 128, 16),
+                                              ('s1', 32, 128, 64)])
 def test_conv3x3_modes(dev, mode, cin, cout, H):
     from viewformer_amd import ops
     n, W = 3, H
@@ -97,9 +100,10 @@ def test_conv3x3_modes(dev, mode, cin, cout, H):
     _close(out.view(n, Ho, Ho, cout).permute(0, 3, 1, 2), ref, 2e-5, 2e-5, f'conv {mode} {cin}->{cout}')
 
 
-def test_conv_with_groupnorm_swish_prologue_and_residual(dev):
+@pytest.mark.parametrize('C,H', [(64, 16), (128, 32)])      # generic per-tap kernel / halo-tile kernel
+def test_conv_with_groupnorm_swish_prologue_and_residual(dev, C, H):
     from viewformer_amd import ops
-    n, C, H = 2, 64, 16
+    n = 2
     x = _rand((n, C, H, H), 21) * 2 + 0.5
     gamma, beta = _rand((C,), 22) * 0.3 + 1, _rand((C,), 23) * 0.2
     w, b = _rand((C, C, 3, 3), 24, 0.05), _rand((C,), 25)

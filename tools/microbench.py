@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Per-kernel microbenchmark (GPU): times the hot kernels at the bench's dominant shapes with HIP
+events.  Used under rocprofv3 for the profiles/ summaries.  python tools/microbench.py [names...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from viewformer_amd import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def conv(n_img=56, C=128, H=128, pro=True):
+    x = torch.randn(n_img * H * H, C, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.03
+    wp = ops.pack_conv_oihw(w)
+    b = torch.randn(C, device=dev)
+    out = torch.empty_like(x)
+    prol = None
+    if pro:
+        g = torch.ones(C, device=dev)
+        m, s = ops.groupnorm_stats(x, g, n_img, H * H, C)
+        prol = (m, s, torch.zeros(C, device=dev))
+    M = n_img * H * H
+    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
+                                  Hin=H, Win=H, Hout=H, Wout=H))
+    fl = 2.0 * M * C * C * 9
+    print(f'conv3x3 {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
+
+
+def gemm(M=7168, K=768, N=3072, epi=0):
+    x = torch.randn(M, K, device=dev)
+    wp = ops.pack_dense_kn(torch.randn(K, N, device=dev) * 0.02)
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi))
+    print(f'gemm {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
+
+
+def vq(M=64 * 448):
+    z = torch.randn(M, 256, device=dev) * 0.2
+    E = torch.randn(256, 1024, device=dev) * 0.05
+    Ep, esq = ops.vq_pack_codebook(E)
+    ms = timeit(lambda: ops.vq_argmin(z, Ep, esq, 256, 1024))
+    by = M * 256 * 4 + 256 * 1024 * 4 + M * 8
+    print(f'vq_argmin M={M}: {ms:.4f} ms  {2.0 * M * 256 * 1024 / ms / 1e9:.1f} TF  {by / ms / 1e6:.1f} GB/s algorithmic')
+
+
+def attn(B=32, H=12, S=7, L=64):
+    d, T = H * 64, S * L
+    qkv = torch.randn(B * T, 3 * d, device=dev) * 0.3
+    out = torch.empty(B * T, d, device=dev)
+    ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
+                                             3 * d, d, 1.0, True))
+    useful = 4.0 * H * 64 * L * L * S * (S + 1) / 2 * B
+    print(f'attn B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
+
+
+def gn(n_img=56, C=128, HW=16384):
+    x = torch.randn(n_img * HW, C, device=dev)
+    g = torch.ones(C, device=dev)
+    ms = timeit(lambda: ops.groupnorm_stats(x, g, n_img, HW, C))
+    print(f'gn_stats {n_img}x{HW}x{C}: {ms:.4f} ms  {x.numel() * 4 / ms / 1e6:.1f} GB/s')
+
+
+ALL = dict(conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
+           gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
+           conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8))
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        ALL[n]()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Summarise the rocprofv3 (rocpd sqlite) outputs written by tools/prof.sh: per-kernel average
+duration from the kernel trace and per-dispatch mean of every PMC counter.
+usage: python tools/summarize_prof.py <prof dir> [kernel-name substrings...]"""
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def tables(c):
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    return lambda p: [t for t in tabs if t.startswith(p)][0]
+
+
+def main():
+    out = sys.argv[1]
+    filt = sys.argv[2:] or ['igemm', 'vq_argmin', 'attn_', 'gn_partial', 'layernorm', 'conv_in', 'softmax']
+    lines = []
+    for db in sorted(glob.glob(os.path.join(out, '*', '*.db'))):
+        c = sqlite3.connect(db)
+        T = tables(c)
+        tag = os.path.basename(os.path.dirname(db))
+        kd, ks = T('rocpd_kernel_dispatch'), T('rocpd_info_kernel_symbol')
+        rows = c.execute(f"select s.kernel_name, count(*), avg(d.end-d.start), sum(d.end-d.start), max(s.arch_vgpr_count), "
+                         f"max(d.group_segment_size) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name "
+                         f"order by 4 desc").fetchall()
+        tot = sum(r[3] for r in rows) or 1
+        if tag.startswith('trace'):
+            lines.append(f'== {tag}: kernel trace (all dispatches incl. warm-up)')
+            for n, cnt, avg, s, vg, lds in rows[:14]:
+                lines.append(f'  {n[:72]:72s} calls={cnt:5d} avg_us={avg / 1e3:10.2f} total_ms={s / 1e6:9.3f} pct={100 * s / tot:5.1f} vgpr={vg} lds={lds}')
+            continue
+        pe, ip = T('rocpd_pmc_event'), T('rocpd_info_pmc')
+        q = (f"select s.kernel_name, p.name, avg(e.value), count(*) from {pe} e join {ip} p on e.pmc_id=p.id "
+             f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name")
+        agg = defaultdict(dict)
+        for n, pn, v, cnt in c.execute(q):
+            agg[n][pn] = v
+        dur = {r[0]: r[2] for r in rows}
+        lines.append(f'== {tag}: PMC, per-dispatch mean (summed over all XCD/SE instances)')
+        for n, d in agg.items():
+            if any(f in n for f in filt):
+                lines.append(f'  {n[:72]}  avg_us={dur.get(n, 0) / 1e3:.2f}')
+                lines.append('      ' + ', '.join(f'{k}={v:.5g}' for k, v in sorted(d.items())))
+    open(os.path.join(out, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main()

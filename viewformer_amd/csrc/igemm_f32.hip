@@ -17,6 +17,9 @@
 // Reference call sites replaced: see include/vf_hip.h (vqgan_th.py Conv2d sites, migt.py Conv1D).
 #include "vf_common.h"
 #include "../../include/vf_hip.h"
+#include <stdlib.h>
+
+int vf_conv3_halo_try(const vf_igemm_args& a, hipStream_t stream, int* status);   // conv3_halo_f32.hip
 
 namespace {
 
@@ -320,6 +323,13 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
     if (pro && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
     if (pro && a.mode == VF_MODE_GEMM && a.pro_rows_per_img <= 0) return VF_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // 3x3 stride-1 / upsample layers with wide channels go to the halo-tile kernel (conv3_halo_f32.hip);
+        // VF_DISABLE_HALO=1 keeps everything on this generic per-tap kernel (A/B timing, debugging).
+        static const bool halo_off = [] { const char* e = getenv("VF_DISABLE_HALO"); return e && e[0] == '1'; }();
+        int st = 0;
+        if (!halo_off && vf_conv3_halo_try(a, s, &st) == 0) return st;
+    }
     const int BN = bn_for(a.Cout);
     if (BN == 128) return launch_igemm<2, 2, 2, 2>(a, s);
     if (BN == 64) return launch_igemm<4, 1, 1, 2>(a, s);
