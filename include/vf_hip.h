@@ -130,10 +130,15 @@ int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, flo
  * skip_masked=1 skips key tiles that are masked for the whole query tile (their softmax weight
  * underflows to exactly 0.0f whenever the row max exceeds -1e4+104); 0 = dense reference form.
  * L=0 disables the mask (plain softmax attention).
+ * twin_view = Vc >= 0: views Vc, Vc+1, ... are alternative endings of the same sequence position (each
+ * sees views < Vc and itself, never a sibling) — the reference's branch streams
+ * (branching_attention.py:94-125), used to run the evaluator's generation pass (MASK view) and
+ * localization pass (LOC view, evaluate_transformer.py:119-123,134-136) as ONE pass over S+1 views
+ * with bit-identical rows.  -1 = plain block-causal.
  * ------------------------------------------------------------------------------------- */
 int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out,
                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                            float scale, int skip_masked, void* stream);
+                            float scale, int skip_masked, int twin_view, void* stream);
 /* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
 int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
 

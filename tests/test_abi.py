@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_queries(lib):
-    assert lib.vf_abi_version() == 1
+    assert lib.vf_abi_version() == 2
     assert lib.vf_build_arch() == b'gfx950'
     # [chunks=4][taps=9][nblk=1][32][128]
     assert lib.vf_igemm_packed_floats(128, 128, 9) == 4 * 9 * 32 * 128
@@ -62,7 +62,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.vf_argmax_rows_f32(d, 0, 16, 16, d, None) == 0
     assert lib.vf_argmax_rows_f32(d, 4, 16, 8, d, None) == -1             # ld < n
     assert lib.vf_groupnorm_stats_f32(d, d, 1, 64, 48, 32, 1e-6, d, d, d, None) == -2
-    assert lib.vf_attn_blockcausal_f32(d, d, d, d, 1, 2, 64, 64, 64, 128, 128, 128, 1.0, 1, None) == -1   # ldq < H*64
+    assert lib.vf_attn_blockcausal_f32(d, d, d, d, 1, 2, 64, 64, 64, 128, 128, 128, 1.0, 1, -1, None) == -1   # ldq < H*64
     assert lib.vf_dense_small_k_gelu_f32(d, d, d, d, 4, 32, 8, 1, None) == -2
     assert lib.vf_conv_in_u8_f32(None, None, d, d, d, 1, 8, 8, 32, None) == -1
 

@@ -188,3 +188,24 @@ def test_no_cpu_fallback(dev, tiny_vq):
         VQGAN(cfg).load_state_dict(sd).to('cpu')
     with pytest.raises(_lib.VfError):
         ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), 4, 128)
+
+
+def test_fused_generate_and_localize_is_bit_identical_to_two_passes(dev, full_vq):
+    """the twin-view single pass == the reference's two separate transformer calls, bit for bit"""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    vcfg, vsd, _ = full_vq
+    mcfg = MIGTConfig(sequence_size=6, localization_weight='cosine(0,1,120000)', pose_multiplier=0.2, n_layer=3)
+    msd = make_migt_weights(mcfg, seed=4, std=0.05)
+    frames, cams = synthetic_scene_batch(2, 4, 128, seed=8)
+    vq_m = _vq_model(vcfg, vsd, dev, 'NHWC')
+    for skip in (True, False):
+        tr_m = _migt(mcfg, msd, dev)
+        tr_m.skip_masked = skip
+        a = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True, fused_passes=True)
+        b = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True, fused_passes=False)
+        assert torch.equal(a['logits_last'], b['logits_last'])
+        assert torch.equal(a['pose_last'], b['pose_last'])
+        assert torch.equal(a['generated_images'], b['generated_images'])
+        assert torch.equal(a['generated_cameras'], b['generated_cameras'])

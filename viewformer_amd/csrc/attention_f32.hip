@@ -29,7 +29,7 @@ constexpr int V_LD = 64;
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int skip_masked) {
+                                                                  float scale, int skip_masked, int twin) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
 
@@ -61,6 +61,14 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
         }
     }
     const int qview = (L > 0) ? qrow / L : 0;
+    // visibility of key view kv from query view qv.  Plain block-causal: kv <= qv.  With `twin` = Vc >= 0 the
+    // views Vc, Vc+1, ... are alternatives of the SAME sequence position (the MASK view and the LOC view of
+    // the evaluator's two passes, = the reference's branch streams, branching_attention.py:94-125): each sees
+    // the common prefix and itself, never a sibling.
+    const int Vc = twin >= 0 ? twin : 0x3fffffff;
+    auto visible = [&](int qv, int kv) { return kv == qv || min(kv, Vc) < min(qv, Vc); };
+    const bool uniform_views = L > 0 && (L % KT) == 0;      // a key tile and a wave's 32 queries sit inside one view
+    const int qview_w = (L > 0) ? __builtin_amdgcn_readfirstlane((q0 + wave * 32) / L) : 0;
 
     // number of key tiles the workgroup / this wave must visit
     int kmax = T, kmax_w = T;   // exclusive
@@ -110,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
         }
         __syncthreads();
         if (kt + 1 < ntiles) prefetch(kt + 1);
-        if (kt >= ntiles_w) continue;   // every key of this tile is masked for this wave's 32 queries
+        // every key of this tile is masked for this wave's 32 queries -> contributes exactly 0.0f
+        if (kt >= ntiles_w) continue;
+        if (skip_masked && uniform_views && !visible(qview_w, (kt * KT) / L)) continue;
 
         // ---- S^T = K . Q^T ----------------------------------------------------------------
         f32x16 st[2];
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float s = st[t2][r] * scale;
-                if (L > 0 && (key / L) > qview) s = -1e4f;     // w*m - 1e4*(1-m)
+                if (L > 0 && !visible(qview, key / L)) s = -1e4f;     // w*m - 1e4*(1-m)
                 if (key >= T) s = -INFINITY;                   // padding keys do not exist
                 st[t2][r] = s;
                 mx = fmaxf(mx, s);
@@ -197,13 +207,14 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
 extern "C" {
 
 int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int T, int L,
-                            int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, void* stream) {
+                            int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
+                            void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked);
+                       ldv, ldo, scale, skip_masked, twin_view);
     return vf_last_status();
 }
 

@@ -11,7 +11,11 @@ from . import geometry
 from . import ops
 
 
-def generate_batch_predictions(transformer_model, codebook_model, images, cameras, return_codes: bool = False):
+def generate_batch_predictions(transformer_model, codebook_model, images, cameras, return_codes: bool = False,
+                               fused_passes: bool = True):
+    """``fused_passes``: run the generation pass and the localization pass as one twin-view pass
+    (MIGT.generate_and_localize; bit-identical rows, 8/14 of the transformer work at S=7); False = the
+    reference's two separate calls."""
     dev = codebook_model.device
     images = torch.as_tensor(images).to(dev)
     cameras = torch.as_tensor(cameras, dtype=torch.float32).to(dev)
@@ -29,9 +33,13 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     codes = codebook_model.encode(images.reshape(B * S, *images.shape[2:]))[-1]
     codes = codes.to(torch.int32).view(B, S, t, t)                      # :110,116
 
-    ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], transformer_model.mask_token)], 1)   # :120-121
-    out = transformer_model(dict(input_ids=ids, poses=cameras), training=False, last_view_logits_only=True)
-    lg = out['logits_last']                                             # == output['logits'][:, -1]
+    pose_last = None
+    if transformer_model.use_localization and fused_passes:
+        lg, pose_last = transformer_model.generate_and_localize(codes, cameras)       # :119-123 + :134-136
+    else:
+        ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], transformer_model.mask_token)], 1)   # :120-121
+        out = transformer_model(dict(input_ids=ids, poses=cameras), training=False, last_view_logits_only=True)
+        lg = out['logits_last']                                         # == output['logits'][:, -1]
     nE = lg.shape[-1]
     generated_codes = ops.argmax_rows(lg.view(-1, nE), B * t * t, nE).view(B, t, t)   # :123 (ties -> lowest index)
 
@@ -41,9 +49,11 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     generated_images = ops.postprocess_u8(dec.contiguous())             # :128-129
 
     if transformer_model.use_localization:                              # :134-136
-        out2 = transformer_model(dict(input_ids=codes, poses=cameras[:, :-1]), training=False,
-                                 last_view_logits_only=True)
-        generated_cameras = transformer_model.reduce_cameras(out2['pose_prediction'][:, -1:], -2)
+        if pose_last is None:
+            out2 = transformer_model(dict(input_ids=codes, poses=cameras[:, :-1]), training=False,
+                                     last_view_logits_only=True)
+            pose_last = out2['pose_prediction'][:, -1:]
+        generated_cameras = transformer_model.reduce_cameras(pose_last, -2)
     else:
         generated_cameras = cameras[:, :1]                              # :138
     if transformer_model.config.augment_poses == 'relative':            # :139-140
@@ -51,7 +61,7 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     res = dict(ground_truth_images=images[:, -1], generated_images=generated_images,
                ground_truth_cameras=ground_truth_cameras, generated_cameras=generated_cameras[:, -1])
     if return_codes:
-        res.update(codes=codes, generated_codes=generated_codes, logits_last=lg, decoded=dec)
+        res.update(codes=codes, generated_codes=generated_codes, logits_last=lg, decoded=dec, pose_last=pose_last)
     return res
 
 

@@ -137,6 +137,70 @@ class MIGT:
         """MIGT.reduce_cameras, migt.py:532-533"""
         return geometry.reduce_cameras(cameras, axis)
 
+    def _blocks(self, ids, add_emb, B, V, L, twin_view=-1):
+        """embedding sum -> n_layer x Block -> ln_f over V views of L tokens.  ids [B,V,...] int,
+        add_emb [B,V,d] (pose embedding or LOC-token row per view).  Returns [B*V*L, d]."""
+        c, dev = self.config, self.device
+        d, H = c.d_model, c.n_head
+        T, M = V * L, B * V * L
+        add = add_emb.contiguous().view(B * V, d)
+        ids32 = ids.reshape(M).to(torch.int32).contiguous()
+        h = ops.embed_sum(ids32, self._wte, self._wpe, add, B * V, L, d, c.n_embeddings + 2)   # migt.py:392
+        qkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
+        att = torch.empty((M, d), dtype=torch.float32, device=dev)
+        for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
+            p = f'h.{i}'
+            a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d)
+            ca = self._dense[p + '.attn.c_attn']
+            ops.igemm(a, ca.wp, M, d, 3 * d, qkv, bias=ca.bias)
+            # thirds are (V, Q, K): migt.py:207-213
+            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
+                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, twin_view)
+            h = self._gemm(att, p + '.attn.c_proj', M, res=h)
+            m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
+            f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
+            h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
+        return ops.layernorm(h, *self._ln['ln_f'], M, d)                    # migt.py:408
+
+    def generate_and_localize(self, codes, cameras):
+        """The evaluator's two transformer passes (evaluate_transformer.py:119-123 and :134-136) as ONE pass.
+
+        Pass 1 feeds [codes[:, :-1], MASK] with all S poses; pass 2 feeds all S real code maps with S-1 poses
+        and the LOC embedding on the last view.  Views 0..S-2 are identical inputs in both, and block-causal
+        attention never lets them see the last view, so their hidden states are bit-identical: only the last
+        view differs.  We run S+1 views [ctx_0..ctx_{S-2}, MASK-view, LOC-view] with the last two marked as
+        twins (each attends to the context and itself, never to its sibling) — the reference's own branch-stream
+        construction (migt.py:392-401, branching_attention.py:94-125).  Every produced row equals the two-pass
+        row bit-for-bit (tests/test_hip_models.py), at 8/14 of the transformer work for S = 7.
+
+        codes [B,S,t,t] int (all S views encoded), cameras [B,S,7] float32 (relative + normalised).
+        Returns (logits_last [B,t,t,n_embeddings], pose_prediction_last [B,1,L,7])."""
+        if not self.use_localization:
+            raise RuntimeError('generate_and_localize needs a model with the localization head')
+        c, dev = self.config, self.device
+        codes = codes.to(dev)
+        cameras = cameras.to(dev)
+        B, S = codes.shape[:2]
+        tshape = tuple(codes.shape[2:])
+        L = int(np.prod(tshape))
+        d, nE = c.d_model, c.n_embeddings
+        if d // c.n_head != 64:
+            raise ops._lib.VfError('attention kernel supports head dim 64 only')
+        pose_emb = self._pose_embed(cameras)                                            # [B,S,d]
+        lpe = self._wte[self.localization_token].view(1, 1, d).expand(B, 1, d)
+        add = torch.cat([pose_emb, lpe], 1)                                             # [B,S+1,d]
+        mask = torch.full_like(codes[:, :1], self.mask_token)
+        ids = torch.cat([codes[:, :-1], mask, codes[:, -1:]], 1)                        # [B,S+1,t,t]
+        hf = self._blocks(ids, add, B, S + 1, L, twin_view=S - 1).view(B, S + 1, L, d)
+        h_mask = hf[:, S - 1].contiguous().view(B * L, d)
+        h_loc = hf[:, S].contiguous().view(B * L, d)
+        lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
+        ops.igemm(h_mask, self._lm_head, B * L, d, nE, lg)                              # migt.py:417
+        p1 = self._gemm(h_loc, 'pose_criterion.pose_classifier.c_fc', B * L, epilogue=ops.EPI_GELU)
+        p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', B * L)
+        pose = geometry.pose_head_postprocess(p2.view(B, 1, L, 7), c.pose_multiplier)
+        return lg.view(B, *tshape, nE), pose
+
     # ------------------------------------------------------------------ forward (single stream, inference)
     def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False):
         if training or compute_losses:
@@ -154,7 +218,7 @@ class MIGT:
         B, S = orig_shape[:2]
         L = int(np.prod(orig_shape[2:]))
         d, H = c.d_model, c.n_head
-        T, M = S * L, B * S * L
+        M = B * S * L
         if d // H != 64:
             raise ops._lib.VfError('attention kernel supports head dim 64 only')
 
@@ -165,25 +229,7 @@ class MIGT:
             pose_emb = torch.cat([pose_emb, lpe], 1)
         elif Sp != S:
             raise ValueError(f'poses has {Sp} views but input_ids has {S}')
-        add = pose_emb.contiguous().view(B * S, d)
-        ids32 = ids.reshape(B * S * L).to(torch.int32).contiguous()
-        h = ops.embed_sum(ids32, self._wte, self._wpe, add, B * S, L, d, c.n_embeddings + 2)   # migt.py:392
-
-        qkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
-        att = torch.empty((M, d), dtype=torch.float32, device=dev)
-        for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
-            p = f'h.{i}'
-            a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d)
-            ca = self._dense[p + '.attn.c_attn']
-            ops.igemm(a, ca.wp, M, d, 3 * d, qkv, bias=ca.bias)
-            # thirds are (V, Q, K): migt.py:207-213
-            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
-                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked)
-            h = self._gemm(att, p + '.attn.c_proj', M, res=h)
-            m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
-            f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
-            h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
-        hf = ops.layernorm(h, *self._ln['ln_f'], M, d)                      # migt.py:408
+        hf = self._blocks(ids, pose_emb, B, S, L)
 
         out = dict(hidden_states=[hf.view(B, S, L, d)])
         nE = c.n_embeddings
@@ -197,8 +243,12 @@ class MIGT:
             ops.igemm(hf, self._lm_head, M, d, nE, lg)                       # migt.py:417,51-56
             out['logits'] = lg.view(*orig_shape, nE)
         if self.use_localization:                                            # migt.py:430-451
-            p1 = self._gemm(hf, 'pose_criterion.pose_classifier.c_fc', M, epilogue=ops.EPI_GELU)
-            p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', M)
-            out['pose_prediction'] = geometry.pose_head_postprocess(p2.view(B, S, L, 7), c.pose_multiplier)
+            if last_view_logits_only:      # pose head on the last view only: shape [B,1,L,7], so [:, -1:] still works
+                hp, Mp, Sp_out = hf.view(B, S, L, d)[:, -1].contiguous().view(B * L, d), B * L, 1
+            else:
+                hp, Mp, Sp_out = hf, M, S
+            p1 = self._gemm(hp, 'pose_criterion.pose_classifier.c_fc', Mp, epilogue=ops.EPI_GELU)
+            p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', Mp)
+            out['pose_prediction'] = geometry.pose_head_postprocess(p2.view(B, Sp_out, L, 7), c.pose_multiplier)
         out['loss'] = 0
         return out

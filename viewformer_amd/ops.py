@@ -172,10 +172,11 @@ def codebook_gather(E, idx, D, Kc):
 
 
 # ------------------------------------------------------------------ attention / transformer glue
-def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True):
+def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1):
     lib = _lib.load()
     check(lib.vf_attn_blockcausal_f32(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
-                                      ldo, scale, 1 if skip_masked else 0, _stream()), 'vf_attn_blockcausal_f32')
+                                      ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
+          'vf_attn_blockcausal_f32')
     return out
 
 
