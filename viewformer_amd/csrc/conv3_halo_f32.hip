@@ -22,6 +22,7 @@
 // Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,
 // 197,249) with GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
 #include "vf_common.h"
+#include "epilogue.h"
 #include "../../include/vf_hip.h"
 
 namespace {
@@ -200,24 +201,25 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
     // ---- epilogue -------------------------------------------------------------------------------------
     float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
     const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
+    // batched, branch-free tile epilogue (epilogue.h): tiles are always full here
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            const int py = y0 + wave_m * 4 + mi * 2;
+            // accumulator row r -> pixel index inside the image (perm_* are compile-time per r, selected by half)
+            auto pix = [&](int r) {
                 const int i0 = (r & 3) + 8 * (r >> 2);
                 const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
                 const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
-                const int oy = y0 + wave_m * 4 + mi * 2 + prow;
-                const int ox = x0 + ppx;
-                const size_t pix = (size_t)oy * p.Wout + ox;
-                float v = acc[mi][j][r] + bias;
-                if (Res) v += Res[pix * p.ldr + n];
-                Out[pix * p.ldc + n] = v;
-            }
+                return (py + prow) * p.Wout + x0 + ppx;
+            };
+            auto oo = [&](int r) { return pix(r) * p.ldc; };
+            auto ro = [&](int r) { return pix(r) * p.ldr; };
+            if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
+            else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
         }
     }
 }

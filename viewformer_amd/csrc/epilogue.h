@@ -1,0 +1,64 @@
+// Shared MFMA-tile epilogue for the f32 GEMM-family kernels (gfx950).
+//
+// A 32x32 accumulator tile in the C layout holds, per lane, 16 rows (r -> (r&3) + 8*(r>>2) [+4*half, folded
+// into the base]) of ONE column.  The first version of the kernels stored element by element inside
+// `if (m < M)` / `if (res)` branches: every element became its own basic block ending in
+// `s_waitcnt vmcnt(0)`, and since vmcnt also counts stores on CDNA4 each of the 64 stores per lane waited
+// for the previous store's memory round trip — ~40 us of serialized latency per workgroup, as long as
+// the whole MFMA loop (found with tools/mfma_peak.hip + ISA inspection).  Here a tile is handled as
+// ONE basic block: all 16 residual loads are issued back to back, one wait, 16 adds, 16 back-to-back
+// stores.  Row offsets come from a functor so the halo conv (permuted pixel rows) shares the code.
+#pragma once
+#include "vf_common.h"
+
+// off(r) -> element offset of accumulator row r relative to `out` / `res` (already positioned at the lane's
+// column and at the +4*half row).  FULL: every row of the tile is in range (wave-uniform fact).
+template <int EPI, bool HAS_RES, typename OffOut, typename OffRes>
+__device__ __forceinline__ void vf_store_tile(const f32x16& acc, float bias, float* __restrict__ out,
+                                              const float* __restrict__ res, OffOut off_out, OffRes off_res) {
+    float v[16];
+    if (HAS_RES) {
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rr[r] = res[off_res(r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = acc[r] + bias;
+            if (EPI == 1) t = vf_gelu_erf(t);
+            v[r] = t + rr[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = acc[r] + bias;
+            if (EPI == 1) t = vf_gelu_erf(t);
+            v[r] = t;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[off_out(r)] = v[r];
+}
+
+// Ragged tile (some rows >= M): same batching, rows clamped for the loads and predicated for the store via
+// a select of the destination into a per-lane dummy (the lane's own valid row 0 is rewritten with its own
+// value — no branch, no out-of-bounds access).  `nrows` = number of valid rows counted from this lane's row 0.
+template <int EPI, bool HAS_RES>
+__device__ __forceinline__ void vf_store_tile_ragged(const f32x16& acc, float bias, float* __restrict__ out,
+                                                     const float* __restrict__ res, long long ldc, long long ldr,
+                                                     int rows_left /* M - (row of r=0 incl. half) */) {
+    if (rows_left <= 0) return;      // whole lane out of range (uniform per half-wave; rare tail tile only)
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        float t = acc[r] + bias;
+        if (EPI == 1) t = vf_gelu_erf(t);
+        if (HAS_RES) t += res[(long long)(row < rows_left ? row : 0) * ldr];
+        v[r] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (row < rows_left) out[(long long)row * ldc] = v[r];
+    }
+}

@@ -16,10 +16,12 @@
 //
 // Reference call sites replaced: see include/vf_hip.h (vqgan_th.py Conv2d sites, migt.py Conv1D).
 #include "vf_common.h"
+#include "epilogue.h"
 #include "../../include/vf_hip.h"
 #include <stdlib.h>
 
 int vf_conv3_halo_try(const vf_igemm_args& a, hipStream_t stream, int* status);   // conv3_halo_f32.hip
+int vf_gemm_direct_try(const vf_igemm_args& a, hipStream_t stream, int* status);  // gemm_direct_f32.hip
 
 namespace {
 
@@ -211,18 +213,34 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
         const int n = nblk * BN + (wave_n * WN_T + j) * 32 + l31;
         const bool nok = n < p.Cout;
         const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+        // batched tile epilogue (epilogue.h): one basic block per tile, no per-element vmcnt(0) round trips.
+        // Columns past Cout (padded weight tiles) are steered to rows_left = 0.
+        const long long ldc = p.ldc, ldr = p.ldr;
+        const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
 #pragma unroll
         for (int i = 0; i < WM_T; ++i) {
-            const int mbase = mtile * BM + (wave_m * WM_T + i) * 32 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (nok && m < p.M) {
-                    float v = acc[i][j][r] + bias;
-                    if (p.epilogue == VF_EPI_GELU_ERF) v = vf_gelu_erf(v);
-                    if (Res) v += Res[(size_t)m * p.ldr + n];
-                    Out[(size_t)m * p.ldc + n] = v;
+            const int m0 = mtile * BM + (wave_m * WM_T + i) * 32 + 4 * half;
+            const int nn = nok ? n : 0;
+            float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
+            const float* rs = Res ? Res + (size_t)(m0 < p.M ? m0 : 0) * ldr + nn : nullptr;
+            const int rows_left = nok ? p.M - m0 : 0;
+            const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);   // workgroup-uniform
+            if (full) {
+                auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
+                auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
+                if (gelu) {
+                    if (Res) vf_store_tile<1, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<1, false>(acc[i][j], bias, o, rs, oo, ro);
+                } else {
+                    if (Res) vf_store_tile<0, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<0, false>(acc[i][j], bias, o, rs, oo, ro);
                 }
+            } else if (gelu) {
+                if (Res) vf_store_tile_ragged<1, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<1, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+            } else {
+                if (Res) vf_store_tile_ragged<0, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<0, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
             }
         }
     }
@@ -329,6 +347,11 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
         static const bool halo_off = [] { const char* e = getenv("VF_DISABLE_HALO"); return e && e[0] == '1'; }();
         int st = 0;
         if (!halo_off && vf_conv3_halo_try(a, s, &st) == 0) return st;
+        // A/B arm: the LDS-free streaming GEMM (gemm_direct_f32.hip).  Measured on MI355X it ties this
+        // LDS-staged kernel in the K loop (118 vs 123 TF asymptotic) and loses ~4 % end to end at K = 768
+        // (DESIGN.md §5), so it is opt-in: VF_ENABLE_DIRECT=1.
+        static const bool direct_on = [] { const char* e = getenv("VF_ENABLE_DIRECT"); return e && e[0] == '1'; }();
+        if (direct_on && vf_gemm_direct_try(a, s, &st) == 0) return st;
     }
     const int BN = bn_for(a.Cout);
     if (BN == 128) return launch_igemm<2, 2, 2, 2>(a, s);
