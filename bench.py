@@ -196,12 +196,31 @@ def main():
         step()
         ms, fl, n, top = prof.summary()
         prof.uninstall()
-        ach = fl / (ms * 1e-3) / 1e12
-        line['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_f32_kernel (conv3x3/1x1/dense, v_mfma_f32_32x32x2_f32)',
+        fam = fl / (ms * 1e-3) / 1e12
+        # dominant kernel = conv3_halo_kernel at its dominant launch shape: the 128->128 3x3 conv @128x128
+        # (mode 1, M = images*128*128): SURVEY §8(d) per-unit figure 2*9*128*128 FLOP per output pixel x M pixels.
+        dom_key, dom = max(((k, v) for k, v in top if k[0] == 1), key=lambda kv: kv[1][0], default=(None, None))
+        if dom is None:
+            dom_key, dom = top[0]
+        d_ms = dom[0] / dom[2]                               # average launch duration (HIP events, launch stream)
+        d_fl = dom[1] / dom[2]                               # algorithmic FLOP per launch
+        ach = d_fl / (d_ms * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC passes of profiles/r1_conv_halo_pmc.txt (2*FETCH_SIZE + WRITE_SIZE,
+        # gfx950 correction), measured on a 56-image launch of this shape and scaled by pixels
+        pmc_bytes_per_pixel = (2 * 497520e3 + 458750e3) * 1.024 / (56 * 128 * 128) if dom_key[0] == 1 and dom_key[2:4] == (128, 128) else None
+        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv3_halo_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, '
+                                                        'v_mfma_f32_32x32x2_f32)',
                             'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-                            'launches_per_step': n, 'kernel_ms_per_step': round(ms, 3),
-                            'algorithmic_gflop_per_step': round(fl / 1e9, 1),
+                            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                            'traffic': (round(pmc_bytes_per_pixel * dom_key[1]) if pmc_bytes_per_pixel else None),
+                            'traffic_unit': 'bytes/launch (PMC, scaled from the 56-image profile)',
+                            'launch_shape_mode_M_Cin_Cout_batch': list(dom_key), 'avg_launch_ms': round(d_ms, 4),
+                            'algorithmic_gflop_per_launch': round(d_fl / 1e9, 1),
+                            'algorithmic_bytes_per_launch': dom_key[1] * (dom_key[2] + 2 * dom_key[3]) * 4,
+                            'family': {'kernels': 'igemm_f32 + conv3_halo (every conv/dense launch of the step)',
+                                       'achieved': round(fam, 2), 'frac': round(fam / F32_MFMA_PEAK_TFLOPS, 4),
+                                       'launches_per_step': n, 'kernel_ms_per_step': round(ms, 3),
+                                       'algorithmic_gflop_per_step': round(fl / 1e9, 1)},
                             'top_shapes_mode_M_Cin_Cout_batch': [
                                 {'shape': list(k), 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1),
                                  'launches': v[2]} for k, v in top]}

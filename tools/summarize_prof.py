@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Summarise the rocprofv3 (rocpd sqlite) outputs written by tools/prof.sh: per-kernel average
-duration from the kernel trace and per-dispatch mean of every PMC counter.
+"""Summarise the rocprofv3 (rocpd sqlite) outputs written by tools/prof.sh / prof_bench.sh:
+per-kernel average duration from the kernel trace, and for PMC passes the per-dispatch TOTAL of each
+counter (summed over all XCD/SE/channel instances of the dispatch, then averaged over dispatches).
 usage: python tools/summarize_prof.py <prof dir> [kernel-name substrings...]"""
 import glob
 import os
@@ -14,9 +15,15 @@ def tables(c):
     return lambda p: [t for t in tabs if t.startswith(p)][0]
 
 
+def short(n):
+    n = n.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')
+    return n[:78]
+
+
 def main():
     out = sys.argv[1]
-    filt = sys.argv[2:] or ['igemm', 'vq_argmin', 'attn_', 'gn_partial', 'layernorm', 'conv_in', 'softmax']
+    filt = sys.argv[2:] or ['igemm', 'conv3_halo', 'gemm_direct', 'vq_argmin', 'attn_', 'gn_partial', 'layernorm',
+                            'conv_in', 'softmax']
     lines = []
     for db in sorted(glob.glob(os.path.join(out, '*', '*.db'))):
         c = sqlite3.connect(db)
@@ -28,22 +35,23 @@ def main():
                          f"order by 4 desc").fetchall()
         tot = sum(r[3] for r in rows) or 1
         if tag.startswith('trace'):
-            lines.append(f'== {tag}: kernel trace (all dispatches incl. warm-up)')
-            for n, cnt, avg, s, vg, lds in rows[:14]:
-                lines.append(f'  {n[:72]:72s} calls={cnt:5d} avg_us={avg / 1e3:10.2f} total_ms={s / 1e6:9.3f} pct={100 * s / tot:5.1f} vgpr={vg} lds={lds}')
+            lines.append(f'== {tag}: rocprofv3 --kernel-trace, all dispatches of the run (incl. warm-up)')
+            for n, cnt, avg, s, vg, lds in rows[:16]:
+                lines.append(f'  {short(n):78s} calls={cnt:5d} avg_us={avg / 1e3:10.2f} total_ms={s / 1e6:9.3f} '
+                             f'pct={100 * s / tot:5.1f} vgpr={vg} lds={lds}')
             continue
         pe, ip = T('rocpd_pmc_event'), T('rocpd_info_pmc')
-        q = (f"select s.kernel_name, p.name, avg(e.value), count(*) from {pe} e join {ip} p on e.pmc_id=p.id "
-             f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name")
-        agg = defaultdict(dict)
-        for n, pn, v, cnt in c.execute(q):
-            agg[n][pn] = v
+        q = (f"select s.kernel_name, p.name, d.id, sum(e.value) from {pe} e join {ip} p on e.pmc_id=p.id "
+             f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name, d.id")
+        acc = defaultdict(lambda: defaultdict(list))
+        for n, pn, did, v in c.execute(q):
+            acc[n][pn].append(v)
         dur = {r[0]: r[2] for r in rows}
-        lines.append(f'== {tag}: PMC, per-dispatch mean (summed over all XCD/SE instances)')
-        for n, d in agg.items():
+        lines.append(f'== {tag}: rocprofv3 --pmc, per-dispatch totals (sum over instances), mean over dispatches')
+        for n, d in acc.items():
             if any(f in n for f in filt):
-                lines.append(f'  {n[:72]}  avg_us={dur.get(n, 0) / 1e3:.2f}')
-                lines.append('      ' + ', '.join(f'{k}={v:.5g}' for k, v in sorted(d.items())))
+                lines.append(f'  {short(n)}  avg_us={dur.get(n, 0) / 1e3:.2f}')
+                lines.append('      ' + ', '.join(f'{k}={sum(v) / len(v):.5g}' for k, v in sorted(d.items())))
     open(os.path.join(out, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
