@@ -135,6 +135,10 @@ int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, flo
  * (branching_attention.py:94-125), used to run the evaluator's generation pass (MASK view) and
  * localization pass (LOC view, evaluate_transformer.py:119-123,134-136) as ONE pass over S+1 views
  * with bit-identical rows.  -1 = plain block-causal.
+ * twin_view = -Sv <= -2: STREAMS mode, Sv views per stream, view index = stream*Sv + position: stream 0 is the
+ * main block-causal sequence, a branch stream s >= 1 at position i sees main views j < i and its own (s,i)
+ * tile — compute_causal_block_multiend_attention (branching_attention.py:82-126) for all streams in one launch
+ * (multi-context evaluators evaluate_transformer_multictx.py:60-77; forward of the training graph migt.py:392-401).
  * ------------------------------------------------------------------------------------- */
 int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out,
                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,

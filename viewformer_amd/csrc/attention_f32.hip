@@ -65,8 +65,20 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
     // views Vc, Vc+1, ... are alternatives of the SAME sequence position (the MASK view and the LOC view of
     // the evaluator's two passes, = the reference's branch streams, branching_attention.py:94-125): each sees
     // the common prefix and itself, never a sibling.
+    //   twin <= -2: STREAMS mode with Sv = -twin views per stream: view index = stream*Sv + i.  Stream 0 is the
+    //   main block-causal sequence; a branch stream s >= 1 at position i sees main views j < i and its own
+    //   (s, i) tile only — compute_causal_block_multiend_attention for every position at once
+    //   (branching_attention.py:94-125; used by the multi-context evaluators and the training graph).
     const int Vc = twin >= 0 ? twin : 0x3fffffff;
-    auto visible = [&](int qv, int kv) { return kv == qv || min(kv, Vc) < min(qv, Vc); };
+    const int Sv = twin <= -2 ? -twin : 0;
+    auto visible = [&](int qv, int kv) {
+        if (Sv > 0) {
+            const int qs = qv / Sv, qi = qv - qs * Sv;
+            const int ks = kv / Sv, ki = kv - ks * Sv;
+            return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+        }
+        return kv == qv || min(kv, Vc) < min(qv, Vc);
+    };
     const bool uniform_views = L > 0 && (L % KT) == 0;      // a key tile and a wave's 32 queries sit inside one view
     const int qview_w = (L > 0) ? __builtin_amdgcn_readfirstlane((q0 + wave * 32) / L) : 0;
 
@@ -143,26 +155,47 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
 
         // ---- mask + online softmax (lane = one query; its 32 keys of this tile) ----------------
         float mx = -INFINITY;
+        // a tile that lies inside one view, is visible to the wave (we did not skip it) and has no padding keys
+        // needs no per-element masking at all (wave-uniform): the common case for L = 64
+        const bool plain = (kt * KT + KT <= T) &&
+                           (L == 0 || (uniform_views && visible(qview_w, (kt * KT) / L)));   // (dense mode visits masked tiles too)
+        if (plain) {
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float s = st[t2][r] * scale;
-                if (L > 0 && !visible(qview, key / L)) s = -1e4f;     // w*m - 1e4*(1-m)
-                if (key >= T) s = -INFINITY;                   // padding keys do not exist
-                st[t2][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float s = st[t2][r] * scale;
+                    st[t2][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float s = st[t2][r] * scale;
+                    if (L > 0 && !visible(qview, key / L)) s = -1e4f;     // w*m - 1e4*(1-m)
+                    if (key >= T) s = -INFINITY;                   // padding keys do not exist
+                    st[t2][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);     // 0 on the first tile (m_run = -inf)
+        // exp via the hardware exp2 (v_exp_f32, 1 ulp) on a pre-scaled argument: 2 VALU instead of ~15 for the
+        // libm expf.  Relative error of a weight <= |x| * 6e-8 (argument rounding), far inside the fp32-class
+        // tolerance of the logits; the 32 exps per lane per tile were ~60 % of the kernel's VALU work.
+        constexpr float LOG2E = 1.4426950408889634f;
+        // (x - m) * log2e, not fma(x, log2e, -m*log2e): a masked-only tile must give alpha == 1.0f EXACTLY so that
+        // skipping it is bit-identical to visiting it
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // 0 on the first tile (m_run = -inf)
         float psum = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = expf(st[t2][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f((st[t2][r] - m_new) * LOG2E);
                 st[t2][r] = p;
                 psum += p;
             }

@@ -137,7 +137,7 @@ class MIGT:
         """MIGT.reduce_cameras, migt.py:532-533"""
         return geometry.reduce_cameras(cameras, axis)
 
-    def _blocks(self, ids, add_emb, B, V, L, twin_view=-1):
+    def _blocks(self, ids, add_emb, B, V, L, mask_spec=-1):
         """embedding sum -> n_layer x Block -> ln_f over V views of L tokens.  ids [B,V,...] int,
         add_emb [B,V,d] (pose embedding or LOC-token row per view).  Returns [B*V*L, d]."""
         c, dev = self.config, self.device
@@ -155,7 +155,7 @@ class MIGT:
             ops.igemm(a, ca.wp, M, d, 3 * d, qkv, bias=ca.bias)
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
-                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, twin_view)
+                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec)
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
@@ -191,7 +191,7 @@ class MIGT:
         add = torch.cat([pose_emb, lpe], 1)                                             # [B,S+1,d]
         mask = torch.full_like(codes[:, :1], self.mask_token)
         ids = torch.cat([codes[:, :-1], mask, codes[:, -1:]], 1)                        # [B,S+1,t,t]
-        hf = self._blocks(ids, add, B, S + 1, L, twin_view=S - 1).view(B, S + 1, L, d)
+        hf = self._blocks(ids, add, B, S + 1, L, mask_spec=S - 1).view(B, S + 1, L, d)
         h_mask = hf[:, S - 1].contiguous().view(B * L, d)
         h_loc = hf[:, S].contiguous().view(B * L, d)
         lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
@@ -201,12 +201,53 @@ class MIGT:
         pose = geometry.pose_head_postprocess(p2.view(B, 1, L, 7), c.pose_multiplier)
         return lg.view(B, *tshape, nE), pose
 
+    def _call_streams(self, ids, pose_emb, loc_tokens, out_poses, B, S, L, orig_shape):
+        """Multi-stream ("branching") forward, migt.py:371-455 with training=False.
+
+        Streams are laid out as extra views of one sequence (view index = stream*S + position) and the attention
+        kernel's STREAMS mask gives a branch position i the main views < i plus its own tile — i.e.
+        compute_causal_block_multiend_attention for every stream in one launch per layer.  Weights are shared
+        across streams exactly as in Block.call (migt.py:230-238)."""
+        c, dev = self.config, self.device
+        d, nE = c.d_model, c.n_embeddings
+        ids_streams = [ids.reshape(B, S, L)]
+        add_streams = [pose_emb]
+        img_ptr = pose_ptr = 0
+        if out_poses is not None:                                            # migt.py:382-385,393-396
+            out_poses = out_poses.to(dev)
+            if out_poses.shape[1] != S:
+                raise ValueError('output_poses must have one pose per view')
+            ids_streams.append(torch.full((B, S, L), self.mask_token, dtype=ids.dtype, device=dev))
+            add_streams.append(self._pose_embed(out_poses))
+            img_ptr = len(ids_streams) - 1
+        if loc_tokens is not None:                                           # migt.py:378-381,398-401
+            lt = loc_tokens.to(dev).reshape(B, -1, L)
+            if lt.shape[1] != S:
+                raise ValueError('localization_tokens must have one token map per view')
+            ids_streams.append(lt.to(ids.dtype))
+            add_streams.append(self._wte[self.localization_token].view(1, 1, d).expand(B, S, d))
+            pose_ptr = len(ids_streams) - 1
+        NS = len(ids_streams)
+        hf = self._blocks(torch.cat(ids_streams, 1), torch.cat(add_streams, 1), B, NS * S, L,
+                          mask_spec=(-S if NS > 1 else -1)).view(B, NS, S, L, d)
+        out = dict(hidden_states=[hf[:, s] for s in range(NS)])
+        M = B * S * L
+        hi = hf[:, img_ptr].contiguous().view(M, d)
+        lg = torch.empty((M, nE), dtype=torch.float32, device=dev)
+        ops.igemm(hi, self._lm_head, M, d, nE, lg)                           # migt.py:417
+        out['logits'] = lg.view(*orig_shape, nE)
+        if self.use_localization:                                            # migt.py:430-451
+            hp = hf[:, pose_ptr].contiguous().view(M, d)
+            p1 = self._gemm(hp, 'pose_criterion.pose_classifier.c_fc', M, epilogue=ops.EPI_GELU)
+            p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', M)
+            out['pose_prediction'] = geometry.pose_head_postprocess(p2.view(B, S, L, 7), c.pose_multiplier)
+        out['loss'] = 0
+        return out
+
     # ------------------------------------------------------------------ forward (single stream, inference)
     def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False):
-        if training or compute_losses:
-            raise NotImplementedError('training / multi-stream graph is not built yet (SURVEY.md §8 row a18)')
-        if inputs.get('localization_tokens') is not None or inputs.get('output_poses') is not None:
-            raise NotImplementedError('multi-context streams (output_poses / localization_tokens) are a "next" row')
+        if training:
+            raise NotImplementedError('training (dropout, losses, backward) is not built yet (SURVEY.md §8 row a18)')
         if self._sd_host is None or self.device is None:
             raise RuntimeError('MIGT: load_state_dict() and .to("cuda") first')
         c, dev = self.config, self.device
@@ -229,6 +270,20 @@ class MIGT:
             pose_emb = torch.cat([pose_emb, lpe], 1)
         elif Sp != S:
             raise ValueError(f'poses has {Sp} views but input_ids has {S}')
+
+        # ---- optional branch streams (migt.py:371-401): MASK stream for images, LOC stream for poses ----------
+        loc_tokens = inputs.get('localization_tokens')
+        out_poses = inputs.get('output_poses')
+        if compute_losses:                                                   # forward graph of the training step
+            if loc_tokens is None and self.use_localization:
+                loc_tokens = ids
+            if out_poses is None:
+                out_poses = poses
+        if loc_tokens is not None or out_poses is not None:
+            if last_view_logits_only:
+                raise ValueError('last_view_logits_only applies to the single-stream call')
+            return self._call_streams(ids, pose_emb, loc_tokens, out_poses, B, S, L, orig_shape)
+
         hf = self._blocks(ids, pose_emb, B, S, L)
 
         out = dict(hidden_states=[hf.view(B, S, L, d)])
