@@ -163,6 +163,48 @@ int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx
 /* clip[-1,1] -> /2+0.5 -> trunc(x*255.5) uint8  (evaluate_transformer.py:128-129, TF semantics) */
 int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
+ * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
+ * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.
+ * ------------------------------------------------------------------------------------- */
+/* dst[c][r] = src[r][c], `batch` matrices with strides (floats) */
+int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
+                     int64_t bs_src, int64_t bs_dst, void* stream);
+/* out[n] (+)= sum_m x[m][n]  (bias gradients; deterministic two-stage)  ws: vf_colsum_workspace_bytes(N) */
+size_t vf_colsum_workspace_bytes(int N);
+int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream);
+/* LayerNormalization backward (migt.py:225,227,292): dx, and dgamma/dbeta (+)= */
+size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d);
+int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                         int64_t rows, int d, float eps, int accumulate, void* ws, void* stream);
+/* exact-erf GELU (tf.nn.gelu, migt.py:13,70) forward on a saved pre-activation, and its backward */
+int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream);
+int vf_gelu_bwd_f32(const float* u, const float* df, float* du, int64_t n, void* stream);
+/* materialised attention probabilities for the backward pass: s[b][q][k] -> softmax(s*scale masked with -1e4) in
+ * place (branching_attention.py:5-18,101-117; mask_spec as vf_attn_blockcausal_f32's twin_view), and
+ * dS = P*(dP - sum dP*P)*scale (zero where masked) in place on dp */
+int vf_softmax_mask_f32(float* s, int64_t batch, int T, int L, int mask_spec, float scale, void* stream);
+int vf_softmax_mask_bwd_f32(const float* p, float* dp, int64_t batch, int T, int L, int mask_spec, float scale, void* stream);
+/* tf.nn.sparse_softmax_cross_entropy_with_logits (migt.py:423): loss[r], dlogits[r][:] = (softmax - onehot)*row_weight[r] */
+int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* row_weight, float* loss, float* dlogits,
+                      int64_t rows, int V, void* stream);
+/* pose MSE of QuaternionPoseRepresentation.call (migt.py:165-177): raw [rows][7], gt [rows/L][7] */
+int vf_pose_mse_f32(const float* raw, const float* gt, const float* row_weight, float* pos_loss, float* ori_loss, float* draw,
+                    int64_t rows, int L, float position_multiplier, void* stream);
+/* backward of vf_embed_sum_f32: dwte (atomic scatter), dwpe (atomic), dadd[bs][:] = sum_l dh */
+int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
+                     int vocab, void* stream);
+/* weight/bias gradient of vf_dense_small_k_gelu_f32's linear part: dW[k][n] += sum_r x[r][k]*dy[r][n], db[n] += sum_r dy */
+int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* db, int64_t rows, int K, int N, void* stream);
+/* AdamWeightDecay step (viewformer/models/utils.py:507-537 on Keras Adam): p -= lr_decay*p; m,v update;
+ * p -= lr_adam * m / (sqrt(v) + eps)   with lr_adam = lr*sqrt(1-b2^t)/(1-b1^t), lr_decay = lr*weight_decay or 0 */
+int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_decay, float lr_adam, float beta1,
+                 float beta2, float eps, void* stream);
+int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream);
+/* tf.clip_by_norm per tensor (migt.py:486-487): x *= clip / max(||x||, clip); scratch1 = one float */
+int vf_clip_by_norm_f32(float* x, int64_t n, float clip, float* scratch1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,7 +220,7 @@ def pose_head(sd, cfg, hidden, dtype):
 
 
 def migt_forward(sd, cfg, input_ids, poses, localization_tokens=None, output_poses=None,
-                 dtype=torch.float32, compute_losses=False):
+                 dtype=torch.float32, compute_losses=False, grad=False):
     """MIGT.call (training=False), migt.py:338-455.
 
     input_ids [B,S,t,t] int, poses [B,Sp,7] float32.  Returns dict with
@@ -229,7 +229,7 @@ def migt_forward(sd, cfg, input_ids, poses, localization_tokens=None, output_pos
     [B,S,L,7].  ``compute_losses=True`` builds the 2-/3-stream training graph
     (loss values themselves are not restated here).
     """
-    with torch.no_grad():
+    with (torch.enable_grad() if grad else torch.no_grad()):     # grad=True: autograd reference for the training step
         B, S = input_ids.shape[:2]
         ids = input_ids.reshape(B, S, -1).long()
         L = ids.shape[-1]

@@ -1,0 +1,238 @@
+"""Training step.  CPU: oracle schedule / optimizer restatement and the DP gradient
+all-reduce over gloo (world 2).  GPU: every backward kernel against torch autograd, the full-step gradients
+against fp64 autograd over the oracle, and the AdamWeightDecay update against its numpy restatement."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import TINY_MIGT
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_schedules_match_reference_formulas():
+    from oracle import train_oracle as to
+    from viewformer_amd.train import learning_rate, parse_schedule
+    # WarmUp: lr * step/warmup below warmup; CosineDecay(init, total - warmup) after (models/utils.py:346-361,403-412)
+    assert learning_rate(0, 1e-4, 40000, 2000) == 0.0
+    assert abs(learning_rate(1000, 1e-4, 40000, 2000) - 0.5e-4) < 1e-12
+    assert abs(learning_rate(2000, 1e-4, 40000, 2000) - 1e-4) < 1e-12
+    assert abs(learning_rate(21000, 1e-4, 40000, 2000) - 0.5e-4) < 1e-12
+    assert learning_rate(40000, 1e-4, 40000, 2000) < 1e-12 and learning_rate(10 ** 6, 1e-4, 40000, 2000) < 1e-12
+    for s in (0, 7, 1999, 2000, 12345, 39999):
+        assert abs(learning_rate(s, 6.4e-4, 40000, 2000) - to.learning_rate(s, 6.4e-4, 40000, 2000)) < 1e-15
+    f = parse_schedule('cosine(0,1,120000)')                      # README.md:356 (SM7)
+    assert f(0) == 0.0 and abs(f(60000) - 0.5) < 1e-12 and abs(f(120000) - 1.0) < 1e-12 and f(10 ** 7) == 1.0
+    assert parse_schedule('5.')(123) == 5.0
+    assert abs(to.schedule_value('cosine(0,1,120000)', 30000) - f(30000)) < 1e-15
+
+
+def test_oracle_adam_weight_decay_step():
+    from oracle import train_oracle as to
+    from viewformer_amd.config import MIGTConfig
+    cfg = MIGTConfig(learning_rate=1e-3, weight_decay=0.05, total_steps=100)
+    p = {'w.weight': np.array([1.0, -2.0]), 'w.bias': np.array([0.5])}
+    g = {'w.weight': np.array([0.1, 0.2]), 'w.bias': np.array([-0.3])}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    lr = to.adam_weight_decay_step(p, g, m, v, step=5, cfg=cfg, warmup_steps=10)
+    assert abs(lr - 0.5e-3) < 1e-15
+    lr_t = lr * math.sqrt(1 - 0.999 ** 6) / (1 - 0.9 ** 6)
+    # weight: decayed then Adam; bias: Adam only
+    w0 = 1.0 - lr * 1.0 * 0.05
+    assert abs(p['w.weight'][0] - (w0 - lr_t * (0.1 * 0.1) / (math.sqrt(0.001 * 0.01) + 1e-8))) < 1e-12
+    assert abs(p['w.bias'][0] - (0.5 - lr_t * (0.1 * -0.3) / (math.sqrt(0.001 * 0.09) + 1e-8))) < 1e-12
+
+
+def _ar_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from viewformer_amd import sharding
+    sharding.init_from_env('gloo')
+    flat = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    handles = sharding.allreduce_sum_ranges(flat, [(0, 8), (8, 8), (8, 40)])
+    for h in handles:
+        h.wait()
+    if rank == 0:
+        torch.save(flat, out)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_is_a_sum_over_replicas(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'g.pt')
+    mp.spawn(_ar_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.equal(torch.load(out), torch.arange(40, dtype=torch.float32) * 3)      # SUM, not mean
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _err(a, b):
+    b = torch.as_tensor(b).double()
+    return ((a.detach().cpu().double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.gpu
+def test_backward_kernels_against_autograd(dev):
+    from viewformer_amd import train_ops as T
+    # transpose (ragged, batched)
+    x = _rand((3, 70, 45), 1)
+    t = T.transpose(x.to(dev), 70, 45, batch=3, bs_src=70 * 45)
+    assert torch.equal(t.cpu(), x.transpose(1, 2).contiguous())
+    # column sums
+    y = _rand((1000, 130), 2)
+    out = torch.ones(130, device=dev)
+    T.colsum(y.to(dev), out, 1000, 130, accumulate=True)
+    assert _err(out, 1 + y.double().sum(0)) < 1e-5
+    # LayerNorm backward
+    rows, d = 150, 768
+    xx, dy, g = (_rand((rows, d), 3) * 2 + 0.3).double().requires_grad_(), _rand((rows, d), 4).double(), (_rand((d,), 5) + 1).double().requires_grad_()
+    b = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    F.layer_norm(xx, (d,), g, b, eps=1e-5).backward(dy)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dx = T.layernorm_bwd(dy.float().to(dev), xx.detach().float().to(dev), g.detach().float().to(dev), dg, db, rows, d)
+    assert _err(dx, xx.grad) < 2e-5 and _err(dg, g.grad) < 2e-5 and _err(db, b.grad) < 2e-5
+    # GELU fwd/bwd
+    u = (_rand((4000,), 6) * 2).double().requires_grad_()
+    F.gelu(u).backward(torch.ones_like(u) * 0.7)
+    assert _err(T.gelu(u.detach().float().to(dev)), F.gelu(u.detach())) < 1e-6
+    assert _err(T.gelu_bwd(u.detach().float().to(dev), torch.full((4000,), 0.7, device=dev)), u.grad) < 1e-5
+    # masked softmax fwd/bwd (streams mask, Sv = 2 views per stream, 3 streams, L = 16)
+    B, Tn, L, Sv = 2, 96, 16, 2
+    s = (_rand((B, Tn, Tn), 7) * 3).double().requires_grad_()
+    qv = torch.arange(Tn) // L
+    qs, qi, ks, ki = qv[:, None] // Sv, qv[:, None] % Sv, qv[None] // Sv, qv[None] % Sv
+    vis = torch.where(qs == 0, (ks == 0) & (ki <= qi), ((ks == 0) & (ki < qi)) | (qv[:, None] == qv[None])).double()
+    p = torch.softmax(s * vis - 1e4 * (1 - vis), -1)
+    dp = _rand((B, Tn, Tn), 8).double()
+    p.backward(dp)
+    pg = T.softmax_mask_(s.detach().float().to(dev).clone(), B, Tn, L, -Sv)
+    assert _err(pg, p.detach()) < 1e-6
+    dsg = T.softmax_mask_bwd_(pg, dp.float().to(dev).clone(), B, Tn, L, -Sv)
+    assert _err(dsg, s.grad) < 1e-5
+    # softmax cross-entropy
+    lg = (_rand((64, 1024), 9) * 2).double().requires_grad_()
+    tg = torch.from_numpy(np.random.Generator(np.random.PCG64(10)).integers(0, 1024, 64))
+    w = torch.linspace(0, 1, 64).double()
+    (F.cross_entropy(lg, tg, reduction='none') * w).sum().backward()
+    loss, dl = T.softmax_ce(lg.detach().float().to(dev), tg.int().to(dev), w.float().to(dev), 64, 1024)
+    assert _err(loss, F.cross_entropy(lg.detach(), tg, reduction='none')) < 1e-6 and _err(dl, lg.grad) < 1e-5
+    # AdamWeightDecay
+    pw, gw = _rand((1000,), 11), _rand((1000,), 12)
+    m0, v0 = _rand((1000,), 13) * 0.1, _rand((1000,), 14).abs() * 0.01
+    pd, md, vd = pw.to(dev).clone(), m0.to(dev).clone(), v0.to(dev).clone()
+    T.adamw_(pd, gw.to(dev), md, vd, 1e-3 * 0.05, 2e-3, 0.9, 0.999, 1e-8)
+    pr = pw.double() * (1 - 1e-3 * 0.05)
+    mr = 0.9 * m0.double() + 0.1 * gw.double()
+    vr = 0.999 * v0.double() + 0.001 * gw.double() ** 2
+    pr = pr - 2e-3 * mr / (vr.sqrt() + 1e-8)
+    # (1 - beta2) is formed in fp32 like Keras does (0.00100004673 vs 0.001): 5e-5 relative on v
+    assert _err(pd, pr) < 1e-5 and _err(md, mr) < 1e-6 and _err(vd, vr) < 1e-4
+    # clip_by_norm
+    z = _rand((5000,), 15)
+    zc = T.clip_by_norm_(z.to(dev).clone(), 3.0, torch.zeros(1, device=dev))
+    assert _err(zc, z.double() * 3.0 / max(z.double().norm().item(), 3.0)) < 1e-6
+
+
+def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0):
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    cfg = MIGTConfig(**TINY_MIGT, dropout=0.0, n_loss_skip=1, localization_weight='cosine(0,2,10)' if loc else '0',
+                     pose_multiplier=0.2, learning_rate=1e-3, weight_decay=0.05, total_steps=50, gradient_clip_val=clip)
+    sd = make_migt_weights(cfg, seed=seed, std=0.08)
+    g = np.random.Generator(np.random.PCG64(seed + 3))
+    t = cfg.token_image_size
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, t, t)))
+    _, cams = synthetic_scene_batch(B, S, 8, seed)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])       # process_batch, train_transformer.py:31-64
+    model = MIGT(cfg).load_state_dict(sd).to(dev)
+    return cfg, sd, tokens, poses, MIGTTrainer(model, warmup_steps=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loc', [False, True])
+def test_train_step_gradients_match_autograd(dev, loc):
+    from oracle import train_oracle as to
+    cfg, sd, tokens, poses, tr = _setup(loc, dev)
+    tr.step_count = 3                       # a non-trivial localization weight
+    metrics = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    grads, ref_metrics = to.gradients(sd, cfg, poses, tokens, step=3)
+    assert abs(float(metrics['loss']) - ref_metrics['loss']) < 1e-4 * max(1.0, abs(ref_metrics['loss']))
+    assert abs(float(metrics['ce_loss']) - ref_metrics['ce_loss']) < 1e-4
+    worst = ('', 0.0)
+    for name in tr.names:
+        ref = grads[name].reshape(tr.slices[name][2])
+        got = tr.g(name)
+        if not loc and name.startswith('pose_criterion'):
+            assert float(got.abs().max()) == 0.0
+            continue
+        e = _err(got, ref)
+        if e > worst[1]:
+            worst = (name, e)
+        assert e < 2e-3, (name, e, float(ref.abs().max()))
+    print('worst relative gradient error', worst)
+
+
+@pytest.mark.gpu
+def test_train_steps_follow_the_optimizer_restatement(dev):
+    """3 full steps (forward, backward, AdamWeightDecay with warm-up) vs autograd + numpy optimizer on the oracle"""
+    from oracle import train_oracle as to
+    cfg, sd, tokens, poses, tr = _setup(True, dev, seed=2)
+    params = {k: np.asarray(v, dtype=np.float64).copy() for k, v in sd.items()}
+    params = {k: (v.reshape(-1) if k.endswith('.bias') else v) for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    losses = []
+    for step in range(3):
+        met = tr.train_step(poses, tokens)
+        grads, ref = to.gradients(params, cfg, poses, tokens, step=step)
+        to.adam_weight_decay_step(params, {k: grads[k].numpy().reshape(params[k].shape) for k in params}, m, v2, step, cfg,
+                                  warmup_steps=4)
+        losses.append((float(met['loss']), ref['loss']))
+    for a, b in losses:
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), losses
+    assert losses[2][0] < losses[0][0]                         # it learns on a fixed batch
+    new = tr.state_dict()
+    lr_sum = sum(to.learning_rate(s, cfg.learning_rate, cfg.total_steps, 4) for s in range(3))
+    for k in tr.names:
+        ref = torch.as_tensor(params[k].reshape(new[k].shape))
+        diff = (new[k].double() - ref).abs().max().item()
+        # Adam normalises by sqrt(v): a coordinate whose true gradient is ~0 (e.g. the key bias of c_attn — softmax is
+        # invariant to it) moves by +-lr on rounding noise alone, in the reference too; allow that much absolute slack.
+        assert diff < 2e-3 * ref.abs().max().item() + 0.2 * lr_sum, (k, diff)
+
+
+@pytest.mark.gpu
+def test_per_tensor_gradient_clipping(dev):
+    cfg, sd, tokens, poses, tr = _setup(False, dev, clip=1e-3)
+    tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    for name in tr.names:
+        assert float(tr.g(name).norm()) <= 1e-3 * (1 + 1e-4), name
+    with pytest.raises(NotImplementedError):
+        from viewformer_amd.config import MIGTConfig
+        from viewformer_amd.migt import MIGT
+        from viewformer_amd.train import MIGTTrainer
+        from viewformer_amd.weights import make_migt_weights
+        c2 = MIGTConfig(**TINY_MIGT)                           # default dropout 0.1
+        MIGTTrainer(MIGT(c2).load_state_dict(make_migt_weights(c2)).to(dev))

@@ -50,6 +50,23 @@ EXPORTS = {
     'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),
     'vf_postprocess_u8': (c_int, [P, P, c_int64, P]),
+    # ---- training step
+    'vf_transpose_f32': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, c_int64, P]),
+    'vf_colsum_workspace_bytes': (c_size_t, [c_int]),
+    'vf_colsum_f32': (c_int, [P, P, c_int64, c_int, c_int64, c_int, P, P]),
+    'vf_layernorm_bwd_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P]),
+    'vf_gelu_f32': (c_int, [P, P, c_int64, P]),
+    'vf_gelu_bwd_f32': (c_int, [P, P, P, c_int64, P]),
+    'vf_softmax_mask_f32': (c_int, [P, c_int64, c_int, c_int, c_int, c_float, P]),
+    'vf_softmax_mask_bwd_f32': (c_int, [P, P, c_int64, c_int, c_int, c_int, c_float, P]),
+    'vf_softmax_ce_f32': (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    'vf_pose_mse_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, P]),
+    'vf_embed_bwd_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'vf_dense_small_k_bwd_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    'vf_adamw_f32': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
+    'vf_add_inplace_f32': (c_int, [P, P, c_int64, P]),
+    'vf_clip_by_norm_f32': (c_int, [P, c_int64, c_float, P, P]),
 }
 
 _lib = None

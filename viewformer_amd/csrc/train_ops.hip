@@ -1,0 +1,472 @@
+// Training-step kernels of the MIGT transformer, gfx950, fp32.
+//
+// The dense contractions of the backward pass reuse igemm_f32.hip (dX = dY.W^T with the weight packed
+// transposed; dW = X^T.dY through vf_transpose_f32 + a packed dY).  This file holds the HBM-bound pieces:
+// transposes, column sums (bias grads), LayerNorm backward, exact-erf GELU forward/backward, the
+// materialised branching-attention softmax (forward with the reference's w*m - 1e4*(1-m) mask and its
+// backward), softmax-cross-entropy, the pose MSE, the embedding backward and the AdamWeightDecay update.
+// Reference: MIGT.train_step migt.py:464-505, losses :416-448, QuaternionPoseRepresentation.call :156-177,
+// AdamWeightDecay / WarmUp / create_optimizer viewformer/models/utils.py:310-564.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+inline unsigned grid1(long long total, int per_block, unsigned cap = 32768) {
+    long long b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------ batched 2-D transpose (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                        int cols, long long ld_src, long long ld_dst,
+                                                        long long bs_src, long long bs_dst) {
+    __shared__ float tile[32][33];
+    const float* s = src + blockIdx.z * bs_src;
+    float* d = dst + blockIdx.z * bs_dst;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? s[(long long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;          // dst[c][r]
+        if (c < cols && r < rows) d[(long long)c * ld_dst + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ------------------------------------------------------------------ column sums: out[n] (+)= sum_m x[m][n]
+// stage 1: grid (ceil(N/256), nsplit) -> part[split][N]; stage 2 reduces the splits in fixed order (deterministic)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long long M,
+                                                             int N, long long ld, int nsplit) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long per = (M + nsplit - 1) / nsplit;
+    const long long m0 = blockIdx.y * per, m1 = min(M, m0 + per);
+    float s = 0.f;
+    for (long long m = m0; m < m1; ++m) s += x[m * ld + n];
+    part[(long long)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N,
+                                                           int nsplit, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += part[(long long)i * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (one wave per row)
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma/dbeta partials per row-block
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ dgb_part, long long rows, int d, float eps,
+                                                            int rows_per_block) {
+    // each wave walks rows_per_block/4 rows and keeps per-lane dgamma/dbeta partials in registers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    f32x4 dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (long long row = r0 + wave; row < min(rows, r0 + rows_per_block); row += 4) {
+        f32x4 xv[MAXV], gv[MAXV], dyv[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                xv[i] = *reinterpret_cast<const f32x4*>(x + row * d + c * 4);
+                dyv[i] = *reinterpret_cast<const f32x4*>(dy + row * d + c * 4);
+                s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+            }
+        }
+        const float mean = vf_wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = xv[i][e] - mean; q += t * t; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(vf_wave_sum(q) / (float)d + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[i][e] - mean) * rstd;
+                    const float g = dyv[i][e] * gm[e];
+                    gv[i][e] = g;
+                    xv[i][e] = xh;
+                    sg += g;
+                    sgx += g * xh;
+                    dg[i][e] += dyv[i][e] * xh;
+                    db[i][e] += dyv[i][e];
+                }
+            }
+        }
+        sg = vf_wave_sum(sg) / (float)d;
+        sgx = vf_wave_sum(sgx) / (float)d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[i][e] - sg - xv[i][e] * sgx);
+                *reinterpret_cast<f32x4*>(dx + row * d + c * 4) = o;
+            }
+        }
+    }
+    // partial[block][wave][2][d]
+    float* p = dgb_part + ((long long)blockIdx.x * 4 + wave) * 2 * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            *reinterpret_cast<f32x4*>(p + c * 4) = dg[i];
+            *reinterpret_cast<f32x4*>(p + d + c * 4) = db[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GELU (exact erf) forward / backward
+__global__ void gelu_kernel(const float* __restrict__ u, float* __restrict__ f, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        f[i] = vf_gelu_erf(u[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df, float* __restrict__ du, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = u[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        du[i] = df[i] * (cdf + x * pdf);
+    }
+}
+
+// ------------------------------------------------------------------ materialised attention softmax with the view mask
+__device__ __forceinline__ bool vf_visible(int qv, int kv, int spec) {
+    if (spec <= -2) {                       // streams of Sv views (same rule as attention_f32.hip)
+        const int Sv = -spec;
+        const int qs = qv / Sv, qi = qv - qs * Sv, ks = kv / Sv, ki = kv - ks * Sv;
+        return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+    }
+    const int Vc = spec >= 0 ? spec : 0x3fffffff;
+    return kv == qv || min(kv, Vc) < min(qv, Vc);
+}
+// one wave per score row: s -> softmax(s*m - 1e4*(1-m)) in place; rows = batch*T, row length T
+__global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ s, long long rows, int T, int L, int spec,
+                                                           float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % T);
+    const int qv = L > 0 ? q / L : 0;
+    float* r = s + row * T;
+    float mx = -INFINITY;
+    for (int c = lane; c < T; c += 64) {
+        float v = r[c] * scale;
+        if (L > 0 && !vf_visible(qv, c / L, spec)) v = -1e4f;
+        r[c] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = vf_wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < T; c += 64) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
+    sum = vf_wave_sum(sum);
+    for (int c = lane; c < T; c += 64) r[c] = r[c] / sum;
+}
+// dS = P * (dP - sum_j dP*P) * scale, zero where masked (the -1e4 constant and w*0 carry no gradient); in place on dP
+__global__ __launch_bounds__(256) void softmax_mask_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long long rows,
+                                                               int T, int L, int spec, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % T);
+    const int qv = L > 0 ? q / L : 0;
+    const float* pr = p + row * T;
+    float* dr = dp + row * T;
+    float dot = 0.f;
+    for (int c = lane; c < T; c += 64) dot += pr[c] * dr[c];
+    dot = vf_wave_sum(dot);
+    for (int c = lane; c < T; c += 64) {
+        float g = pr[c] * (dr[c] - dot) * scale;
+        if (L > 0 && !vf_visible(qv, c / L, spec)) g = 0.f;
+        dr[c] = g;
+    }
+}
+
+// ------------------------------------------------------------------ softmax cross-entropy (one wave per row)
+// loss[r] = lse - logit[target]; dlogits = (softmax - onehot) * w[r]   (sparse_softmax_cross_entropy_with_logits, migt.py:423)
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int* __restrict__ target,
+                                                 const float* __restrict__ w, float* __restrict__ loss, float* __restrict__ dl,
+                                                 long long rows, int V) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + row * V;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
+    mx = vf_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(x[c] - mx);
+    s = vf_wave_sum(s);
+    const int t = target[row];
+    const float lse = mx + logf(s);
+    if (lane == 0) loss[row] = lse - x[t];
+    const float wr = w[row];
+    float* d = dl + row * V;
+    for (int c = lane; c < V; c += 64) d[c] = (expf(x[c] - mx) / s - (c == t ? 1.f : 0.f)) * wr;
+}
+
+// ------------------------------------------------------------------ pose MSE (migt.py:165-177): per token
+// y = gt * [pm,pm,pm,1,1,1,1]; pos = mean_3 (y - raw)^2 ; ori = mean_4 (y - raw)^2 ; d raw = 2 (raw - y)/k * w[row]
+__global__ void pose_loss_kernel(const float* __restrict__ raw, const float* __restrict__ gt, const float* __restrict__ w,
+                                 float* __restrict__ pos, float* __restrict__ ori, float* __restrict__ draw, long long rows,
+                                 int L, float pm) {
+    const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* g = gt + (r / L) * 7;
+    const float* x = raw + r * 7;
+    float* d = draw + r * 7;
+    const float wr = w[r];
+    float p = 0.f, o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float e = x[i] - g[i] * pm; p += e * e; d[i] = 2.f * e / 3.f * wr; }
+#pragma unroll
+    for (int i = 3; i < 7; ++i) { const float e = x[i] - g[i]; o += e * e; d[i] = 2.f * e / 4.f * wr; }
+    pos[r] = p / 3.f;
+    ori[r] = o / 4.f;
+}
+
+// ------------------------------------------------------------------ embedding backward
+// dwte[ids[tok]] += dh[tok] (float atomics: rows collide), dadd[bs] = sum_l dh, dwpe[l] += sum_bs dh (atomics)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh, const int* __restrict__ ids,
+                                                        float* __restrict__ dwte, float* __restrict__ dwpe,
+                                                        float* __restrict__ dadd, long long BS, int L, int d, int vocab) {
+    // one block per (bs): threads stride over d; loop over l
+    const long long bs = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const long long tok = bs * L + l;
+            const float g = dh[tok * d + c];
+            acc += g;
+            int id = ids[tok];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            atomicAdd(dwte + (long long)id * d + c, g);
+            atomicAdd(dwpe + (long long)l * d + c, g);
+        }
+        dadd[bs * d + c] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ tiny dense (K <= 16) weight/bias gradient
+__global__ void dense_small_k_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
+                                         float* __restrict__ db, long long rows, int K, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc[16];
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    float b = 0.f;
+    for (long long r = 0; r < rows; ++r) {
+        const float g = dy[r * N + n];
+        b += g;
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(x[r * K + k], g, acc[k]);
+    }
+    for (int k = 0; k < K; ++k) dW[(long long)k * N + n] += acc[k];
+    db[n] += b;
+}
+
+// ------------------------------------------------------------------ AdamWeightDecay (models/utils.py:507-537 + Keras Adam)
+// var -= lr_decay * var (decoupled, before the Adam update); m,v update; var -= lr_adam * m / (sqrt(v) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr_decay, float lr_adam, float b1, float b2, float eps) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float w = p[i];
+        w -= lr_decay * w;
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = w - lr_adam * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ------------------------------------------------------------------ axpy-style helpers
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a[i] += b[i];
+}
+__global__ void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i] * x[i];
+    s = vf_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ void scale_kernel(float* __restrict__ x, const float* __restrict__ sumsq, float clip, long long n) {
+    // tf.clip_by_norm: x * clip / max(norm, clip)
+    const float norm = sqrtf(*sumsq);
+    const float f = clip / fmaxf(norm, clip);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
+                     int64_t bs_src, int64_t bs_dst, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || batch < 1 || ld_src < cols || ld_dst < rows) return VF_ERR_BAD_ARG;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, (long long)ld_src,
+                       (long long)ld_dst, (long long)bs_src, (long long)bs_dst);
+    return vf_last_status();
+}
+
+size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)64 * N * sizeof(float) : 0; }
+
+int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream) {
+    if (!x || !out || !ws || M <= 0 || N <= 0 || ld < N) return VF_ERR_BAD_ARG;
+    int nsplit = (int)((M + 511) / 512);
+    if (nsplit > 64) nsplit = 64;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, s, x, (float*)ws, (long long)M, N,
+                       (long long)ld, nsplit);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ws, out, N, nsplit, accumulate);
+    return vf_last_status();
+}
+
+size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
+    if (rows <= 0 || d <= 0) return 0;
+    const int64_t blocks = (rows + 63) / 64;
+    // [blocks*4][2d] per-wave partials + [64][2d] column-sum scratch + [2d] result
+    return ((size_t)blocks * 4 * 2 * d + (size_t)64 * 2 * d + (size_t)2 * d) * sizeof(float);
+}
+
+int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                         int64_t rows, int d, float eps, int accumulate, void* ws, void* stream) {
+    if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !ws || rows <= 0 || d <= 0) return VF_ERR_BAD_ARG;
+    if ((d & 3) || d > 1024) return VF_ERR_UNSUPPORTED;
+    const int rpb = 64;
+    const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
+    int st = vf_last_status();
+    if (st) return st;
+    // partial layout [blocks*4][2][d]: reduce the (blocks*4) rows of the [.., 2d] matrix
+    const int64_t prow = (int64_t)blocks * 4;
+    // column sums of a [prow][2d] matrix -> [2d]; dgamma = first d, dbeta = second d.  Reuse colsum with a private tail of ws.
+    float* tmp = (float*)ws + (size_t)prow * 2 * d;    // caller sized ws via vf_layernorm_bwd_workspace_bytes + colsum ws
+    float* outv = tmp + (size_t)64 * 2 * d;
+    st = vf_colsum_f32((const float*)ws, outv, prow, 2 * d, 2 * d, 0, tmp, stream);
+    if (st) return st;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv, dgamma, d, 1, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv + d, dbeta, d, 1, accumulate);
+    return vf_last_status();
+}
+
+int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream) {
+    if (!u || !f || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid1(n, 256)), dim3(256), 0, (hipStream_t)stream, u, f, (long long)n);
+    return vf_last_status();
+}
+
+int vf_gelu_bwd_f32(const float* u, const float* df, float* du, int64_t n, void* stream) {
+    if (!u || !df || !du || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1(n, 256)), dim3(256), 0, (hipStream_t)stream, u, df, du, (long long)n);
+    return vf_last_status();
+}
+
+int vf_softmax_mask_f32(float* s, int64_t batch, int T, int L, int mask_spec, float scale, void* stream) {
+    if (!s || batch <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
+    const long long rows = (long long)batch * T;
+    hipLaunchKernelGGL(softmax_mask_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, rows, T, L,
+                       mask_spec, scale);
+    return vf_last_status();
+}
+
+int vf_softmax_mask_bwd_f32(const float* p, float* dp, int64_t batch, int T, int L, int mask_spec, float scale, void* stream) {
+    if (!p || !dp || batch <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
+    const long long rows = (long long)batch * T;
+    hipLaunchKernelGGL(softmax_mask_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, rows,
+                       T, L, mask_spec, scale);
+    return vf_last_status();
+}
+
+int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* row_weight, float* loss, float* dlogits,
+                      int64_t rows, int V, void* stream) {
+    if (!logits || !target || !row_weight || !loss || !dlogits || rows <= 0 || V <= 0) return VF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, row_weight,
+                       loss, dlogits, (long long)rows, V);
+    return vf_last_status();
+}
+
+int vf_pose_mse_f32(const float* raw, const float* gt, const float* row_weight, float* pos_loss, float* ori_loss, float* draw,
+                    int64_t rows, int L, float position_multiplier, void* stream) {
+    if (!raw || !gt || !row_weight || !pos_loss || !ori_loss || !draw || rows <= 0 || L <= 0) return VF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_loss_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, gt,
+                       row_weight, pos_loss, ori_loss, draw, (long long)rows, L, position_multiplier);
+    return vf_last_status();
+}
+
+int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
+                     int vocab, void* stream) {
+    if (!dh || !ids || !dwte || !dwpe || !dadd || BS <= 0 || L <= 0 || d <= 0 || vocab <= 0) return VF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)BS), dim3(256), 0, (hipStream_t)stream, dh, ids, dwte, dwpe, dadd,
+                       (long long)BS, L, d, vocab);
+    return vf_last_status();
+}
+
+int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* db, int64_t rows, int K, int N, void* stream) {
+    if (!x || !dy || !dW || !db || rows <= 0 || K <= 0 || N <= 0) return VF_ERR_BAD_ARG;
+    if (K > 16) return VF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dense_small_k_bwd_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, dy, dW, db,
+                       (long long)rows, K, N);
+    return vf_last_status();
+}
+
+int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_decay, float lr_adam, float beta1,
+                 float beta2, float eps, void* stream) {
+    if (!param || !grad || !m || !v || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n,
+                       lr_decay, lr_adam, beta1, beta2, eps);
+    return vf_last_status();
+}
+
+int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream) {
+    if (!a || !b || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n);
+    return vf_last_status();
+}
+
+int vf_clip_by_norm_f32(float* x, int64_t n, float clip, float* scratch1, void* stream) {
+    if (!x || !scratch1 || n <= 0 || clip <= 0.f) return VF_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n, 256, 1024)), dim3(256), 0, s, x, scratch1, (long long)n);
+    hipLaunchKernelGGL(scale_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, s, x, scratch1, clip, (long long)n);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -54,6 +54,17 @@ def sum_over_ranks(value: float, device='cpu') -> float:
     return float(t.item())
 
 
+def allreduce_sum_ranges(flat: torch.Tensor, ranges, group=None):
+    """The training step's one collective (the 88.4 M-element gradient all-reduce): SUM over
+    replicas of contiguous ranges of the flat gradient buffer — no division by the world size, because the
+    reference sums per-replica mean-loss gradients (migt.py:471-476 + MirroredStrategy).  One asynchronous
+    RCCL (gloo in the CPU tests) all-reduce per range (a transformer layer = 28 MB fp32, large enough to run at
+    xGMI link rate); returns the work handles."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    return [dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True) for a, b in ranges if b > a]
+
+
 def gather_to_rank0(t: torch.Tensor):
     """optional: collect per-rank result tensors (e.g. uint8 novel views) on rank 0"""
     if not (dist.is_available() and dist.is_initialized()):

@@ -1,0 +1,363 @@
+"""One data-parallel training step of the MIGT transformer on MI355X (BASELINE config #4).
+
+Host-side mirror of ``MIGT.train_step`` (viewformer/models/migt.py:464-505): multi-stream forward with saved
+activations (streams of :392-401 laid out as extra views, attention by the STREAMS mask), the losses of :416-448
+(token cross-entropy on the MASK stream, pose MSE on the LOC stream, views >= n_loss_skip, per-sample means,
+``reduce_mean`` over the local batch :476), backward, optional per-tensor ``clip_by_norm`` (:486-487), gradient
+all-reduce SUM across replicas (what MirroredStrategy does under ``apply_gradients`` :488 — per-replica mean loss,
+summed gradients, no division by the world size) and the AdamWeightDecay update with the warm-up + cosine schedule
+of ``create_optimizer`` (viewformer/models/utils.py:371-437,440-564; compile() :457-462 uses 2000 warm-up steps).
+
+All arithmetic is in libvf_hip.so: the backward's dense contractions are vf_igemm_f32 launches
+(dX = dY.W^T with transposed-packed weights, dW = X^T.dY through a transpose + packed dY), attention backward
+re-materialises the probabilities per head with batched GEMMs (first version: dense, no causal skipping), the rest
+are the HBM-bound kernels of csrc/train_ops.hip.  Parameters, gradients and Adam moments live in flat fp32
+buffers so that a layer's gradients are one contiguous RCCL all-reduce issued as soon as that layer's backward
+is done (overlapping the remaining backward).
+
+Limits of this first version (raise NotImplementedError otherwise): dropout must be 0, label_smoothing 0,
+random_pose_multiplier 1, no dynamic pose-loss weighting.
+"""
+import math
+import re
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from . import train_ops as T
+from . import geometry
+from . import sharding
+from .migt import MIGT
+
+
+def parse_schedule(s):
+    """'1', '5.' or 'cosine(a,b,N)' -> callable(step) (viewformer/utils/schedules.py:72-112,194-201)"""
+    s = str(s).strip()
+    m = re.fullmatch(r'cosine\(([^,]+),([^,]+),([^)]+)\)', s)
+    if m:
+        a, b, n = float(m.group(1)), float(m.group(2)), float(m.group(3))
+        return lambda t: b + (a - b) * 0.5 * (math.cos(min(1.0, t / n) * math.pi) + 1.0)
+    v = float(s)
+    return lambda t: v
+
+
+def learning_rate(step, init_lr, total_steps, warmup_steps):
+    """WarmUp(CosineDecay) of create_optimizer (models/utils.py:310-361,403-412); ``step`` = optimizer.iterations"""
+    if warmup_steps and step < warmup_steps:
+        return init_lr * (step / warmup_steps)
+    decay_steps = max(total_steps - warmup_steps, 1)
+    t = min(step - warmup_steps, decay_steps)
+    return init_lr * 0.5 * (1.0 + math.cos(math.pi * t / decay_steps))
+
+
+class MIGTTrainer:
+    def __init__(self, model: MIGT, warmup_steps: int = 2000, beta1: float = 0.9, beta2: float = 0.999,
+                 eps: float = 1e-8, process_group=None):
+        cfg = model.config
+        if cfg.dropout != 0:
+            raise NotImplementedError('dropout > 0 is not built yet: set dropout=0.0 in MIGTConfig')
+        if cfg.label_smoothing != 0 or cfg.random_pose_multiplier != 1 or cfg.use_dynamic_pose_loss:
+            raise NotImplementedError('label smoothing / random pose multiplier / dynamic pose loss are not built')
+        if model._sd_host is None or model.device is None:
+            raise RuntimeError('load_state_dict() and .to("cuda") the model first')
+        self.model, self.cfg, self.dev = model, cfg, model.device
+        self.warmup_steps, self.b1, self.b2, self.eps = warmup_steps, beta1, beta2, eps
+        self.group = process_group
+        self.step_count = 0                          # optimizer.iterations == model._train_counter
+        self.loc_weight = parse_schedule(cfg.localization_weight)
+        self._layout()
+        self._bind()
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _layout(self):
+        h, c = self.model._sd_host, self.cfg
+        head = ['wte.weight', 'wpe.embeddings']
+        for n in ('pose_embedding.c_fc', 'pose_embedding.c_proj', 'pose_criterion.pose_classifier.c_fc',
+                  'pose_criterion.pose_classifier.c_proj'):
+            head += [n + '.weight', n + '.bias']
+        head += ['ln_f.gamma', 'ln_f.beta']
+        layers = []
+        for i in range(c.n_layer):
+            p = f'h.{i}'
+            names = [p + '.ln_1.gamma', p + '.ln_1.beta', p + '.attn.c_attn.weight', p + '.attn.c_attn.bias',
+                     p + '.attn.c_proj.weight', p + '.attn.c_proj.bias', p + '.ln_2.gamma', p + '.ln_2.beta',
+                     p + '.mlp.c_fc.weight', p + '.mlp.c_fc.bias', p + '.mlp.c_proj.weight', p + '.mlp.c_proj.bias']
+            layers.append(names)
+        self.names = head + [n for l in layers for n in l]
+        self.slices, off = {}, 0
+        for n in self.names:
+            shape = tuple(h[n].shape)
+            k = int(np.prod(shape))
+            self.slices[n] = (off, off + k, shape)
+            off += (k + 3) // 4 * 4                      # keep every tensor 16-byte aligned
+        self.total = off
+        self.head_range = (0, self.slices[layers[0][0]][0] if layers else off)
+        self.layer_ranges = [(self.slices[l[0]][0], self.slices[l[-1]][1]) for l in layers]
+        dev = self.dev
+        self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        for n in self.names:
+            a, b, _ = self.slices[n]
+            self.flat_p[a:b] = torch.from_numpy(h[n].reshape(-1)).to(dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self._scratch = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def p(self, name):
+        a, b, s = self.slices[name]
+        return self.flat_p[a:b].view(s)
+
+    def g(self, name):
+        a, b, s = self.slices[name]
+        return self.flat_g[a:b].view(s)
+
+    def _bind(self):
+        """point the model's tensors at the flat buffer and (re)build every packed weight"""
+        m, c = self.model, self.cfg
+        m._wte, m._wpe = self.p('wte.weight'), self.p('wpe.embeddings')
+        for name, dn in m._dense.items():
+            dn.w_raw, dn.bias = self.p(name + '.weight'), self.p(name + '.bias')
+        for name in list(m._ln):
+            m._ln[name] = (self.p(name + '.gamma'), self.p(name + '.beta'))
+        self.wpT = getattr(self, 'wpT', {})
+        self.repack()
+
+    def repack(self):
+        m, c = self.model, self.cfg
+        nE, d = c.n_embeddings, c.d_model
+        for name, dn in m._dense.items():
+            if dn.k % 32 == 0:
+                dn.wp = ops.pack(dn.w_raw, dn.k, dn.n, 1, sk=dn.n, sn=1, st=0, out=dn.wp)                  # forward: x @ W
+            if dn.n % 32 == 0:                                                                                # dX = dY @ W^T
+                self.wpT[name] = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0, out=self.wpT.get(name))
+        m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
+        self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
+
+    # ------------------------------------------------------------------ building blocks
+    def _linear(self, x, name, M, res=None):
+        return self.model._gemm(x, name, M, res=res)
+
+    def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None):
+        """grads of y = x @ W + b given dy [M,N]; returns dx (+res) or None"""
+        dn = self.model._dense[name]
+        K, N = dn.k, dn.n
+        T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
+        Mp = (M + 31) // 32 * 32                                                     # reduction length padded to the K stage
+        xt = None
+        if Mp != M:
+            xt = torch.zeros((1, K, Mp), dtype=torch.float32, device=x.device)
+        xt = T.transpose(x, M, K, out=xt, ld_dst=Mp)                                 # [K][Mp]
+        dyp = ops.pack(dy, M, N, 1, sk=N, sn=1, st=0)                                # rows >= M are zero-filled by the packer
+        gw = self.g(name + '.weight')
+        ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                             # dW += X^T dY
+        if not need_dx:
+            return None
+        dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        ops.igemm(dy, self.wpT[name], M, N, K, dx, res=res)
+        return dx
+
+    def _ln_bwd(self, name, dy, x, M):
+        d = self.cfg.d_model
+        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
+
+    def _attn_bwd(self, qkv, datt, B, Tn, L, spec):
+        """dQKV from dA by re-materialising P per head (branching_attention.py:82-126 semantics)"""
+        c = self.cfg
+        d, H = c.d_model, c.n_head
+        M = B * Tn
+        dqkv = torch.empty((M, 3 * d), dtype=torch.float32, device=qkv.device)
+        S = torch.empty((B, Tn, Tn), dtype=torch.float32, device=qkv.device)
+        dP = torch.empty_like(S)
+        pf_T = ops.packed_floats(64, Tn)
+        bs = Tn * 3 * d
+        for h in range(H):
+            q, k, v = qkv[:, d + h * 64:], qkv[:, 2 * d + h * 64:], qkv[:, h * 64:]
+            da = datt[:, h * 64:]
+            kp = ops.pack(k, 64, Tn, 1, sk=1, sn=3 * d, st=0, batch=B, src_bstride=bs)              # B[c][key] = K[key][c]
+            ops.igemm(q, kp, Tn, 64, Tn, S, lda=3 * d, batch=B, stride_x=bs, stride_w=pf_T, stride_out=Tn * Tn)
+            T.softmax_mask_(S, B, Tn, L, spec, 1.0)                                                   # P
+            vp = ops.pack(v, 64, Tn, 1, sk=1, sn=3 * d, st=0, batch=B, src_bstride=bs)              # B[c][key] = V[key][c]
+            ops.igemm(da, vp, Tn, 64, Tn, dP, lda=d, batch=B, stride_x=Tn * d, stride_w=pf_T, stride_out=Tn * Tn)
+            T.softmax_mask_bwd_(S, dP, B, Tn, L, spec, 1.0)                                           # dS (in dP)
+            pf_k = ops.packed_floats(Tn, 64)
+            kq = ops.pack(k, Tn, 64, 1, sk=3 * d, sn=1, st=0, batch=B, src_bstride=bs)              # B[key][c] = K[key][c]
+            ops.igemm(dP, kq, Tn, Tn, 64, dqkv[:, d + h * 64:], lda=Tn, ldc=3 * d, batch=B, stride_x=Tn * Tn,
+                      stride_w=pf_k, stride_out=bs)                                                   # dQ = dS K
+            dSt = T.transpose(dP, Tn, Tn, batch=B, bs_src=Tn * Tn)
+            qq = ops.pack(q, Tn, 64, 1, sk=3 * d, sn=1, st=0, batch=B, src_bstride=bs)
+            ops.igemm(dSt, qq, Tn, Tn, 64, dqkv[:, 2 * d + h * 64:], lda=Tn, ldc=3 * d, batch=B, stride_x=Tn * Tn,
+                      stride_w=pf_k, stride_out=bs)                                                   # dK = dS^T Q
+            Pt = T.transpose(S, Tn, Tn, batch=B, bs_src=Tn * Tn)
+            dap = ops.pack(da, Tn, 64, 1, sk=d, sn=1, st=0, batch=B, src_bstride=Tn * d)
+            ops.igemm(Pt, dap, Tn, Tn, 64, dqkv[:, h * 64:], lda=Tn, ldc=3 * d, batch=B, stride_x=Tn * Tn,
+                      stride_w=pf_k, stride_out=bs)                                                   # dV = P^T dA
+        return dqkv
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, poses, tokens, reduce_gradients: bool = True, apply_update: bool = True):
+        """poses [b,S,7] float32 (already through process_batch: relative + normalised), tokens [b,S,t,t] int.
+        Returns the metrics dict of MIGT.train_step (loss, ce_loss, acc, pose_* ...)."""
+        m, c, dev = self.model, self.cfg, self.dev
+        poses = poses.to(dev)
+        tokens = tokens.to(dev)
+        if poses.dtype != torch.float32:
+            raise TypeError('poses must be float32 (migt.py:346)')
+        B, S = tokens.shape[:2]
+        L = int(np.prod(tokens.shape[2:]))
+        d, H, nE = c.d_model, c.n_head, c.n_embeddings
+        use_loc = m.use_localization
+        NS = 3 if use_loc else 2
+        V = NS * S
+        Tn, M, M1 = V * L, B * V * L, B * S * L
+        skip = c.n_loss_skip
+        if not 0 <= skip < S:
+            raise ValueError('n_loss_skip must be < sequence length')
+        self.flat_g.zero_()
+
+        # ---- forward with saved activations --------------------------------------------------------------
+        pin = geometry.pose_model_input(poses, c.pose_multiplier).reshape(B * S, 7).contiguous()
+        fc = m._dense['pose_embedding.c_fc']
+        u1 = ops.dense_small_k(pin, fc.w_raw, fc.bias, B * S, 7, fc.n, gelu=False)
+        h1 = T.gelu(u1)
+        pe = self._linear(h1, 'pose_embedding.c_proj', B * S).view(B, S, d)
+        tok = tokens.reshape(B, S, L)
+        ids_streams = [tok, torch.full_like(tok, m.mask_token)]
+        add_streams = [pe, pe]
+        if use_loc:
+            ids_streams.append(tok)
+            add_streams.append(m._wte[m.localization_token].view(1, 1, d).expand(B, S, d))
+        ids32 = torch.cat(ids_streams, 1).reshape(M).to(torch.int32).contiguous()
+        add = torch.cat(add_streams, 1).contiguous().view(B * V, d)
+        h = ops.embed_sum(ids32, m._wte, m._wpe, add, B * V, L, d, nE + 2)
+        saved = []
+        for i in range(c.n_layer):
+            p = f'h.{i}'
+            n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d)
+            qkv = self._linear(n1, p + '.attn.c_attn', M)
+            att = torch.empty((M, d), dtype=torch.float32, device=dev)
+            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0,
+                                 True, -S)
+            h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
+            n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d)
+            u = self._linear(n2, p + '.mlp.c_fc', M)
+            f = T.gelu(u)
+            h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
+            saved.append((h, n1, qkv, att, h_mid, n2, u, f))
+            h = h_out
+        hf = ops.layernorm(h, *m._ln['ln_f'], M, d).view(B, NS, S, L, d)
+
+        # ---- losses (migt.py:416-448) ---------------------------------------------------------------------
+        view_ok = (torch.arange(S, device=dev) >= skip).float().view(1, S, 1).expand(B, S, L).reshape(M1)
+        denom = float((S - skip) * L * B)
+        hmask = hf[:, 1].contiguous().view(M1, d)
+        logits = torch.empty((M1, nE), dtype=torch.float32, device=dev)
+        ops.igemm(hmask, m._lm_head, M1, d, nE, logits)
+        tgt = tok.reshape(M1).to(torch.int32).contiguous()
+        w_ce = (view_ok * (c.image_generation_weight / denom)).contiguous()
+        ce_rows, dlogits = T.softmax_ce(logits, tgt, w_ce, M1, nE)
+        ce_b = ce_rows.view(B, S, L)[:, skip:].mean((1, 2))
+        loss_b = ce_b * c.image_generation_weight
+        metrics = dict(ce_loss=ce_b.mean())
+        pred = ops.argmax_rows(logits, M1, nE).view(B, S, L)
+        metrics['acc'] = (pred[:, skip:] == tok[:, skip:]).float().mean()
+        if use_loc:
+            loc_w = float(self.loc_weight(self.step_count))
+            hloc = hf[:, 2].contiguous().view(M1, d)
+            up = self._linear(hloc, 'pose_criterion.pose_classifier.c_fc', M1)
+            p1 = T.gelu(up)
+            raw = self._linear(p1, 'pose_criterion.pose_classifier.c_proj', M1)
+            w_pose = (view_ok * (loc_w / denom)).contiguous()
+            pos_r, ori_r, draw = T.pose_mse(raw, poses.reshape(B * S, 7).contiguous(), w_pose, M1, L, c.pose_multiplier)
+            pos_b = pos_r.view(B, S, L)[:, skip:].mean((1, 2))
+            ori_b = ori_r.view(B, S, L)[:, skip:].mean((1, 2))
+            loss_b = loss_b + (pos_b + ori_b) * loc_w
+            metrics.update(pose_pos_loss=pos_b.mean(), pose_ori_loss=ori_b.mean(), pose_loss=(pos_b + ori_b).mean(),
+                           localization_weight=loc_w)
+        metrics['loss'] = loss_b.mean()                                              # reduce_mean, migt.py:476
+
+        # ---- backward -------------------------------------------------------------------------------------
+        dhf = torch.zeros((B, NS, S, L, d), dtype=torch.float32, device=dev)
+        # tied LM head: dH = dlogits @ wte[:nE];  dwte[:nE] = dlogits^T @ H
+        dhm = torch.empty((M1, d), dtype=torch.float32, device=dev)
+        ops.igemm(dlogits, self.lm_T, M1, nE, d, dhm)
+        dhf[:, 1] = dhm.view(B, S, L, d)
+        dlt = T.transpose(dlogits, M1, nE)
+        hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
+        gwte = self.g('wte.weight')
+        ops.igemm(dlt, hp, nE, M1, d, gwte)                                           # rows [0, nE) of the (zeroed) grad
+        if use_loc:
+            name = 'pose_criterion.pose_classifier.c_proj'
+            dn = m._dense[name]
+            T.colsum(draw, self.g(name + '.bias'), M1, 7, accumulate=True)
+            p1t = T.transpose(p1, M1, dn.k)
+            drp = ops.pack(draw, M1, 7, 1, sk=7, sn=1, st=0)
+            ops.igemm(p1t, drp, dn.k, M1, 7, self.g(name + '.weight'))
+            w2t = T.transpose(dn.w_raw, dn.k, 7).view(7, dn.k)
+            dp1 = ops.dense_small_k(draw, w2t, None, M1, 7, dn.k, gelu=False)
+            dup = T.gelu_bwd(up, dp1)
+            dhl = self._linear_bwd('pose_criterion.pose_classifier.c_fc', hloc, dup, M1)
+            dhf[:, 2] = dhl.view(B, S, L, d)
+        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M)
+        handles = []
+        overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
+        for i in reversed(range(c.n_layer)):
+            p = f'h.{i}'
+            h_in, n1, qkv, att, h_mid, n2, u, f = saved[i]
+            df = self._linear_bwd(p + '.mlp.c_proj', f, dh, M)
+            du = T.gelu_bwd(u, df)
+            dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
+            dh_mid = T.add_(self._ln_bwd(p + '.ln_2', dn2, h_mid, M), dh)
+            datt = self._linear_bwd(p + '.attn.c_proj', att, dh_mid, M)
+            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S)
+            dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
+            dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
+            saved[i] = None
+            if overlap:                                                              # this layer's grads are final
+                a, b = self.layer_ranges[i]
+                handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
+        dadd = T.embed_bwd(dh, ids32, gwte, self.g('wpe.embeddings'), B * V, L, d, nE + 2).view(B, V, d)
+        dpe = (dadd[:, :S] + dadd[:, S:2 * S]).contiguous().view(B * S, d)
+        if use_loc:
+            T.colsum(dadd[:, 2 * S:].contiguous().view(B * S, d), gwte[m.localization_token], B * S, d, accumulate=True)
+        dh1 = self._linear_bwd('pose_embedding.c_proj', h1, dpe, B * S)
+        du1 = T.gelu_bwd(u1, dh1)
+        T.dense_small_k_bwd(pin, du1, self.g('pose_embedding.c_fc.weight'), self.g('pose_embedding.c_fc.bias'), B * S, 7, fc.n)
+
+        # ---- clip (per replica, per tensor, before aggregation), all-reduce SUM, AdamWeightDecay ------------
+        if c.gradient_clip_val and c.gradient_clip_val > 0:
+            for n in self.names:
+                T.clip_by_norm_(self.g(n).reshape(-1), float(c.gradient_clip_val), self._scratch)
+        if reduce_gradients and self._world() > 1:
+            if overlap:
+                a, b = self.head_range
+                handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                handles += sharding.allreduce_sum_ranges(self.flat_g, [self.head_range] + self.layer_ranges, self.group)
+            for hd in handles:
+                hd.wait()
+        if apply_update:
+            self.apply_gradients()
+        return metrics
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def apply_gradients(self):
+        c = self.cfg
+        step = self.step_count
+        lr = learning_rate(step, c.learning_rate, c.total_steps, self.warmup_steps)
+        t = step + 1
+        lr_adam = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        for n in self.names:
+            a, b, _ = self.slices[n]
+            decay = c.weight_decay > 0 and 'bias' not in n            # models/utils.py:424: only "bias" names are excluded
+            T.adamw_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
+                     lr * c.weight_decay if decay else 0.0, lr_adam, self.b1, self.b2, self.eps)
+        self.step_count += 1
+        self.repack()
+
+    def state_dict(self):
+        return {n: self.p(n).detach().cpu().clone() for n in self.names}

@@ -1,0 +1,117 @@
+"""Tensor-level wrappers of the training-step entry points (include/vf_hip.h, csrc/train_ops.hip).
+Same rules as ops.py: raw device pointers, torch = memory + stream only, no fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _p, _f32, _chk, _stream
+
+
+def transpose(src, rows, cols, ld_src=None, batch=1, bs_src=0, out=None, ld_dst=None):
+    """dst[b][c][r] = src[b][r][c]; ``ld_dst`` > rows leaves the tail of every output row untouched
+    (pass a zero-filled ``out`` to get zero padding)"""
+    ld_src = cols if ld_src is None else ld_src
+    ld_dst = rows if ld_dst is None else ld_dst
+    if out is None:
+        out = torch.empty((batch, cols, ld_dst), dtype=torch.float32, device=src.device)
+    check(_lib.load().vf_transpose_f32(_p(_f32(src)), _p(out), rows, cols, ld_src, ld_dst, batch, bs_src, cols * ld_dst, _stream()),
+          'vf_transpose_f32')
+    return out
+
+
+_ws_cache = {}
+
+
+def _ws(nbytes, dev, key):
+    t = _ws_cache.get((key, dev))
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _ws_cache[(key, dev)] = t
+    return t
+
+
+def colsum(x, out, M, N, ld=None, accumulate=False):
+    lib = _lib.load()
+    ws = _ws(int(lib.vf_colsum_workspace_bytes(N)), x.device, 'colsum')
+    check(lib.vf_colsum_f32(_p(_f32(x)), _p(_f32(out)), M, N, N if ld is None else ld, 1 if accumulate else 0, _p(ws), _stream()),
+          'vf_colsum_f32')
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True):
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    ws = _ws(int(lib.vf_layernorm_bwd_workspace_bytes(rows, d)), x.device, 'lnbwd')
+    check(lib.vf_layernorm_bwd_f32(_p(_f32(dy)), _p(_f32(x)), _p(_f32(gamma)), _p(dx), _p(dgamma), _p(dbeta), rows, d, eps,
+                                   1 if accumulate else 0, _p(ws), _stream()), 'vf_layernorm_bwd_f32')
+    return dx
+
+
+def gelu(u):
+    f = torch.empty_like(u)
+    check(_lib.load().vf_gelu_f32(_p(_f32(u)), _p(f), u.numel(), _stream()), 'vf_gelu_f32')
+    return f
+
+
+def gelu_bwd(u, df):
+    du = torch.empty_like(u)
+    check(_lib.load().vf_gelu_bwd_f32(_p(_f32(u)), _p(_f32(df)), _p(du), u.numel(), _stream()), 'vf_gelu_bwd_f32')
+    return du
+
+
+def softmax_mask_(s, batch, T, L, mask_spec, scale=1.0):
+    check(_lib.load().vf_softmax_mask_f32(_p(_f32(s)), batch, T, L, mask_spec, scale, _stream()), 'vf_softmax_mask_f32')
+    return s
+
+
+def softmax_mask_bwd_(p, dp, batch, T, L, mask_spec, scale=1.0):
+    check(_lib.load().vf_softmax_mask_bwd_f32(_p(_f32(p)), _p(_f32(dp)), batch, T, L, mask_spec, scale, _stream()),
+          'vf_softmax_mask_bwd_f32')
+    return dp
+
+
+def softmax_ce(logits, target_i32, row_weight, rows, V):
+    loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    dl = torch.empty((rows, V), dtype=torch.float32, device=logits.device)
+    check(_lib.load().vf_softmax_ce_f32(_p(_f32(logits)), _p(_chk(target_i32, torch.int32)), _p(_f32(row_weight)), _p(loss), _p(dl),
+                                        rows, V, _stream()), 'vf_softmax_ce_f32')
+    return loss, dl
+
+
+def pose_mse(raw, gt, row_weight, rows, L, position_multiplier):
+    dev = raw.device
+    pos = torch.empty(rows, dtype=torch.float32, device=dev)
+    ori = torch.empty(rows, dtype=torch.float32, device=dev)
+    draw = torch.empty((rows, 7), dtype=torch.float32, device=dev)
+    check(_lib.load().vf_pose_mse_f32(_p(_f32(raw)), _p(_f32(gt)), _p(_f32(row_weight)), _p(pos), _p(ori), _p(draw), rows, L,
+                                      position_multiplier, _stream()), 'vf_pose_mse_f32')
+    return pos, ori, draw
+
+
+def embed_bwd(dh, ids_i32, dwte, dwpe, BS, L, d, vocab):
+    dadd = torch.empty((BS, d), dtype=torch.float32, device=dh.device)
+    check(_lib.load().vf_embed_bwd_f32(_p(_f32(dh)), _p(_chk(ids_i32, torch.int32)), _p(_f32(dwte)), _p(_f32(dwpe)), _p(dadd), BS, L,
+                                       d, vocab, _stream()), 'vf_embed_bwd_f32')
+    return dadd
+
+
+def dense_small_k_bwd(x, dy, dW, db, rows, K, N):
+    check(_lib.load().vf_dense_small_k_bwd_f32(_p(_f32(x)), _p(_f32(dy)), _p(_f32(dW)), _p(_f32(db)), rows, K, N, _stream()),
+          'vf_dense_small_k_bwd_f32')
+
+
+def adamw_(param, grad, m, v, lr_decay, lr_adam, beta1, beta2, eps):
+    check(_lib.load().vf_adamw_f32(_p(_f32(param)), _p(_f32(grad)), _p(_f32(m)), _p(_f32(v)), param.numel(), lr_decay, lr_adam,
+                                   beta1, beta2, eps, _stream()), 'vf_adamw_f32')
+
+
+def add_(a, b):
+    check(_lib.load().vf_add_inplace_f32(_p(_f32(a)), _p(_f32(b)), a.numel(), _stream()), 'vf_add_inplace_f32')
+    return a
+
+
+def clip_by_norm_(x, clip, scratch1):
+    check(_lib.load().vf_clip_by_norm_f32(_p(_f32(x)), x.numel(), clip, _p(scratch1), _stream()), 'vf_clip_by_norm_f32')
+    return x
