@@ -30,7 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 p
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(dev, localization: bool):
+def build_models(dev, localization: bool, precision: str = 'f32'):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -42,8 +42,11 @@ def build_models(dev, localization: bool):
                       localization_weight='cosine(0,1,120000)' if localization else '0')
     vsd = make_vqgan_weights(vcfg, seed=0, codebook_scale=0.05)
     msd = make_migt_weights(mcfg, seed=0)
-    vq = VQGAN(vcfg, data_format='NHWC').load_state_dict(vsd).to(dev)
-    tr = MIGT(mcfg).load_state_dict(msd).to(dev)
+    # precision 'mixed': encoder + codebook lookup exact fp32 (bit-exact tokens), transformer dense layers and decoder
+    # convolutions on bf16 MFMA (tolerance-bounded logits / pixels) — the split the north star specifies
+    arm = 'bf16' if precision == 'mixed' else 'f32'
+    vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm).load_state_dict(vsd).to(dev)
+    tr = MIGT(mcfg, precision=arm).load_state_dict(msd).to(dev)
     return vq, tr, (vcfg, vsd, mcfg, msd)
 
 
@@ -132,6 +135,10 @@ def main():
     ap.add_argument('--views', type=int, default=7, help='views per scene (6 context + 1 novel)')
     ap.add_argument('--no-localization', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['f32', 'mixed'], default='f32',
+                    help="f32: everything exact fp32 (default, full parity); mixed: fp32 encoder/lookup + bf16-MFMA "
+                         "transformer dense layers and decoder convolutions (logits/pixels within the tolerances of "
+                         "tests/test_hip_bf16.py)")
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -148,7 +155,7 @@ def main():
     localization = not args.no_localization
     S, B = args.views, args.batch
 
-    vq, tr, models_cfg = build_models(dev, localization)
+    vq, tr, models_cfg = build_models(dev, localization, args.precision)
     frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
     frames_d = torch.from_numpy(frames).to(dev)
     cams_d = torch.from_numpy(cams).to(dev)
@@ -180,11 +187,14 @@ def main():
             'metric': 'novel views/sec (encode->AR transformer->decode), 128px 6-ctx',
             'value': round(value, 3), 'unit': 'novel views/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32' if args.precision == 'f32' else 'bf16'), 'data': 'synthetic',
             'config': {'workload': 'SM7 codebook+transformer, 6 context views -> 1 novel view, 128x128 '
                                    '(BASELINE.json configs[1])',
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'localization_pass': localization,
                        'target_view_encoded': True, 'parallelism': f'scene-shard x{world}, no collective',
+                       'precision': ('exact fp32 everywhere' if args.precision == 'f32' else
+                                     'mixed: fp32 encoder + codebook lookup (bit-exact tokens), bf16-MFMA transformer dense '
+                                     'layers + decoder convs (fp32 accumulate; tolerances in tests/test_hip_bf16.py)'),
                        'weights': 'random-init (deterministic generator), full-size VQGAN 67.9M + MIGT 88.4M',
                        'algorithmic_gflop_per_view': round(gf, 1),
                        'whole_path_tflops': round(value * gf / 1e3, 2)},

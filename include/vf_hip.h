@@ -164,6 +164,22 @@ int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx
 int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Reduced-precision arm (bf16 MFMA, fp32 activations in HBM, fp32 accumulate / epilogue) for the layers whose
+ * outputs the north star bounds by a tolerance rather than bit-exactness: the transformer's dense layers and
+ * the decoder's convolutions.  Same vf_igemm_args as the exact path; w_packed points to the bf16 packing.
+ * vf_gemm_bf16: VF_MODE_GEMM, Cin % 64 == 0, no prologue.
+ * vf_conv3_halo_bf16: VF_MODE_CONV3_S1 / _UP2 with the halo-kernel shape rules (Cin % 32, Cout % 128,
+ * Wout % 16, Hout % 8), GroupNorm(+swish) prologue, bias, residual.
+ * ------------------------------------------------------------------------------------- */
+size_t vf_gemm_bf16_packed_elems(int K, int N);            /* number of bf16 elements of the packed weight */
+int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int batch,
+                      int64_t src_bstride, void* stream);
+int vf_gemm_bf16(const vf_igemm_args* args /* host */, void* stream);
+size_t vf_conv3_bf16_packed_elems(int Cin, int Cout);
+int vf_conv3_bf16_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
+int vf_conv3_halo_bf16(const vf_igemm_args* args /* host */, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.

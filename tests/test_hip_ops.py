@@ -284,3 +284,21 @@ def test_embed_sum_small_dense_argmax_softmax_postprocess(dev):
     dec.view(-1)[:6] = torch.tensor([-3.0, -1.0, 0.0, 0.999, 1.0, 7.0])
     u8 = ops.postprocess_u8(dec.to(dev)).cpu()
     assert torch.equal(u8, vq.postprocess_u8(dec.permute(0, 3, 1, 2)))
+
+
+@pytest.mark.parametrize('M,K,N', [(300, 256, 512), (2048, 512, 512), (64, 64, 256)])
+def test_gemm_small_tile_variant(dev, M, K, N):
+    """few rows -> under-filled grid -> the 64x64-tile variant reading half blocks of the 128-wide packing"""
+    from viewformer_amd import ops
+    x, w, b, r = _rand((M, K), 31), _rand((K, N), 32, 0.1), _rand((N,), 33), _rand((M, N), 34)
+    out = torch.empty((M, N), device=dev)
+    ops.igemm(x.to(dev), ops.pack_dense_kn(w.to(dev)), M, K, N, out, bias=b.to(dev), res=r.to(dev))
+    _close(out, x.double() @ w.double() + b.double() + r.double(), 2e-5, 2e-5, f'small-tile gemm {M}x{K}x{N}')
+    # 8x8 maps, 512 channels: the decoder's under-filled 3x3 convs
+    n, C, H = 3, 256, 8
+    xi, wc, bc = _rand((n, C, H, H), 35), _rand((C, C, 3, 3), 36, 0.03), _rand((C,), 37)
+    ref = F.conv2d(xi.double(), wc.double(), bc.double(), padding=1)
+    o2 = torch.empty((n * H * H, C), device=dev)
+    ops.igemm(xi.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_conv_oihw(wc.to(dev)), n * H * H, C, C, o2, bias=bc.to(dev),
+              mode=ops.MODE_CONV3_S1, Hin=H, Win=H, Hout=H, Wout=H)
+    _close(o2.view(n, H, H, C).permute(0, 3, 1, 2), ref, 2e-5, 2e-5, 'small-tile conv 8x8')

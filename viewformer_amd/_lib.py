@@ -50,6 +50,13 @@ EXPORTS = {
     'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),
     'vf_postprocess_u8': (c_int, [P, P, c_int64, P]),
+    # ---- bf16 arm (transformer dense layers, decoder convolutions)
+    'vf_gemm_bf16_packed_elems': (c_size_t, [c_int, c_int]),
+    'vf_gemm_bf16_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, P]),
+    'vf_gemm_bf16': (c_int, [POINTER(VfIgemmArgs), P]),
+    'vf_conv3_bf16_packed_elems': (c_size_t, [c_int, c_int]),
+    'vf_conv3_bf16_pack': (c_int, [P, P, c_int, c_int, P]),
+    'vf_conv3_halo_bf16': (c_int, [POINTER(VfIgemmArgs), P]),
     # ---- training step
     'vf_transpose_f32': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, c_int64, P]),
     'vf_colsum_workspace_bytes': (c_size_t, [c_int]),

@@ -1,0 +1,279 @@
+// bf16-MFMA sibling of conv3_halo_f32.hip (same halo-tile structure, same pixel permutation, same epilogue):
+// 3x3 stride-1 / nearest-x2-upsample convolutions of the DECODER on v_mfma_f32_32x32x16_bf16, with fp32
+// activations in HBM, the GroupNorm-apply(+swish) prologue evaluated in fp32 and rounded to bf16 (RNE) when the
+// patch is parked in LDS, bf16 fragment-packed weights streamed L2 -> VGPR, fp32 accumulation and the fp32
+// bias/residual epilogue.  Decoded pixels are bounded by a tolerance in the north star (not bit-exact), so this
+// arm trades 2^-9 operand rounding for the 16x faster matrix pipe; the encoder never uses it.
+// Patch pixel stride 80 B (64 B of bf16 + 16 B pad): 16 consecutive patch pixels -> 16 distinct 16-byte LDS
+// slots for every ds_read_b128 lane group, for every tap shift.
+#include "vf_common.h"
+#include "epilogue.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 32;
+constexpr int P_LDB = 80;           // bytes per patch pixel in LDS
+constexpr int TH = 8, TW = 16;
+constexpr int BN = 128;
+constexpr int TAP_BYTES = CK * BN * 2;   // one (chunk, tap, n-block) weight tile: 8 KB
+
+__host__ __device__ constexpr int perm_row(int i) { return (i < 4) ? 0 : (i < 12) ? 1 : (i < 16) ? 0 : (i < 20) ? 1 : (i < 28) ? 0 : 1; }
+__host__ __device__ constexpr int perm_px(int i) {
+    return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
+}
+
+template <bool UP2>
+struct Geo {
+    static constexpr int PH = UP2 ? (TH / 2 + 2) : (TH + 2);
+    static constexpr int PW = UP2 ? (TW / 2 + 2) : (TW + 2);
+    static constexpr int NPIX = PH * PW;
+    static constexpr int SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
+};
+
+__device__ __forceinline__ float fast_swish(float t) {
+    // bf16 arm only: hardware exp2 + rcp (the result is rounded to 8 mantissa bits right after)
+    return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
+
+template <bool UP2, bool PRO, bool SWISH>
+__global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p) {
+    using G = Geo<UP2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][BUF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    int bid = blockIdx.x;
+    const int nblk = bid % nb; bid /= nb;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int img = bid / tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int sy0 = UP2 ? (y0 / 2 - 1) : (y0 - 1);
+    const int sx0 = UP2 ? (x0 / 2 - 1) : (x0 - 1);
+
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / CK;
+    const int last_stage = nchunks * 9 - 1;
+
+    const int c4 = tid & 7;
+    int s_off[G::SLOTS];
+    bool s_ok[G::SLOTS];
+    int s_lds[G::SLOTS];
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int pixc = pix < G::NPIX ? pix : G::NPIX;
+        const int pr = pixc / G::PW, pc = pixc - pr * G::PW;
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
+        s_ok[q] = ok;
+        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_lds[q] = pixc * P_LDB + c4 * 8;
+    }
+
+    f32x4 preg[G::SLOTS];
+    f32x4 pmean, pscale, pbeta;
+    auto patch_load = [&](int chunk) {
+        const float* xc = X + chunk * CK;
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+        if (PRO) {
+            pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
+        }
+    };
+    auto patch_store_slot = [&](int buf, int q) {
+        unsigned char* dst = smem_h + buf * G::BUF;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = preg[q][e];
+            if (PRO) {
+                t = (t - pmean[e]) * pscale[e] + pbeta[e];
+                if (SWISH) t = fast_swish(t);
+            }
+            o[e] = (__bf16)(s_ok[q] ? t : 0.f);
+        }
+        *reinterpret_cast<bf16x4*>(dst + s_lds[q]) = o;
+    };
+
+    const int trow = perm_row(l31), tpx = perm_px(l31);
+    int a_base[2], a_r[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int a0 = wave_m * 4 + mi * 2 + trow;
+        a_r[mi] = a0;
+        a_base[mi] = (a0 * G::PW + tpx) * P_LDB + half * 16;
+    }
+
+    // packed weights [chunk][tap][nblk][ks(2)][half(2)][n(128)][8 bf16]
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    bf16x8 bc[4], bn[4];
+    auto b_load = [&](bf16x8 (&dst)[4], int stage) {
+        const unsigned char* src = Wb + (size_t)stage * tap_stride;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                dst[ks * 2 + j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16 + b_lane);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    patch_load(0);
+    b_load(bc, 0);
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
+        patch_load(min(chunk + 1, nchunks - 1));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            b_load(bn, min(chunk * 9 + tap + 1, last_stage));
+            int aoff[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (UP2) {
+                    const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
+                    aoff[mi] = (pr * G::PW + pc) * P_LDB + half * 16;
+                } else {
+                    aoff[mi] = a_base[mi] + (dy * G::PW + dx) * P_LDB;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(patch + aoff[mi] + ks * 32);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bc[ks * 2 + j], acc[mi][j], 0, 0, 0);
+            }
+            if (tap >= 1 && tap <= G::SLOTS) patch_store_slot((chunk + 1) & 1, tap - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+        }
+        __syncthreads();
+    }
+
+    float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
+    const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int py = y0 + wave_m * 4 + mi * 2;
+            auto pix = [&](int r) {
+                const int i0 = (r & 3) + 8 * (r >> 2);
+                const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
+                const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
+                return (py + prow) * p.Wout + x0 + ppx;
+            };
+            auto oo = [&](int r) { return pix(r) * p.ldc; };
+            auto ro = [&](int r) { return pix(r) * p.ldr; };
+            if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
+            else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
+        }
+    }
+}
+
+__global__ void pack_conv_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks) {
+    // dst [chunk][tap][nblk][ks(2)][half(2)][n(128)][8]; src OIHW [Cout][Cin][3][3]
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        long long t = idx >> 3;
+        const int nl = (int)(t % BN); t /= BN;
+        const int half = (int)(t & 1);
+        const int ks = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int nblk = (int)(t % nb); t /= nb;
+        const int tap = (int)(t % 9);
+        const int chunk = (int)(t / 9);
+        const int c = chunk * CK + ks * 16 + half * 8 + e;
+        const int n = nblk * BN + nl;
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * 9 + tap];
+        dst[idx] = (__bf16)v;
+    }
+}
+
+template <bool UP2, bool PRO, bool SWISH>
+int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
+    using G = Geo<UP2>;
+    const size_t smem = (size_t)2 * G::BUF;
+    const int n_img = a.M / (a.Hout * a.Wout);
+    const long long blocks = (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv3_halo_bf16_kernel<UP2, PRO, SWISH>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
+    return vf_last_status();
+}
+
+template <bool UP2>
+int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
+    if (!a.pro_mean) return launch_halo<UP2, false, false>(a, s);
+    return a.pro_swish ? launch_halo<UP2, true, true>(a, s) : launch_halo<UP2, true, false>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vf_conv3_bf16_packed_elems(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)((Cin + CK - 1) / CK) * 9 * ((Cout + BN - 1) / BN) * CK * BN;
+}
+
+int vf_conv3_bf16_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream) {
+    if (!w_oihw || !dst || Cin <= 0 || Cout <= 0) return VF_ERR_BAD_ARG;
+    const int nb = (Cout + BN - 1) / BN, nchunks = (Cin + CK - 1) / CK;
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (__bf16*)dst, Cin, Cout, nb,
+                       nchunks);
+    return vf_last_status();
+}
+
+int vf_conv3_halo_bf16(const vf_igemm_args* args, void* stream) {
+    if (!args) return VF_ERR_BAD_ARG;
+    const vf_igemm_args& a = *args;
+    if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
+    if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
+    if (a.Cout % BN != 0 || a.Cin % CK != 0 || a.Hout % TH != 0 || a.Wout % TW != 0) return VF_ERR_UNSUPPORTED;
+    if (a.Hin <= 0 || a.Win <= 0 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_S1 && (a.Hout != a.Hin || a.Wout != a.Win)) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_UP2 && (a.Hout != a.Hin * 2 || a.Wout != a.Win * 2)) return VF_ERR_BAD_ARG;
+    if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+    if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
+    if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true>(a, s) : dispatch_pro<false>(a, s);
+}
+
+}  // extern "C"

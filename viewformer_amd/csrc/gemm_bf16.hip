@@ -1,0 +1,215 @@
+// Dense / 1x1 GEMM on bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 activations in HBM, fp32 accumulate and
+// the fp32 bias / exact-erf GELU / residual epilogue — the reduced-precision arm for the transformer and the
+// decoder (north star: "transformer logits and decoded pixels within a stated fp tolerance"; the encoder and
+// the codebook lookup stay exact fp32 so that token indices remain bit-exact).
+//
+//   out[m][n] = epi( sum_k bf16(A[m][k]) * bf16(W[k][n]) + bias[n] ) + res[m][n]       (products exact, fp32 sums)
+//
+// 128x128 tile per 256-thread workgroup (2x2 waves of 64x64), K in stages of 64: A is loaded as fp32 float4,
+// rounded to bf16 (v_cvt_pk_bf16_f32, RNE) in registers and parked in LDS with a 144-byte row stride (every
+// hardware ds_read_b128 lane group hits 16 distinct 16-byte slots); W is pre-packed fragment-major
+// ([k-chunk][n-block][k-step(4)][half(2)][n(128)][8 bf16]) so the B stage is a linear 16 KB copy and a lane's B
+// fragment is one ds_read_b128.  Double-buffered LDS (70 KB -> 2 workgroups/CU), one barrier per stage,
+// 16 MFMAs (512 matrix-pipe cycles) per wave per stage.
+#include "vf_common.h"
+#include "epilogue.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 64;
+constexpr int BM = 128, BN = 128;
+constexpr int A_LDB = 144;                  // bytes per A row in LDS (128 data + 16 pad)
+constexpr int A_BYTES = BM * A_LDB;         // 18432
+constexpr int B_BYTES = CK * BN * 2;        // 16384
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                    // [2][A_BYTES]
+    unsigned char* Bs = smem_b + 2 * A_BYTES;      // [2][B_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = (p.Cout + BN - 1) / BN;
+    const int nblk = blockIdx.x % nb;
+    const int mtile = blockIdx.x / nb;
+    const int bz = blockIdx.z;
+    const float* __restrict__ X = p.x + (size_t)bz * p.stride_x;
+    const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)bz * p.stride_w * 2
+                                           + (size_t)nblk * B_BYTES;
+    const size_t stage_stride = (size_t)nb * B_BYTES;
+    const int nstages = p.Cin / CK;
+
+    // A staging: thread -> float4 column (tid & 15), rows (tid >> 4) + 16 q
+    const int a_c4 = tid & 15, a_r0 = tid >> 4;
+    const float* arow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int m = mtile * BM + a_r0 + 16 * q;
+        m = m < p.M ? m : p.M - 1;                 // clamped: rows past M are never stored
+        arow[q] = X + (size_t)m * p.lda + a_c4 * 4;
+    }
+    f32x4 areg[8];
+    f32x4 breg[4];
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const f32x4*>(arow[q] + s * CK);
+        const unsigned char* src = Wp + (size_t)s * stage_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[q] = *reinterpret_cast<const f32x4*>(src + (size_t)(tid + 256 * q) * 16);
+    };
+    auto store_stage = [&](int buf) {
+        unsigned char* a_dst = As + buf * A_BYTES;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[q][e];
+            *reinterpret_cast<bf16x4*>(a_dst + (a_r0 + 16 * q) * A_LDB + a_c4 * 8) = v;
+        }
+        unsigned char* b_dst = Bs + buf * B_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(b_dst + (size_t)(tid + 256 * q) * 16) = breg[q];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        load_stage(min(s + 1, nstages - 1));
+        const unsigned char* a_src = As + (s & 1) * A_BYTES + (wave_m * 64 + l31) * A_LDB + half * 16;
+        const unsigned char* b_src = Bs + (s & 1) * B_BYTES + (half * BN + wave_n * 64 + l31) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_src + i * 32 * A_LDB + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(b_src + (ks * 2 * BN + j * 32) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        store_stage((s + 1) & 1);                 // (the last iteration re-stores the last stage into the idle buffer)
+        __syncthreads();
+    }
+
+    float* __restrict__ Out = p.out + (size_t)bz * p.stride_out;
+    const float* __restrict__ Res = p.res ? p.res + (size_t)bz * p.stride_res : nullptr;
+    const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);
+    const long long ldc = p.ldc, ldr = p.ldr;
+    const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
+            const int nn = nok ? n : 0;
+            float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
+            const float* rs = Res ? Res + (size_t)(m0 < p.M ? m0 : 0) * ldr + nn : nullptr;
+            const int rows_left = nok ? p.M - m0 : 0;
+            if (full) {
+                auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
+                auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
+                if (gelu) {
+                    if (Res) vf_store_tile<1, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<1, false>(acc[i][j], bias, o, rs, oo, ro);
+                } else {
+                    if (Res) vf_store_tile<0, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<0, false>(acc[i][j], bias, o, rs, oo, ro);
+                }
+            } else if (gelu) {
+                if (Res) vf_store_tile_ragged<1, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<1, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+            } else {
+                if (Res) vf_store_tile_ragged<0, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<0, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+            }
+        }
+    }
+}
+
+// pack fp32 [K][N] (strided) -> bf16 fragment-major [K/64][nb][ks(4)][half(2)][n(128)][8]
+__global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N, long long sk,
+                                 long long sn, int nb, int nchunks, long long src_bstride, long long dst_bstride) {
+    const long long total = (long long)nchunks * nb * CK * BN;
+    const int bz = blockIdx.y;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        long long t = idx >> 3;
+        const int nl = (int)(t % BN); t /= BN;
+        const int half = (int)(t & 1);
+        const int ks = (int)((t >> 1) & 3);
+        t >>= 3;
+        const int nblk = (int)(t % nb);
+        const int chunk = (int)(t / nb);
+        const int k = chunk * CK + ks * 16 + half * 8 + e;
+        const int n = nblk * BN + nl;
+        float v = 0.f;
+        if (k < K && n < N) v = src[(size_t)bz * src_bstride + k * sk + n * sn];
+        dst[(size_t)bz * dst_bstride + idx] = (__bf16)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vf_gemm_bf16_packed_elems(int K, int N) {
+    if (K <= 0 || N <= 0) return 0;
+    return (size_t)((K + CK - 1) / CK) * ((N + BN - 1) / BN) * CK * BN;
+}
+
+int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int batch, int64_t src_bstride,
+                      void* stream) {
+    if (!src || !dst || K <= 0 || N <= 0 || batch < 1) return VF_ERR_BAD_ARG;
+    const int nb = (N + BN - 1) / BN, nchunks = (K + CK - 1) / CK;
+    const long long total = (long long)nchunks * nb * CK * BN;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, K, N,
+                       (long long)sk, (long long)sn, nb, nchunks, (long long)src_bstride, total);
+    return vf_last_status();
+}
+
+int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
+    if (!args) return VF_ERR_BAD_ARG;
+    const vf_igemm_args& a = *args;
+    if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
+    if (a.mode != VF_MODE_GEMM || a.pro_mean) return VF_ERR_UNSUPPORTED;
+    if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
+    if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+    const size_t smem = (size_t)2 * (A_BYTES + B_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nb = (a.Cout + BN - 1) / BN, mt = (a.M + BM - 1) / BM;
+    dim3 grid((unsigned)(mt * nb), 1, (unsigned)(a.batch > 0 ? a.batch : 1));
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), smem, (hipStream_t)stream, a);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -27,7 +27,6 @@ namespace {
 
 constexpr int CK = 32;     // K per stage
 constexpr int A_LD = 36;   // LDS row stride of the A tile (floats)
-constexpr int BM = 128;
 
 __host__ __device__ inline int bn_for(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 
@@ -38,10 +37,13 @@ struct RowInfo {
     int valid;
 };
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+// PBN = column-block width of the weight PACKING (bn_for(Cout)); equals the tile width BN except for the 64x64
+// small-tile variant, which walks half of a 128-wide packed block.
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int PBN = WAVES_N * WN_T * 32>
 __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
     constexpr int BN = WAVES_N * WN_T * 32;
-    static_assert(WAVES_M * WM_T * 32 == BM, "tile");
+    constexpr int BM = WAVES_M * WM_T * 32;   // 128, or 64 for the small-tile variant (under-filled grids)
+    constexpr int AP = BM / 32;               // A staging passes (32 rows x 8 float4 per pass)
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     constexpr int B_F4 = CK * BN / 4 / 256;   // float4 per thread for the B stage
 
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
     // ---- per-thread staging rows -------------------------------------------------------
     const int a_col4 = tid & 7;
     const int a_row0 = tid >> 3;
-    RowInfo rows[4];
+    RowInfo rows[AP];
     const int HWo = p.Hout * p.Wout;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < AP; ++q) {
         const int m = mtile * BM + a_row0 + 32 * q;
         RowInfo r;
         r.valid = m < p.M;
@@ -98,15 +100,15 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
         rows[q] = r;
     }
 
-    f32x4 areg[4];
+    f32x4 areg[AP];
     f32x4 breg[B_F4];
-    f32x4 pmean[4], pscale[4], pbeta;
-    bool aok[4];
+    f32x4 pmean[AP], pscale[AP], pbeta;
+    bool aok[AP];
 
     auto load_stage = [&](int chunk, int tap) {
         const int c0 = chunk * CK + a_col4 * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AP; ++q) {
             const RowInfo r = rows[q];
             bool ok = r.valid;
             size_t off;
@@ -139,16 +141,20 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
             }
         }
         if (has_pro && tap == 0) pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + c0);
-        const float* wsrc = Wp + ((size_t)(chunk * taps + tap) * nb + nblk) * (CK * BN);
+        constexpr int SUB = PBN / BN;                       // tile blocks per packed block
+        const int nbp = (p.Cout + PBN - 1) / PBN;
+        const float* wsrc = Wp + ((size_t)(chunk * taps + tap) * nbp + nblk / SUB) * (CK * PBN) + (nblk % SUB) * BN * 4;
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q)
-            breg[q] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(tid + 256 * q) * 4);
+        for (int q = 0; q < B_F4; ++q) {
+            const int li = tid + 256 * q;                   // float4 index inside the [8][BN] tile
+            breg[q] = *reinterpret_cast<const f32x4*>(wsrc + ((size_t)(li / BN) * PBN + (li % BN)) * 4);
+        }
     };
 
     auto store_stage = [&](int buf) {
         float* a_dst = As + buf * (BM * A_LD);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AP; ++q) {
             f32x4 v = areg[q];
             if (has_pro) {
 #pragma unroll
@@ -270,11 +276,12 @@ __global__ void pack_b_kernel(const float* __restrict__ src, float* __restrict__
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int PBN = WAVES_N * WN_T * 32>
 int launch_igemm(const vf_igemm_args& a, hipStream_t stream) {
     constexpr int BN = WAVES_N * WN_T * 32;
+    constexpr int BM = WAVES_M * WM_T * 32;
     const size_t smem = (size_t)(2 * BM * A_LD + 2 * CK * BN) * sizeof(float);
-    auto kern = igemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T>;
+    auto kern = igemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, PBN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -354,7 +361,13 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
         if (direct_on && vf_gemm_direct_try(a, s, &st) == 0) return st;
     }
     const int BN = bn_for(a.Cout);
-    if (BN == 128) return launch_igemm<2, 2, 2, 2>(a, s);
+    if (BN == 128) {
+        // under-filled grid (few rows, e.g. the decoder's 8x8 maps: 2048 rows x 512 channels = 64 tiles of 128x128 on
+        // 256 CUs): the 64x64-tile variant quadruples the workgroup count
+        const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+        if (tiles128 < 384 && a.Cout % 64 == 0) return launch_igemm<2, 2, 1, 1, 128>(a, s);
+        return launch_igemm<2, 2, 2, 2>(a, s);
+    }
     if (BN == 64) return launch_igemm<4, 1, 1, 2>(a, s);
     return launch_igemm<4, 1, 1, 1>(a, s);
 }

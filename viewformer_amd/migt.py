@@ -24,11 +24,16 @@ from .config import MIGTConfig
 
 
 class _Dense:
-    __slots__ = ('wp', 'bias', 'k', 'n', 'w_raw')
+    __slots__ = ('wp', 'wp16', 'bias', 'k', 'n', 'w_raw')
 
 
 class MIGT:
-    def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True):
+    def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True, precision: str = 'f32'):
+        """``precision='bf16'``: the dense layers (c_attn, c_proj, MLP, LM head, pose MLPs) run on the bf16-MFMA arm with
+        fp32 activations / accumulation; LayerNorm, attention, softmax, residual stream and arg-max stay fp32.
+        Logits are then tolerance-bounded (tests state the bound), as the north star allows for the transformer."""
+        assert precision in ('f32', 'bf16')
+        self.precision = precision
         self.config = config or MIGTConfig()
         c = self.config
         self.n_image_tokens = c.token_image_size ** 2
@@ -98,6 +103,7 @@ class MIGT:
             d.bias = dev_t(name + '.bias')
             d.w_raw = w
             d.wp = ops.pack_dense_kn(w) if (pack and d.k % 32 == 0) else None
+            d.wp16 = ops.pack_dense_kn_bf16(w) if (self.precision == 'bf16' and pack and d.k % 64 == 0 and d.n >= 64) else None
             self._dense[name] = d
 
         def ln(name):
@@ -106,6 +112,8 @@ class MIGT:
         self._wte = dev_t('wte.weight')
         self._wpe = dev_t('wpe.embeddings')
         self._lm_head = ops.pack_dense_nk(self._wte, n_rows=c.n_embeddings)    # logits sliced to n_embeddings (migt.py:417)
+        self._lm_head16 = (ops.pack_dense_nk_bf16(self._wte, n_rows=c.n_embeddings)
+                           if self.precision == 'bf16' and c.d_model % 64 == 0 else None)
         dense('pose_embedding.c_fc', pack=False)
         dense('pose_embedding.c_proj')
         dense('pose_criterion.pose_classifier.c_fc')
@@ -121,7 +129,15 @@ class MIGT:
     def _gemm(self, x, name, M, epilogue=ops.EPI_NONE, res=None):
         d = self._dense[name]
         out = torch.empty((M, d.n), dtype=torch.float32, device=x.device)
-        ops.igemm(x, d.wp, M, d.k, d.n, out, bias=d.bias, res=res, epilogue=epilogue)
+        bf16 = d.wp16 is not None
+        ops.igemm(x, d.wp16 if bf16 else d.wp, M, d.k, d.n, out, bias=d.bias, res=res, epilogue=epilogue, bf16=bf16)
+        return out
+
+    def _lm(self, h, M, out):
+        """tied LM head: logits = h @ wte[:n_embeddings]^T  (SharedEmbeddings._linear, migt.py:51-56,417)"""
+        c = self.config
+        bf16 = getattr(self, '_lm_head16', None) is not None
+        ops.igemm(h, self._lm_head16 if bf16 else self._lm_head, M, c.d_model, c.n_embeddings, out, bf16=bf16)
         return out
 
     def _pose_embed(self, poses):
@@ -152,7 +168,7 @@ class MIGT:
             p = f'h.{i}'
             a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d)
             ca = self._dense[p + '.attn.c_attn']
-            ops.igemm(a, ca.wp, M, d, 3 * d, qkv, bias=ca.bias)
+            ops.igemm(a, ca.wp16 if ca.wp16 is not None else ca.wp, M, d, 3 * d, qkv, bias=ca.bias, bf16=ca.wp16 is not None)
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
                                  3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec)
@@ -195,7 +211,7 @@ class MIGT:
         h_mask = hf[:, S - 1].contiguous().view(B * L, d)
         h_loc = hf[:, S].contiguous().view(B * L, d)
         lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
-        ops.igemm(h_mask, self._lm_head, B * L, d, nE, lg)                              # migt.py:417
+        self._lm(h_mask, B * L, lg)                                                     # migt.py:417
         p1 = self._gemm(h_loc, 'pose_criterion.pose_classifier.c_fc', B * L, epilogue=ops.EPI_GELU)
         p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', B * L)
         pose = geometry.pose_head_postprocess(p2.view(B, 1, L, 7), c.pose_multiplier)
@@ -234,7 +250,7 @@ class MIGT:
         M = B * S * L
         hi = hf[:, img_ptr].contiguous().view(M, d)
         lg = torch.empty((M, nE), dtype=torch.float32, device=dev)
-        ops.igemm(hi, self._lm_head, M, d, nE, lg)                           # migt.py:417
+        self._lm(hi, M, lg)                                                  # migt.py:417
         out['logits'] = lg.view(*orig_shape, nE)
         if self.use_localization:                                            # migt.py:430-451
             hp = hf[:, pose_ptr].contiguous().view(M, d)
@@ -291,11 +307,11 @@ class MIGT:
         if last_view_logits_only:
             hl = hf.view(B, S, L, d)[:, -1].contiguous().view(B * L, d)
             lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
-            ops.igemm(hl, self._lm_head, B * L, d, nE, lg)
+            self._lm(hl, B * L, lg)
             out['logits_last'] = lg.view(B, *orig_shape[2:], nE)
         else:
             lg = torch.empty((M, nE), dtype=torch.float32, device=dev)
-            ops.igemm(hf, self._lm_head, M, d, nE, lg)                       # migt.py:417,51-56
+            self._lm(hf, M, lg)                                              # migt.py:417,51-56
             out['logits'] = lg.view(*orig_shape, nE)
         if self.use_localization:                                            # migt.py:430-451
             if last_view_logits_only:      # pose head on the last view only: shape [B,1,L,7], so [:, -1:] still works

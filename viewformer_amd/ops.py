@@ -77,9 +77,41 @@ def pack_dense_nk(w, n_rows=None):
 
 
 # ------------------------------------------------------------------ implicit GEMM
+def pack_dense_kn_bf16(w):
+    """Conv1D weight [nx][nf] -> bf16 fragment packing for vf_gemm_bf16"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    k, n = w.shape
+    out = torch.empty(int(lib.vf_gemm_bf16_packed_elems(k, n)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_gemm_bf16_pack(_p(w), _p(out), k, n, n, 1, 1, 0, _stream()), 'vf_gemm_bf16_pack')
+    return out
+
+
+def pack_dense_nk_bf16(w, n_rows=None):
+    """transposed weight [N][K] (x @ W^T; tied LM head, 1x1 conv [Cout][Cin]) -> bf16 packing"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    n, k = w.shape
+    n = n if n_rows is None else n_rows
+    out = torch.empty(int(lib.vf_gemm_bf16_packed_elems(k, n)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_gemm_bf16_pack(_p(w), _p(out), k, n, 1, k, 1, 0, _stream()), 'vf_gemm_bf16_pack')
+    return out
+
+
+def pack_conv3_bf16(w_oihw):
+    lib = _lib.load()
+    w = _f32(w_oihw).contiguous()
+    cout, cin = w.shape[:2]
+    out = torch.empty(int(lib.vf_conv3_bf16_packed_elems(cin, cout)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_conv3_bf16_pack(_p(w), _p(out), cin, cout, _stream()), 'vf_conv3_bf16_pack')
+    return out
+
+
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
-          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0):
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False):
+    """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
+    (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback)."""
     lib = _lib.load()
     a = VfIgemmArgs()
     a.x = x.data_ptr()
@@ -100,9 +132,17 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     a.ldr = (Cout if ldr is None else ldr)
     a.batch = batch
     a.stride_x, a.stride_w, a.stride_out, a.stride_res = stride_x, stride_w, stride_out, stride_res
-    for t in (x, w_packed, out, bias, res):
+    for t in (x, out, bias, res):
         if t is not None:
             _f32(t)
+    if bf16:
+        _chk(w_packed, torch.bfloat16, 'w_packed')
+        if mode == MODE_GEMM:
+            check(lib.vf_gemm_bf16(ctypes.byref(a), _stream()), 'vf_gemm_bf16')
+        else:
+            check(lib.vf_conv3_halo_bf16(ctypes.byref(a), _stream()), 'vf_conv3_halo_bf16')
+        return out
+    _f32(w_packed)
     check(lib.vf_igemm_f32(ctypes.byref(a), _stream()), 'vf_igemm_f32')
     return out
 

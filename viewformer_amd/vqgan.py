@@ -25,13 +25,19 @@ _IGNORED = re.compile(r'(perceptual_loss\..*)|(loss\..*)')     # vqgan_th.py:322
 
 
 class _Conv:
-    __slots__ = ('wp', 'bias', 'cin', 'cout', 'k', 'w_raw')
+    __slots__ = ('wp', 'wp16', 'bias', 'cin', 'cout', 'k', 'w_raw')
 
 
 class VQGAN:
-    def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 256):
+    def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 256,
+                 decoder_precision: str = 'f32'):
+        """``decoder_precision='bf16'`` runs the DECODER's wide 3x3 convolutions and 1x1 projections on the bf16-MFMA
+        arm (decoded pixels are tolerance-bounded in the north star); the encoder and the codebook lookup are always
+        exact fp32 so token indices stay bit-exact."""
         self.config = config or VQGANConfig()
         assert data_format in ('NCHW', 'NHWC')
+        assert decoder_precision in ('f32', 'bf16')
+        self.decoder_precision = decoder_precision
         self.data_format = data_format
         self.device = torch.device(device) if device is not None else None
         self.max_images_per_call = max_images_per_call
@@ -116,6 +122,12 @@ class VQGAN:
             c.bias = dev_t(name + '.bias')
             c.w_raw = w
             c.wp = ops.pack_conv_oihw(w) if c.cin % 32 == 0 else None
+            c.wp16 = None
+            if self.decoder_precision == 'bf16' and (name.startswith('decoder.') or name == 'post_quant_conv'):
+                if c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
+                    c.wp16 = ops.pack_conv3_bf16(w)
+                elif c.k == 1 and c.cin % 64 == 0:
+                    c.wp16 = ops.pack_dense_nk_bf16(w.reshape(c.cout, c.cin))
             self._conv[name] = c
 
         def norm(name):
@@ -154,15 +166,17 @@ class VQGAN:
         else:
             Ho, Wo = H, W
         out = torch.empty((n * Ho * Wo, c.cout), dtype=torch.float32, device=x.device)
-        ops.igemm(x, c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode, pro=pro,
-                  pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo)
+        bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
+        ops.igemm(x, c.wp16 if bf16 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode, pro=pro,
+                  pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16)
         return out, Ho, Wo
 
     def _conv1(self, x, name, M, pro=None, pro_swish=False, rows_per_img=0, res=None):
         c = self._conv[name]
         out = torch.empty((M, c.cout), dtype=torch.float32, device=x.device)
-        ops.igemm(x, c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro, pro_swish=pro_swish,
-                  pro_rows_per_img=rows_per_img)
+        bf16 = c.wp16 is not None and pro is None
+        ops.igemm(x, c.wp16 if bf16 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro, pro_swish=pro_swish,
+                  pro_rows_per_img=rows_per_img, bf16=bf16)
         return out
 
     def _gn(self, x, name, n, HW, C):
