@@ -5,7 +5,9 @@ One "step" = one pass of ``generate_batch_predictions`` (evaluate_transformer.py
 batch of synthetic scenes already resident in HBM: uint8 frames [B,7,128,128,3] + cameras [B,7,7]
 -> encode all 7 views (target included, as the reference does) -> MIGT pass with the MASK view ->
 argmax -> decode -> uint8 novel view (+ the localization pass the SM7 model runs).
-Workload = BASELINE.json configs[1]: SM7 codebook + transformer, 6 context views -> 1 novel view.
+Workload = BASELINE.json configs[1]: SM7 codebook + transformer, 6 context views -> 1 novel view, bf16: the encoder and
+the codebook lookup stay exact fp32 (bit-exact token indices), the transformer's dense layers and the decoder's
+convolutions run on bf16 MFMA with fp32 accumulation (--precision f32 runs the all-fp32 parity arm).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -135,10 +137,11 @@ def main():
     ap.add_argument('--views', type=int, default=7, help='views per scene (6 context + 1 novel)')
     ap.add_argument('--no-localization', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=['f32', 'mixed'], default='f32',
-                    help="f32: everything exact fp32 (default, full parity); mixed: fp32 encoder/lookup + bf16-MFMA "
-                         "transformer dense layers and decoder convolutions (logits/pixels within the tolerances of "
-                         "tests/test_hip_bf16.py)")
+    ap.add_argument('--precision', choices=['f32', 'mixed'], default='mixed',
+                    help="mixed (default; BASELINE configs[1] names bf16): exact-fp32 encoder + codebook lookup (token indices "
+                         "bit-exact) with the transformer's dense layers and the decoder's convolutions on bf16 MFMA, fp32 "
+                         "accumulate (logits / pixels within the tolerances stated in tests/test_hip_bf16.py); "
+                         "f32: everything exact fp32 (full fp32 parity arm)")
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 

@@ -78,7 +78,16 @@ def gn(n_img=56, C=128, HW=16384):
     print(f'gn_stats {n_img}x{HW}x{C}: {ms:.4f} ms  {x.numel() * 4 / ms / 1e6:.1f} GB/s')
 
 
-ALL = dict(conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
+def convin(n_img=224, H=128, C=128):
+    img = torch.randint(0, 256, (n_img, H, H, 3), dtype=torch.uint8, device=dev)
+    w = torch.randn(C, 3, 3, 3, device=dev) * 0.2
+    b = torch.randn(C, device=dev)
+    out = torch.empty((n_img, H, H, C), device=dev)
+    ms = timeit(lambda: ops.conv_in(img, w, b, n_img, H, H, C, out=out))
+    print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
+
+
+ALL = dict(convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8))
 

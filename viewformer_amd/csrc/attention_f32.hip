@@ -24,14 +24,14 @@ constexpr int DH = 64;
 constexpr int QT = 128;     // queries per workgroup
 constexpr int KT = 64;      // keys per tile
 constexpr int K_LD = 68;    // LDS row stride of the K tile (conflict-free ds_read_b128)
-constexpr int V_LD = 64;
+constexpr int VT_LD = 68;    // V is parked TRANSPOSED ([feature][key]) so a lane's 4 consecutive keys are one ds_read_b128
 
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
                                                                   float scale, int skip_masked, int twin) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
-    __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
+    __shared__ __attribute__((aligned(16))) float Vt[DH * VT_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<f32x4*>(Ks + (s_row0 + 16 * i) * K_LD + s_col4 * 4) = kreg[i];
-            *reinterpret_cast<f32x4*>(Vs + (s_row0 + 16 * i) * V_LD + s_col4 * 4) = vreg[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Vt[(s_col4 * 4 + e) * VT_LD + s_row0 + 16 * i] = vreg[i][e];
         }
         __syncthreads();
         if (kt + 1 < ntiles) prefetch(kt + 1);
@@ -207,15 +208,20 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
             for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
 
         // ---- O^T += V^T . P^T -------------------------------------------------------------
+        // lane (feature d = l31 [+32], half): keys t2*32 + 8j + 4*half + {0..3} are contiguous in Vt's row -> one b128
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float* vrow = Vs + key * V_LD + l31;
+            for (int j = 0; j < 4; ++j) {
+                f32x4 vv[2];
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
-                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[d * 32], st[t2][r], ot[d], 0, 0, 0);
+                    vv[d] = *reinterpret_cast<const f32x4*>(Vt + (d * 32 + l31) * VT_LD + t2 * 32 + 8 * j + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                        ot[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][e], st[t2][4 * j + e], ot[d], 0, 0, 0);
             }
     }
 
