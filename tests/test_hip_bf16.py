@@ -55,10 +55,11 @@ def test_gemm_bf16_layout_and_epilogue(dev, M, K, N):
 
 
 @pytest.mark.parametrize('mode,cin,cout,H,pro', [('s1', 128, 128, 16, True), ('s1', 64, 256, 32, False), ('up', 128, 128, 8, False),
-                                                  ('up', 32, 128, 16, True), ('s1', 256, 128, 64, True)])
+                                                  ('up', 32, 128, 16, True), ('s1', 256, 128, 64, True),
+                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False)])
 def test_conv3_halo_bf16(dev, mode, cin, cout, H, pro):
     from viewformer_amd import ops
-    n = 2
+    n = 3 if H == 8 else 2
     x = _rand((n, cin, H, H), 11) * 1.5 + 0.2
     w, b = _rand((cout, cin, 3, 3), 12, 0.05), _rand((cout,), 13)
     gamma, beta = _rand((cin,), 14) * 0.3 + 1, _rand((cin,), 15) * 0.2

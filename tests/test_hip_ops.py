@@ -78,7 +78,9 @@ def test_gemm_strided_views_and_batch(dev):
                                               ('up', 64, 32, 8), ('s1', 64, 3, 16), ('s1', 256, 512, 8),
                                               # halo-tile kernel shapes (Cout % 128 == 0, W % 16 == 0, H % 8 == 0)
                                               ('s1', 64, 256, 32), ('up', 128, 128, 8), ('up', 32, 128, 16),
-                                              ('s1', 32, 128, 64)])
+                                              ('s1', 32, 128, 64),
+                                              # pair geometry: two 8x8 images per halo tile (odd image count -> duplicate half)
+                                              ('s1', 64, 128, 8), ('s1', 512, 512, 8)])
 def test_conv3x3_modes(dev, mode, cin, cout, H):
     from viewformer_amd import ops
     n, W = 3, H
@@ -100,7 +102,7 @@ def test_conv3x3_modes(dev, mode, cin, cout, H):
     _close(out.view(n, Ho, Ho, cout).permute(0, 3, 1, 2), ref, 2e-5, 2e-5, f'conv {mode} {cin}->{cout}')
 
 
-@pytest.mark.parametrize('C,H', [(64, 16), (128, 32)])      # generic per-tap kernel / halo-tile kernel
+@pytest.mark.parametrize('C,H', [(64, 16), (128, 32), (128, 8)])      # generic per-tap kernel / halo-tile kernel / pair tile
 def test_conv_with_groupnorm_swish_prologue_and_residual(dev, C, H):
     from viewformer_amd import ops
     n = 2

@@ -26,10 +26,11 @@ __host__ __device__ constexpr int perm_px(int i) {
     return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
 }
 
-template <bool UP2>
+// PAIR: one 8x16 tile = two 8x8 images side by side, each with its own 10x10 halo patch (patch width 20)
+template <bool UP2, bool PAIR = false>
 struct Geo {
     static constexpr int PH = UP2 ? (TH / 2 + 2) : (TH + 2);
-    static constexpr int PW = UP2 ? (TW / 2 + 2) : (TW + 2);
+    static constexpr int PW = PAIR ? 20 : (UP2 ? (TW / 2 + 2) : (TW + 2));
     static constexpr int NPIX = PH * PW;
     static constexpr int SLOTS = (NPIX * 8 + 255) / 256;
     static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
@@ -40,9 +41,9 @@ __device__ __forceinline__ float fast_swish(float t) {
     return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
 }
 
-template <bool UP2, bool PRO, bool SWISH>
+template <bool UP2, bool PRO, bool SWISH, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p) {
-    using G = Geo<UP2>;
+    using G = Geo<UP2, PAIR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][BUF]
 
     const int tid = threadIdx.x;
@@ -55,9 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
     int bid = blockIdx.x;
     const int nblk = bid % nb; bid /= nb;
-    const int tx = bid % tilesX; bid /= tilesX;
-    const int ty = bid % tilesY;
-    const int img = bid / tilesY;
+    int tx = 0, ty = 0, img;
+    if (PAIR) { img = bid * 2; }
+    else { tx = bid % tilesX; bid /= tilesX; ty = bid % tilesY; img = bid / tilesY; }
+    const int n_img_total = p.M / (p.Hout * p.Wout);
+    const int img1 = PAIR ? min(img + 1, n_img_total - 1) : img;   // 2nd image of the pair (= the 1st when n_img is odd: same values rewritten)
+    const int pair_pix = (img1 - img) * p.Hin * p.Win;            // pixel offset of the 2nd image
     const int y0 = ty * TH, x0 = tx * TW;
     const int sy0 = UP2 ? (y0 / 2 - 1) : (y0 - 1);
     const int sx0 = UP2 ? (x0 / 2 - 1) : (x0 - 1);
@@ -69,21 +73,25 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     const int c4 = tid & 7;
     int s_off[G::SLOTS];
     bool s_ok[G::SLOTS];
+    int s_sel[G::SLOTS];
     int s_lds[G::SLOTS];
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) {
         const int pix = (tid >> 3) + 32 * q;
         const int pixc = pix < G::NPIX ? pix : G::NPIX;
-        const int pr = pixc / G::PW, pc = pixc - pr * G::PW;
+        const int pr = pixc / G::PW, pc0 = pixc - pr * G::PW;
+        const int sel = PAIR ? (pc0 >= 10) : 0;
+        const int pc = pc0 - 10 * sel;
+        s_sel[q] = sel;
         const int sy = sy0 + pr, sx = sx0 + pc;
         const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
         s_ok[q] = ok;
-        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
         s_lds[q] = pixc * P_LDB + c4 * 8;
     }
 
     f32x4 preg[G::SLOTS];
-    f32x4 pmean, pscale, pbeta;
+    f32x4 pmean, pscale, pbeta, pmean1, pscale1;
     auto patch_load = [&](int chunk) {
         const float* xc = X + chunk * CK;
 #pragma unroll
@@ -92,6 +100,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
             pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
             pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
             pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
+            if (PAIR) {
+                pmean1 = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+                pscale1 = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+            }
         }
     };
     auto patch_store_slot = [&](int buf, int q) {
@@ -101,7 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
         for (int e = 0; e < 4; ++e) {
             float t = preg[q][e];
             if (PRO) {
-                t = (t - pmean[e]) * pscale[e] + pbeta[e];
+                const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
+                const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
+                t = (t - mu) * sc + pbeta[e];
                 if (SWISH) t = fast_swish(t);
             }
             o[e] = (__bf16)(s_ok[q] ? t : 0.f);
@@ -115,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     for (int mi = 0; mi < 2; ++mi) {
         const int a0 = wave_m * 4 + mi * 2 + trow;
         a_r[mi] = a0;
-        a_base[mi] = (a0 * G::PW + tpx) * P_LDB + half * 16;
+        const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
+        a_base[mi] = (a0 * G::PW + tcol) * P_LDB + half * 16;
     }
 
     // packed weights [chunk][tap][nblk][ks(2)][half(2)][n(128)][8 bf16]
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
                 const int i0 = (r & 3) + 8 * (r >> 2);
                 const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
                 const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
+                if (PAIR) return (ppx >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx & 7);
                 return (py + prow) * p.Wout + x0 + ppx;
             };
             auto oo = [&](int r) { return pix(r) * p.ldc; };
@@ -225,20 +241,21 @@ __global__ void pack_conv_bf16_kernel(const float* __restrict__ w, __bf16* __res
     }
 }
 
-template <bool UP2, bool PRO, bool SWISH>
+template <bool UP2, bool PRO, bool SWISH, bool PAIR>
 int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
-    using G = Geo<UP2>;
+    using G = Geo<UP2, PAIR>;
     const size_t smem = (size_t)2 * G::BUF;
     const int n_img = a.M / (a.Hout * a.Wout);
-    const long long blocks = (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv3_halo_bf16_kernel<UP2, PRO, SWISH>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
+    const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)
+                                  : (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv3_halo_bf16_kernel<UP2, PRO, SWISH, PAIR>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
     return vf_last_status();
 }
 
-template <bool UP2>
+template <bool UP2, bool PAIR>
 int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
-    if (!a.pro_mean) return launch_halo<UP2, false, false>(a, s);
-    return a.pro_swish ? launch_halo<UP2, true, true>(a, s) : launch_halo<UP2, true, false>(a, s);
+    if (!a.pro_mean) return launch_halo<UP2, false, false, PAIR>(a, s);
+    return a.pro_swish ? launch_halo<UP2, true, true, PAIR>(a, s) : launch_halo<UP2, true, false, PAIR>(a, s);
 }
 
 }  // namespace
@@ -265,7 +282,8 @@ int vf_conv3_halo_bf16(const vf_igemm_args* args, void* stream) {
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
-    if (a.Cout % BN != 0 || a.Cin % CK != 0 || a.Hout % TH != 0 || a.Wout % TW != 0) return VF_ERR_UNSUPPORTED;
+    const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
+    if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0))) return VF_ERR_UNSUPPORTED;
     if (a.Hin <= 0 || a.Win <= 0 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
     if (a.mode == VF_MODE_CONV3_S1 && (a.Hout != a.Hin || a.Wout != a.Win)) return VF_ERR_BAD_ARG;
     if (a.mode == VF_MODE_CONV3_UP2 && (a.Hout != a.Hin * 2 || a.Wout != a.Win * 2)) return VF_ERR_BAD_ARG;
@@ -273,7 +291,8 @@ int vf_conv3_halo_bf16(const vf_igemm_args* args, void* stream) {
     if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
     if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true>(a, s) : dispatch_pro<false>(a, s);
+    if (pair) return dispatch_pro<false, true>(a, s);
+    return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);
 }
 
 }  // extern "C"

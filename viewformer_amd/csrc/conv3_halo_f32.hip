@@ -38,18 +38,19 @@ __host__ __device__ constexpr int perm_px(int i) {
     return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
 }
 
-template <bool UP2>
+// PAIR: one 8x16 tile = two 8x8 images side by side, each with its own 10x10 halo patch (patch width 20)
+template <bool UP2, bool PAIR = false>
 struct Geo {
     static constexpr int PH = UP2 ? (TH / 2 + 2) : (TH + 2);   // patch extent in source pixels
-    static constexpr int PW = UP2 ? (TW / 2 + 2) : (TW + 2);
+    static constexpr int PW = PAIR ? 20 : (UP2 ? (TW / 2 + 2) : (TW + 2));
     static constexpr int NPIX = PH * PW;
     static constexpr int SLOTS = (NPIX * 8 + 255) / 256;       // float4 staging slots per thread
     static constexpr int BUF = (NPIX + 1) * P_LD;              // +1 dummy pixel: sink for idle staging lanes
 };
 
-template <bool UP2, bool PRO, bool SWISH>
+template <bool UP2, bool PRO, bool SWISH, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
-    using G = Geo<UP2>;
+    using G = Geo<UP2, PAIR>;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][BUF]
 
     const int tid = threadIdx.x;
@@ -64,9 +65,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
     const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
     int bid = blockIdx.x;
     const int nblk = bid % nb; bid /= nb;
-    const int tx = bid % tilesX; bid /= tilesX;
-    const int ty = bid % tilesY;
-    const int img = bid / tilesY;
+    int tx = 0, ty = 0, img;
+    if (PAIR) { img = bid * 2; }
+    else { tx = bid % tilesX; bid /= tilesX; ty = bid % tilesY; img = bid / tilesY; }
+    const int n_img_total = p.M / (p.Hout * p.Wout);
+    const int img1 = PAIR ? min(img + 1, n_img_total - 1) : img;   // 2nd image of the pair (= the 1st when n_img is odd: same values rewritten)
+    const int pair_pix = (img1 - img) * p.Hin * p.Win;            // pixel offset of the 2nd image
     const int y0 = ty * TH, x0 = tx * TW;          // output-tile origin
     const int sy0 = UP2 ? (y0 / 2 - 1) : (y0 - 1); // source-patch origin
     const int sx0 = UP2 ? (x0 / 2 - 1) : (x0 - 1);
@@ -79,21 +83,25 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
     const int c4 = tid & 7;
     int s_off[G::SLOTS];          // source offset in floats inside the image (clamped to 0 when invalid)
     bool s_ok[G::SLOTS];
+    int s_sel[G::SLOTS];
     int s_lds[G::SLOTS];
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) {
         const int pix = (tid >> 3) + 32 * q;
         const int pixc = pix < G::NPIX ? pix : G::NPIX;     // idle lanes write the dummy pixel
-        const int pr = pixc / G::PW, pc = pixc - pr * G::PW;
+        const int pr = pixc / G::PW, pc0 = pixc - pr * G::PW;
+        const int sel = PAIR ? (pc0 >= 10) : 0;
+        const int pc = pc0 - 10 * sel;
+        s_sel[q] = sel;
         const int sy = sy0 + pr, sx = sx0 + pc;
         const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
         s_ok[q] = ok;
-        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
         s_lds[q] = pixc * P_LD + c4 * 4;
     }
 
     f32x4 preg[G::SLOTS];
-    f32x4 pmean, pscale, pbeta;
+    f32x4 pmean, pscale, pbeta, pmean1, pscale1;
     auto patch_load = [&](int chunk) {
         const float* xc = X + chunk * CK;                    // uniform
 #pragma unroll
@@ -105,6 +113,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
             pmean = *reinterpret_cast<const f32x4*>(pm + c4 * 4);
             pscale = *reinterpret_cast<const f32x4*>(ps + c4 * 4);
             pbeta = *reinterpret_cast<const f32x4*>(pb + c4 * 4);
+            if (PAIR) {
+                pmean1 = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+                pscale1 = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+            }
         }
     };
     auto patch_store_slot = [&](int buf, int q) {
@@ -114,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
         for (int e = 0; e < 4; ++e) {
             float t = v[e];
             if (PRO) {
-                t = (t - pmean[e]) * pscale[e] + pbeta[e];
+                const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
+                const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
+                t = (t - mu) * sc + pbeta[e];
                 if (SWISH) t = vf_swish(t);
             }
             v[e] = s_ok[q] ? t : 0.f;                        // zero padding lives in the conv's input space
@@ -129,7 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
     for (int mi = 0; mi < 2; ++mi) {
         const int a0 = wave_m * 4 + mi * 2 + trow;
         a_r[mi] = a0;
-        a_base[mi] = (a0 * G::PW + tpx) * P_LD + half * 4;
+        const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
+        a_base[mi] = (a0 * G::PW + tcol) * P_LD + half * 4;
     }
 
     // ---- B fragments straight from L2: packed [chunk][tap][nblk][g][half][n][4] -----------------------
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
                 const int i0 = (r & 3) + 8 * (r >> 2);
                 const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
                 const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
+                if (PAIR) return (ppx >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx & 7);
                 return (py + prow) * p.Wout + x0 + ppx;
             };
             auto oo = [&](int r) { return pix(r) * p.ldc; };
@@ -224,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(vf_igemm_args p) {
     }
 }
 
-template <bool UP2, bool PRO, bool SWISH>
+template <bool UP2, bool PRO, bool SWISH, bool PAIR>
 int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
-    using G = Geo<UP2>;
+    using G = Geo<UP2, PAIR>;
     const size_t smem = (size_t)2 * G::BUF * sizeof(float);
-    auto kern = conv3_halo_kernel<UP2, PRO, SWISH>;
+    auto kern = conv3_halo_kernel<UP2, PRO, SWISH, PAIR>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -237,15 +253,16 @@ int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
         attr_set = true;
     }
     const int n_img = a.M / (a.Hout * a.Wout);
-    const long long blocks = (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)
+                                  : (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, a);
     return vf_last_status();
 }
 
-template <bool UP2>
+template <bool UP2, bool PAIR>
 int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
-    if (!a.pro_mean) return launch_halo<UP2, false, false>(a, s);
-    return a.pro_swish ? launch_halo<UP2, true, true>(a, s) : launch_halo<UP2, true, false>(a, s);
+    if (!a.pro_mean) return launch_halo<UP2, false, false, PAIR>(a, s);
+    return a.pro_swish ? launch_halo<UP2, true, true, PAIR>(a, s) : launch_halo<UP2, true, false, PAIR>(a, s);
 }
 
 }  // namespace
@@ -254,9 +271,11 @@ int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
 int vf_conv3_halo_try(const vf_igemm_args& a, hipStream_t stream, int* status) {
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return 1;
     if (a.Cout % BN != 0 || a.Cin % CK != 0) return 1;
-    if (a.Hout % TH != 0 || a.Wout % TW != 0) return 1;
+    const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
+    if (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0)) return 1;
     if (a.batch > 1 || a.epilogue != VF_EPI_NONE) return 1;
     if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return 1;
-    *status = (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true>(a, stream) : dispatch_pro<false>(a, stream);
+    *status = pair ? dispatch_pro<false, true>(a, stream)
+                   : (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, stream) : dispatch_pro<false, false>(a, stream);
     return 0;
 }
