@@ -180,6 +180,18 @@ int vf_conv3_bf16_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* 
 int vf_conv3_halo_bf16(const vf_igemm_args* args /* host */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * fp32-EQUIVALENT arm on the bf16 matrix pipe ("x6").  Every fp32 operand is split exactly into three bf16
+ * pieces (x = h + m + l) and each fp32 product is evaluated as the six partial products whose weight is
+ * >= 2^-24 of it, accumulated in fp32 (small terms first).  Error vs fp64 equals the native f32 MFMA's
+ * (profiles/r1_split_bf16_probe.txt); this is NOT a reduced-precision path and replaces the same reference
+ * call sites as vf_igemm_f32's 3x3 modes (torch.nn.Conv2d in vqgan_th.py:23-32,60-70,197,249).
+ * Same vf_igemm_args and shape rules as vf_conv3_halo_bf16; w_packed points to the 3-plane bf16 packing.
+ * ------------------------------------------------------------------------------------- */
+size_t vf_conv3_x6_packed_elems(int Cin, int Cout);       /* number of bf16 elements (3 planes) */
+int vf_conv3_x6_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
+int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.

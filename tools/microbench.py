@@ -25,10 +25,10 @@ def timeit(fn, iters=5, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def conv(n_img=56, C=128, H=128, pro=True):
+def conv(n_img=56, C=128, H=128, pro=True, x6=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
-    wp = ops.pack_conv_oihw(w)
+    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
     b = torch.randn(C, device=dev)
     out = torch.empty_like(x)
     prol = None
@@ -38,9 +38,9 @@ def conv(n_img=56, C=128, H=128, pro=True):
         prol = (m, s, torch.zeros(C, device=dev))
     M = n_img * H * H
     ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
-                                  Hin=H, Win=H, Hout=H, Wout=H))
+                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6))
     fl = 2.0 * M * C * C * 9
-    print(f'conv3x3 {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
+    print(f'conv3x3{" x6" if x6 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 
 
 def gemm(M=7168, K=768, N=3072, epi=0):
@@ -89,7 +89,9 @@ def convin(n_img=224, H=128, C=128):
 
 ALL = dict(convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
-           conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8))
+           conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
+           convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
+           convx6_512=lambda: conv(224, 512, 8, x6=True))
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

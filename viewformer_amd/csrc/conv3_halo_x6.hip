@@ -1,0 +1,329 @@
+// fp32-EQUIVALENT 3x3 convolution on the bf16 matrix pipe ("x6": 6-term split-bf16 products), gfx950.
+// Same halo-tile structure, pixel permutation and epilogue as conv3_halo_f32.hip, but every fp32 operand x is split
+// EXACTLY into three bf16 pieces x = h + m + l (8+8+8 mantissa bits) and every fp32 product a*b is evaluated as
+//     al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh        (each bf16 x bf16 product is exact in fp32)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, small terms first.  The dropped terms (am*bl, al*bm, al*bl) are
+// below 2^-24 of the product, i.e. below the rounding of a native fp32 multiply.  Measured (tools/split_bf16_probe.hip,
+// profiles/r1_split_bf16_probe.txt): error vs fp64 relative to sum|a*b| over K=1152: x6 rms 2.4e-8 / max 1.5e-7,
+// native v_mfma_f32_32x32x2_f32 rms 2.7e-8 / max 1.5e-7, host fmaf chain identical to the f32 MFMA.  The bf16 pipe is
+// 16x the f32 pipe (measured 2.0-2.2 PF vs 0.15 PF), so 6 MFMAs per fp32 product still leave a 2.2x higher ceiling
+// (~350 TF fp32-equivalent) than the native f32 MFMA (157 TF).
+// Data path: fp32 activations in HBM; the GroupNorm-apply(+swish) prologue in exact fp32 (same code as the f32 kernel);
+// the split happens ONCE per patch element when the patch is parked in LDS as [pixel][plane h|m|l][32 ch] bf16
+// (208-byte pixel stride = 13 x 16 B: conflict-free ds_read_b128 for every tap shift); weights are pre-split at pack
+// time into three fragment-packed bf16 planes and streamed L2 -> VGPR one (tap, k-step) stage ahead.
+// Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,197,249) with
+// GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
+#include "vf_common.h"
+#include "epilogue.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 32;
+constexpr int P_LDB = 208;          // bytes per patch pixel in LDS: 3 planes x 64 B + 16 B pad
+constexpr int TH = 8, TW = 16;
+constexpr int BN = 128;
+constexpr int PLANE_BYTES = 2 * BN * 16;      // one (k-step, plane): [half(2)][n(128)][8 bf16] = 4 KB
+constexpr int KS_BYTES = 3 * PLANE_BYTES;     // one k-step of 16 channels: 3 planes
+constexpr int TAP_BYTES = 2 * KS_BYTES;       // one (chunk, tap, n-block) weight tile: 24 KB
+
+__host__ __device__ constexpr int perm_row(int i) { return (i < 4) ? 0 : (i < 12) ? 1 : (i < 16) ? 0 : (i < 20) ? 1 : (i < 28) ? 0 : 1; }
+__host__ __device__ constexpr int perm_px(int i) {
+    return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
+}
+
+// PAIR: one 8x16 tile = two 8x8 images side by side, each with its own 10x10 halo patch (patch width 20)
+template <bool UP2, bool PAIR = false>
+struct Geo {
+    static constexpr int PH = UP2 ? (TH / 2 + 2) : (TH + 2);
+    static constexpr int PW = PAIR ? 20 : (UP2 ? (TW / 2 + 2) : (TW + 2));
+    static constexpr int NPIX = PH * PW;
+    static constexpr int SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    // exact 3-way split: h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m); both subtractions are exact
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+template <bool UP2, bool PRO, bool SWISH, bool PAIR = false>
+__global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) {
+    using G = Geo<UP2, PAIR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][BUF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    int bid = blockIdx.x;
+    const int nblk = bid % nb; bid /= nb;
+    int tx = 0, ty = 0, img;
+    if (PAIR) { img = bid * 2; }
+    else { tx = bid % tilesX; bid /= tilesX; ty = bid % tilesY; img = bid / tilesY; }
+    const int n_img_total = p.M / (p.Hout * p.Wout);
+    const int img1 = PAIR ? min(img + 1, n_img_total - 1) : img;   // 2nd image of the pair (= the 1st when n_img is odd: same values rewritten)
+    const int pair_pix = (img1 - img) * p.Hin * p.Win;            // pixel offset of the 2nd image
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int sy0 = UP2 ? (y0 / 2 - 1) : (y0 - 1);
+    const int sx0 = UP2 ? (x0 / 2 - 1) : (x0 - 1);
+
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / CK;
+    const int last_stage = nchunks * 9 - 1;
+
+    const int c4 = tid & 7;
+    int s_off[G::SLOTS];
+    bool s_ok[G::SLOTS];
+    int s_sel[G::SLOTS];
+    int s_lds[G::SLOTS];
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int pixc = pix < G::NPIX ? pix : G::NPIX;
+        const int pr = pixc / G::PW, pc0 = pixc - pr * G::PW;
+        const int sel = PAIR ? (pc0 >= 10) : 0;
+        const int pc = pc0 - 10 * sel;
+        s_sel[q] = sel;
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
+        s_ok[q] = ok;
+        s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_lds[q] = pixc * P_LDB + c4 * 8;
+    }
+
+    f32x4 preg[G::SLOTS];
+    f32x4 pmean, pscale, pbeta, pmean1, pscale1;
+    auto patch_load = [&](int chunk) {
+        const float* xc = X + chunk * CK;
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+        if (PRO) {
+            pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
+            if (PAIR) {
+                pmean1 = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+                pscale1 = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+            }
+        }
+    };
+    auto patch_store_slot = [&](int buf, int q) {
+        unsigned char* dst = smem_h + buf * G::BUF + s_lds[q];
+        bf16x4 oh, om, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = preg[q][e];
+            if (PRO) {
+                const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
+                const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
+                t = (t - mu) * sc + pbeta[e];
+                if (SWISH) t = vf_swish(t);
+            }
+            __bf16 h, m, l;
+            split3(s_ok[q] ? t : 0.f, h, m, l);
+            oh[e] = h; om[e] = m; ol[e] = l;
+        }
+        *reinterpret_cast<bf16x4*>(dst) = oh;
+        *reinterpret_cast<bf16x4*>(dst + 64) = om;
+        *reinterpret_cast<bf16x4*>(dst + 128) = ol;
+    };
+
+    const int trow = perm_row(l31), tpx = perm_px(l31);
+    int a_base[2], a_r[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int a0 = wave_m * 4 + mi * 2 + trow;
+        a_r[mi] = a0;
+        const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
+        a_base[mi] = (a0 * G::PW + tcol) * P_LDB + half * 16;
+    }
+
+    // packed weights [chunk][tap][nblk][ks(2)][plane(3)][half(2)][n(128)][8 bf16]; one pipeline stage = one (tap, ks)
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    bf16x8 bc[3][2], bn[3][2];
+    auto b_load = [&](bf16x8 (&dst)[3][2], int tap_idx, int ks) {
+        const unsigned char* src = Wb + (size_t)tap_idx * tap_stride + ks * KS_BYTES + b_lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const bf16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    patch_load(0);
+    b_load(bc, 0, 0);
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
+        patch_load(min(chunk + 1, nchunks - 1));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            int aoff[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (UP2) {
+                    const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
+                    aoff[mi] = (pr * G::PW + pc) * P_LDB + half * 16;
+                } else {
+                    aoff[mi] = a_base[mi] + (dy * G::PW + dx) * P_LDB;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 0) b_load(bn, chunk * 9 + tap, 1);
+                else b_load(bn, min(chunk * 9 + tap + 1, last_stage), 0);
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[mi][pl] = *reinterpret_cast<const bf16x8*>(patch + aoff[mi] + pl * 64 + ks * 32);
+                // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t]], bc[PB[t]][j], acc[mi][j], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bc[pl][j] = bn[pl][j];
+            }
+            if (tap >= 1 && tap <= G::SLOTS) patch_store_slot((chunk + 1) & 1, tap - 1);
+        }
+        __syncthreads();
+    }
+
+    float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
+    const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int py = y0 + wave_m * 4 + mi * 2;
+            auto pix = [&](int r) {
+                const int i0 = (r & 3) + 8 * (r >> 2);
+                const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
+                const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
+                if (PAIR) return (ppx >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx & 7);
+                return (py + prow) * p.Wout + x0 + ppx;
+            };
+            auto oo = [&](int r) { return pix(r) * p.ldc; };
+            auto ro = [&](int r) { return pix(r) * p.ldr; };
+            if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
+            else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
+        }
+    }
+}
+
+__global__ void pack_conv_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks) {
+    // dst [chunk][tap][nblk][ks(2)][plane(3)][half(2)][n(128)][8]; src OIHW [Cout][Cin][3][3]
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;       // fp32 weights (each becomes 3 bf16)
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        long long t = idx >> 3;
+        const int nl = (int)(t % BN); t /= BN;
+        const int half = (int)(t & 1);
+        const int ks = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int nblk = (int)(t % nb); t /= nb;
+        const int tap = (int)(t % 9);
+        const int chunk = (int)(t / 9);
+        const int c = chunk * CK + ks * 16 + half * 8 + e;
+        const int n = nblk * BN + nl;
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * 9 + tap];
+        __bf16 h, m, l;
+        split3(v, h, m, l);
+        const size_t base = ((((size_t)(chunk * 9 + tap) * nb + nblk) * 2 + ks) * 3) * (2 * BN * 8) + ((size_t)half * BN + nl) * 8 + e;
+        dst[base] = h;
+        dst[base + 2 * BN * 8] = m;
+        dst[base + 2 * (2 * BN * 8)] = l;
+    }
+}
+
+template <bool UP2, bool PRO, bool SWISH, bool PAIR>
+int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
+    using G = Geo<UP2, PAIR>;
+    const size_t smem = (size_t)2 * G::BUF;
+    const int n_img = a.M / (a.Hout * a.Wout);
+    const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)
+                                  : (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv3_halo_x6_kernel<UP2, PRO, SWISH, PAIR>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
+    return vf_last_status();
+}
+
+template <bool UP2, bool PAIR>
+int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
+    if (!a.pro_mean) return launch_halo<UP2, false, false, PAIR>(a, s);
+    return a.pro_swish ? launch_halo<UP2, true, true, PAIR>(a, s) : launch_halo<UP2, true, false, PAIR>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vf_conv3_x6_packed_elems(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)((Cin + CK - 1) / CK) * 9 * ((Cout + BN - 1) / BN) * CK * BN * 3;
+}
+
+int vf_conv3_x6_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream) {
+    if (!w_oihw || !dst || Cin <= 0 || Cout <= 0) return VF_ERR_BAD_ARG;
+    const int nb = (Cout + BN - 1) / BN, nchunks = (Cin + CK - 1) / CK;
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_x6_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (__bf16*)dst, Cin, Cout, nb,
+                       nchunks);
+    return vf_last_status();
+}
+
+int vf_conv3_halo_x6(const vf_igemm_args* args, void* stream) {
+    if (!args) return VF_ERR_BAD_ARG;
+    const vf_igemm_args& a = *args;
+    if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
+    if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
+    const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
+    if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0))) return VF_ERR_UNSUPPORTED;
+    if (a.Hin <= 0 || a.Win <= 0 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_S1 && (a.Hout != a.Hin || a.Wout != a.Win)) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_UP2 && (a.Hout != a.Hin * 2 || a.Wout != a.Win * 2)) return VF_ERR_BAD_ARG;
+    if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+    if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
+    if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (pair) return dispatch_pro<false, true>(a, s);
+    return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);
+}
+
+}  // extern "C"

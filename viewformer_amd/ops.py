@@ -107,11 +107,30 @@ def pack_conv3_bf16(w_oihw):
     return out
 
 
+def pack_conv3_x6(w_oihw):
+    """OIHW fp32 3x3 weight -> three fragment-packed bf16 planes (exact split w = h + m + l) for vf_conv3_halo_x6"""
+    lib = _lib.load()
+    w = _f32(w_oihw).contiguous()
+    cout, cin = w.shape[:2]
+    out = torch.empty(int(lib.vf_conv3_x6_packed_elems(cin, cout)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_conv3_x6_pack(_p(w), _p(out), cin, cout, _stream()), 'vf_conv3_x6_pack')
+    return out
+
+
+def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
+    """shape rules of vf_conv3_halo_x6 (host-side mirror so callers can pick the packing up front)"""
+    if mode not in (MODE_CONV3_S1, MODE_CONV3_UP2) or Cin % 32 or Cout % 128:
+        return False
+    return (Hout % 8 == 0 and Wout % 16 == 0) or (mode == MODE_CONV3_S1 and Hout == 8 and Wout == 8)
+
+
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
-          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False):
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
-    (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback)."""
+    (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
+    ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
+    split-bf16 kernel (vf_conv3_halo_x6)."""
     lib = _lib.load()
     a = VfIgemmArgs()
     a.x = x.data_ptr()
@@ -135,6 +154,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     for t in (x, out, bias, res):
         if t is not None:
             _f32(t)
+    if x6:
+        _chk(w_packed, torch.bfloat16, 'w_packed')
+        check(lib.vf_conv3_halo_x6(ctypes.byref(a), _stream()), 'vf_conv3_halo_x6')
+        return out
     if bf16:
         _chk(w_packed, torch.bfloat16, 'w_packed')
         if mode == MODE_GEMM:

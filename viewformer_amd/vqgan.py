@@ -25,19 +25,23 @@ _IGNORED = re.compile(r'(perceptual_loss\..*)|(loss\..*)')     # vqgan_th.py:322
 
 
 class _Conv:
-    __slots__ = ('wp', 'wp16', 'bias', 'cin', 'cout', 'k', 'w_raw')
+    __slots__ = ('wp', 'wp16', 'wp6', 'bias', 'cin', 'cout', 'k', 'w_raw')
 
 
 class VQGAN:
     def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 256,
-                 decoder_precision: str = 'f32'):
-        """``decoder_precision='bf16'`` runs the DECODER's wide 3x3 convolutions and 1x1 projections on the bf16-MFMA
+                 decoder_precision: str = 'f32', conv_arith: str = 'x6'):
+        """``conv_arith`` picks how the fp32 3x3 convolutions are evaluated: 'f32' = native f32 MFMA, 'x6' = the
+        fp32-EQUIVALENT six-term split-bf16 kernel (same error against fp64 as the f32 MFMA, ~1.6x faster; see
+        csrc/conv3_halo_x6.hip).  Both give bit-identical token indices on the reference's golden vectors.
+        ``decoder_precision='bf16'`` runs the DECODER's wide 3x3 convolutions and 1x1 projections on the bf16-MFMA
         arm (decoded pixels are tolerance-bounded in the north star); the encoder and the codebook lookup are always
         exact fp32 so token indices stay bit-exact."""
         self.config = config or VQGANConfig()
         assert data_format in ('NCHW', 'NHWC')
-        assert decoder_precision in ('f32', 'bf16')
+        assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6')
         self.decoder_precision = decoder_precision
+        self.conv_arith = conv_arith
         self.data_format = data_format
         self.device = torch.device(device) if device is not None else None
         self.max_images_per_call = max_images_per_call
@@ -123,6 +127,9 @@ class VQGAN:
             c.w_raw = w
             c.wp = ops.pack_conv_oihw(w) if c.cin % 32 == 0 else None
             c.wp16 = None
+            c.wp6 = None
+            if self.conv_arith == 'x6' and c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
+                c.wp6 = ops.pack_conv3_x6(w)
             if self.decoder_precision == 'bf16' and (name.startswith('decoder.') or name == 'post_quant_conv'):
                 if c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                     c.wp16 = ops.pack_conv3_bf16(w)
@@ -169,8 +176,10 @@ class VQGAN:
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
         bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
-        ops.igemm(x, c.wp16 if bf16 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode, pro=pro,
-                  pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16)
+        # fp32-equivalent split-bf16 kernel wherever its plain 8x16 tiling applies (the 8x8 pair tiles gain nothing)
+        x6 = (not bf16 and c.wp6 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
+        ops.igemm(x, c.wp16 if bf16 else c.wp6 if x6 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode,
+                  pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6)
         return out, Ho, Wo
 
     def _conv1(self, x, name, M, pro=None, pro_swish=False, rows_per_img=0, res=None):
