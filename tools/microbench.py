@@ -12,10 +12,14 @@ from viewformer_amd import ops  # noqa: E402
 dev = torch.device('cuda:0')
 
 
-def timeit(fn, iters=5, warm=2):
-    for _ in range(warm):
+def timeit(fn, iters=8, warm=2):
+    # the first launches of a process run at ramping clocks (measured: ~10 % slow): warm for >= 0.3 s of GPU work
+    t0 = time.time()
+    n = 0
+    while n < warm or time.time() - t0 < 0.3:
         fn()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        n += 1
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

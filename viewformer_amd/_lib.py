@@ -9,7 +9,8 @@ import os
 from ctypes import c_int, c_int32, c_int64, c_float, c_void_p, c_size_t, c_char_p, POINTER
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libvf_hip.so')
+# VF_HIP_LIB: developer override used by tools/variants.sh to time side-by-side builds of the same ABI
+LIB_PATH = os.environ.get('VF_HIP_LIB') or os.path.join(HERE, 'libvf_hip.so')
 
 
 class VfIgemmArgs(ctypes.Structure):

@@ -18,6 +18,21 @@
 #include "epilogue.h"
 #include "../../include/vf_hip.h"
 
+// tuning knobs (tools/variants.sh builds side-by-side libraries with different values for A/B timing on the GPU)
+#ifndef VF_X6_BD
+#define VF_X6_BD 5        // weight fragments are fetched this many stages ahead (register ring of BD + 1);
+                          // measured 1/2/5: 192/198/204 TF @128^2 and 98/128/158 TF on the 8x8 pair tiles (L2-miss bound)
+#endif
+#ifndef VF_X6_AD
+#define VF_X6_AD 1        // LDS activation fragments are read this many stages ahead (0 or 1)
+#endif
+#ifndef VF_X6_STORE
+#define VF_X6_STORE 0     // 0: staging slot q is transformed+parked in stage 2q+1; 1: in stage 2q+3
+#endif
+#ifndef VF_X6_PRECISE_SWISH
+#define VF_X6_PRECISE_SWISH 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,6 +60,21 @@ struct Geo {
     static constexpr int SLOTS = (NPIX * 8 + 255) / 256;
     static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
 };
+
+__device__ __forceinline__ float swish_1ulp(float v) {
+    // x * sigmoid(x) to ~1.5 ulp without the library expf / IEEE-division sequences (25 -> 11 VALU per element):
+    // exp(-v) = exp2(t_hi) * (1 + t_lo ln2) with t = -v log2(e) carried as hi + lo (the rounding of t would otherwise
+    // cost |t| 2^-24 relative), v_exp_f32 (1 ulp); 1/(1+e) = v_rcp_f32 + one Newton step.
+    const float LH = -1.4426950408889634f, LL = -1.9259629911266175e-8f;      // -log2(e) = LH + LL
+    float th = v * LH;
+    const float tl = __builtin_fmaf(v, LH, -th) + v * LL;
+    th = fminf(th, 126.0f);                                                    // keeps 1 + e finite (v < -87: result ~ -0)
+    const float e0 = __builtin_amdgcn_exp2f(th);
+    const float d = 1.0f + __builtin_fmaf(e0 * tl, 0.6931471805599453f, e0);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return v * r;
+}
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     // exact 3-way split: h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m); both subtractions are exact
@@ -129,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
                 const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
                 const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
                 t = (t - mu) * sc + pbeta[e];
-                if (SWISH) t = vf_swish(t);
+                if (SWISH) t = VF_X6_PRECISE_SWISH ? vf_swish(t) : swish_1ulp(t);
             }
             __bf16 h, m, l;
             split3(s_ok[q] ? t : 0.f, h, m, l);
@@ -154,13 +184,36 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
     const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
-    bf16x8 bc[3][2], bn[3][2];
-    auto b_load = [&](bf16x8 (&dst)[3][2], int tap_idx, int ks) {
-        const unsigned char* src = Wb + (size_t)tap_idx * tap_stride + ks * KS_BYTES + b_lane;
+    // software pipeline over stages g = chunk*18 + tap*2 + ks: B two stages ahead in a 3-deep register ring (an L2 hit
+    // costs about one stage of MFMA time, so one-ahead left the matrix pipe waiting), A one stage ahead (2-deep)
+    constexpr int BD = VF_X6_BD, RING = BD + 1, AD = VF_X6_AD;
+    static_assert(18 % RING == 0 && (AD == 0 || AD == 1), "ring indices must repeat per chunk");
+    bf16x8 bring[RING][3][2];
+    bf16x8 aring[2][2][3];
+    const int last_g = nchunks * 18 - 1;
+    auto b_load = [&](bf16x8 (&dst)[3][2], int g) {
+        g = min(g, last_g);
+        const unsigned char* src = Wb + (size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES + b_lane;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const bf16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+    };
+    auto a_load = [&](bf16x8 (&dst)[2][3], const unsigned char* patch, int s) {
+        const int tap = s >> 1, ks = s & 1;
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            int aoff;
+            if (UP2) {
+                const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
+                aoff = (pr * G::PW + pc) * P_LDB + half * 16;
+            } else {
+                aoff = a_base[mi] + (dy * G::PW + dx) * P_LDB;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[mi][pl] = *reinterpret_cast<const bf16x8*>(patch + aoff + pl * 64 + ks * 32);
+        }
     };
 
     f32x16 acc[2][2];
@@ -172,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     patch_load(0);
-    b_load(bc, 0, 0);
+#pragma unroll
+    for (int g = 0; g < BD; ++g) b_load(bring[g], g);
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
     __syncthreads();
@@ -180,44 +234,24 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
         patch_load(min(chunk + 1, nchunks - 1));
+        if (AD) a_load(aring[0], patch, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            int aoff[2];
+        for (int s = 0; s < 18; ++s) {
+            b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
+            if (AD == 0) a_load(aring[s & 1], patch, s);
+            else if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+            // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                if (UP2) {
-                    const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
-                    aoff[mi] = (pr * G::PW + pc) * P_LDB + half * 16;
-                } else {
-                    aoff[mi] = a_base[mi] + (dy * G::PW + dx) * P_LDB;
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks == 0) b_load(bn, chunk * 9 + tap, 1);
-                else b_load(bn, min(chunk * 9 + tap + 1, last_stage), 0);
-                bf16x8 a[2][3];
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mi][pl] = *reinterpret_cast<const bf16x8*>(patch + aoff[mi] + pl * 64 + ks * 32);
-                // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t]], bc[PB[t]][j], acc[mi][j], 0, 0, 0);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bc[pl][j] = bn[pl][j];
-            }
-            if (tap >= 1 && tap <= G::SLOTS) patch_store_slot((chunk + 1) & 1, tap - 1);
+                    for (int j = 0; j < 2; ++j)
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi][PA[t]], bring[s % RING][PB[t]][j], acc[mi][j], 0, 0, 0);
+            // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
+            if ((s & 1) && (s >> 1) >= VF_X6_STORE && (s >> 1) - VF_X6_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X6_STORE);
         }
         __syncthreads();
     }

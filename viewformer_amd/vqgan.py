@@ -176,8 +176,7 @@ class VQGAN:
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
         bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
-        # fp32-equivalent split-bf16 kernel wherever its plain 8x16 tiling applies (the 8x8 pair tiles gain nothing)
-        x6 = (not bf16 and c.wp6 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
+        x6 = not bf16 and c.wp6 is not None and ops.conv3_x6_supported(mode, c.cin, c.cout, Ho, Wo)
         ops.igemm(x, c.wp16 if bf16 else c.wp6 if x6 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode,
                   pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6)
         return out, Ho, Wo
