@@ -29,10 +29,11 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, f32 in)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (measured ceiling 2.1-2.2 PF, profiles/r1_split_bf16_probe.txt)
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(dev, localization: bool, precision: str = 'f32'):
+def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x6'):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -47,7 +48,7 @@ def build_models(dev, localization: bool, precision: str = 'f32'):
     # precision 'mixed': encoder + codebook lookup exact fp32 (bit-exact tokens), transformer dense layers and decoder
     # convolutions on bf16 MFMA (tolerance-bounded logits / pixels) — the split the north star specifies
     arm = 'bf16' if precision == 'mixed' else 'f32'
-    vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm).load_state_dict(vsd).to(dev)
+    vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith).load_state_dict(vsd).to(dev)
     tr = MIGT(mcfg, precision=arm).load_state_dict(msd).to(dev)
     return vq, tr, (vcfg, vsd, mcfg, msd)
 
@@ -142,6 +143,9 @@ def main():
                          "bit-exact) with the transformer's dense layers and the decoder's convolutions on bf16 MFMA, fp32 "
                          "accumulate (logits / pixels within the tolerances stated in tests/test_hip_bf16.py); "
                          "f32: everything exact fp32 (full fp32 parity arm)")
+    ap.add_argument('--conv-arith', choices=['x6', 'f32'], default='x6',
+                    help="how the fp32 3x3 convolutions are evaluated: x6 = fp32-equivalent six-term split-bf16 products on the "
+                         "bf16 matrix pipe (same error vs fp64 as the f32 MFMA, tests/test_hip_x6.py); f32 = native f32 MFMA")
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -158,7 +162,7 @@ def main():
     localization = not args.no_localization
     S, B = args.views, args.batch
 
-    vq, tr, models_cfg = build_models(dev, localization, args.precision)
+    vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith)
     frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
     frames_d = torch.from_numpy(frames).to(dev)
     cams_d = torch.from_numpy(cams).to(dev)
@@ -195,9 +199,12 @@ def main():
                                    '(BASELINE.json configs[1])',
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'localization_pass': localization,
                        'target_view_encoded': True, 'parallelism': f'scene-shard x{world}, no collective',
-                       'precision': ('exact fp32 everywhere' if args.precision == 'f32' else
+                       'precision': ('fp32 everywhere' if args.precision == 'f32' else
                                      'mixed: fp32 encoder + codebook lookup (bit-exact tokens), bf16-MFMA transformer dense '
                                      'layers + decoder convs (fp32 accumulate; tolerances in tests/test_hip_bf16.py)'),
+                       'fp32_conv_arithmetic': ('x6: every fp32 product = 6 exact bf16 partial products (operands split h+m+l) '
+                                                'accumulated in fp32 on the bf16 MFMA pipe; error vs fp64 <= native f32 MFMA '
+                                                '(tests/test_hip_x6.py)' if args.conv_arith == 'x6' else 'native f32 MFMA'),
                        'weights': 'random-init (deterministic generator), full-size VQGAN 67.9M + MIGT 88.4M',
                        'algorithmic_gflop_per_view': round(gf, 1),
                        'whole_path_tflops': round(value * gf / 1e3, 2)},
@@ -210,28 +217,38 @@ def main():
         ms, fl, n, top = prof.summary()
         prof.uninstall()
         fam = fl / (ms * 1e-3) / 1e12
-        # dominant kernel = conv3_halo_kernel at its dominant launch shape: the 128->128 3x3 conv @128x128
-        # (mode 1, M = images*128*128): SURVEY §8(d) per-unit figure 2*9*128*128 FLOP per output pixel x M pixels.
+        # dominant kernel = the halo-tile 3x3 conv at its dominant launch shape: 128->128 @128x128 (mode 1,
+        # M = images*128*128): SURVEY §8(d) per-unit figure 2*9*128*128 FLOP per output pixel x M pixels.
         dom_key, dom = max(((k, v) for k, v in top if k[0] == 1), key=lambda kv: kv[1][0], default=(None, None))
         if dom is None:
             dom_key, dom = top[0]
         d_ms = dom[0] / dom[2]                               # average launch duration (HIP events, launch stream)
-        d_fl = dom[1] / dom[2]                               # algorithmic FLOP per launch
+        d_fl = dom[1] / dom[2]                               # algorithmic (fp32 conv) FLOP per launch
         ach = d_fl / (d_ms * 1e-3) / 1e12
-        # HBM bytes per launch from the PMC passes of profiles/r1_conv_halo_pmc.txt (2*FETCH_SIZE + WRITE_SIZE,
-        # gfx950 correction), measured on a 56-image launch of this shape and scaled by pixels
-        pmc_bytes_per_pixel = (2 * 497520e3 + 458750e3) * 1.024 / (56 * 128 * 128) if dom_key[0] == 1 and dom_key[2:4] == (128, 128) else None
-        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv3_halo_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, '
-                                                        'v_mfma_f32_32x32x2_f32)',
-                            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+        x6 = args.conv_arith == 'x6'
+        # HBM bytes per launch from the PMC passes (profiles/r1_conv_x6_pmc.txt / r1_conv_halo_pmc.txt: 2*FETCH_SIZE +
+        # WRITE_SIZE with the gfx950 unit correction), measured on a 56-image launch of this shape, scaled by pixels
+        fetch_kb, write_kb = (530840e3, 458750e3) if x6 else (497520e3, 458750e3)
+        is_dom_shape = dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
+        pmc_bytes_per_pixel = (2 * fetch_kb + write_kb) * 1.024 / (56 * 128 * 128) if is_dom_shape else None
+        # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6
+        peak = BF16_MFMA_PEAK_TFLOPS / 6 if x6 else F32_MFMA_PEAK_TFLOPS
+        line['roofline'] = {'bound': 'mfma',
+                            'kernel': ('conv3_halo_x6_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 6x v_mfma_f32_32x32x16_bf16 '
+                                       'per fp32 product)' if x6 else
+                                       'conv3_halo_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, v_mfma_f32_32x32x2_f32)'),
+                            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                            'frac': round(ach / peak, 4),
+                            'peak_note': ('algorithmic fp32 TFLOP/s; peak = dense bf16 MFMA peak 2500 / 6 partial products. Executed '
+                                          f'bf16 rate {round(6 * ach, 1)} TFLOP/s; the native f32 MFMA peak is {F32_MFMA_PEAK_TFLOPS}'
+                                          if x6 else 'dense f32 MFMA peak'),
                             'traffic': (round(pmc_bytes_per_pixel * dom_key[1]) if pmc_bytes_per_pixel else None),
                             'traffic_unit': 'bytes/launch (PMC, scaled from the 56-image profile)',
                             'launch_shape_mode_M_Cin_Cout_batch': list(dom_key), 'avg_launch_ms': round(d_ms, 4),
                             'algorithmic_gflop_per_launch': round(d_fl / 1e9, 1),
                             'algorithmic_bytes_per_launch': dom_key[1] * (dom_key[2] + 2 * dom_key[3]) * 4,
-                            'family': {'kernels': 'igemm_f32 + conv3_halo (every conv/dense launch of the step)',
-                                       'achieved': round(fam, 2), 'frac': round(fam / F32_MFMA_PEAK_TFLOPS, 4),
+                            'family': {'kernels': 'every conv/dense launch of the step (conv3_halo_x6/_bf16/_f32, igemm_f32, gemm_bf16)',
+                                       'achieved': round(fam, 2),
                                        'launches_per_step': n, 'kernel_ms_per_step': round(ms, 3),
                                        'algorithmic_gflop_per_step': round(fl / 1e9, 1)},
                             'top_shapes_mode_M_Cin_Cout_batch': [

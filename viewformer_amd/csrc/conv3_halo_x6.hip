@@ -20,7 +20,7 @@
 
 // tuning knobs (tools/variants.sh builds side-by-side libraries with different values for A/B timing on the GPU)
 #ifndef VF_X6_BD
-#define VF_X6_BD 5        // weight fragments are fetched this many stages ahead (register ring of BD + 1);
+#define VF_X6_BD 2        // weight fragments are fetched this many stages ahead (register ring of BD + 1);
                           // measured 1/2/5: 192/198/204 TF @128^2 and 98/128/158 TF on the 8x8 pair tiles (L2-miss bound)
 #endif
 #ifndef VF_X6_AD
@@ -28,6 +28,10 @@
 #endif
 #ifndef VF_X6_STORE
 #define VF_X6_STORE 0     // 0: staging slot q is transformed+parked in stage 2q+1; 1: in stage 2q+3
+#endif
+#ifndef VF_X6_SB
+#define VF_X6_SB 1        // 1: __builtin_amdgcn_sched_barrier(0) at every stage boundary (pins the prefetch distance: the
+                          // scheduler otherwise sinks the ring loads next to their uses); 2: also between loads and MFMAs
 #endif
 #ifndef VF_X6_PRECISE_SWISH
 #define VF_X6_PRECISE_SWISH 0
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
             b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
             if (AD == 0) a_load(aring[s & 1], patch, s);
             else if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+            if (VF_X6_SB == 2) __builtin_amdgcn_sched_barrier(0);      // loads are issued before this stage's MFMAs
             // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -251,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
                     for (int j = 0; j < 2; ++j)
                         acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi][PA[t]], bring[s % RING][PB[t]][j], acc[mi][j], 0, 0, 0);
             // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
+            if (VF_X6_SB == 1) __builtin_amdgcn_sched_barrier(0);
             if ((s & 1) && (s >> 1) >= VF_X6_STORE && (s >> 1) - VF_X6_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X6_STORE);
+            if (VF_X6_SB == 2) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
