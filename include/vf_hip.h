@@ -71,6 +71,13 @@ typedef struct vf_igemm_args {
     int32_t lda, ldc, ldr;   /* row strides in floats (conv: lda is ignored, = Cin) */
     int32_t batch;           /* >=1: independent problems, pointer strides below (floats) */
     int64_t stride_x, stride_w, stride_out, stride_res;
+    /* optional fused GroupNorm statistics of the OUTPUT (vf_conv3_halo_x6 / vf_conv3_halo_bf16 only, others refuse a
+     * non-NULL pointer): per-(image, slot, group) partial {sum, sum of squares} of the stored values, laid out
+     * [Nimg][gn_slots][32][2] exactly like vf_groupnorm_stats_f32's workspace, to be reduced by
+     * vf_groupnorm_finalize_f32.  gn_slots must equal vf_conv3_halo_gn_slots(Hout, Wout). */
+    float* gn_part;
+    int32_t gn_slots;
+    int32_t reserved0;
 } vf_igemm_args;
 
 /* floats needed for the packed form of a [taps][K][N] weight (K,N padded to the tile) */
@@ -98,6 +105,10 @@ int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* 
 size_t vf_groupnorm_workspace_bytes(int n_img, int HW, int C);
 int vf_groupnorm_stats_f32(const float* x, const float* gamma, int n_img, int HW, int C, int groups, float eps,
                            float* mean_c, float* scale_c, void* ws, void* stream);
+/* second half of vf_groupnorm_stats_f32 alone: reduce [Nimg][nslots][groups][2] partial {sum, sumsq} (fp64, fixed order)
+ * written by a producer's fused epilogue (vf_igemm_args.gn_part) into mean_c / scale_c.  The activation is not re-read. */
+int vf_groupnorm_finalize_f32(const float* part, const float* gamma, int n_img, int HW, int C, int groups, int nslots,
+                              float eps, float* mean_c, float* scale_c, void* stream);
 int vf_groupnorm_apply_f32(const float* x, const float* mean_c, const float* scale_c, const float* beta,
                            float* out, int n_img, int HW, int C, int swish, void* stream);
 
@@ -187,6 +198,8 @@ int vf_conv3_halo_bf16(const vf_igemm_args* args /* host */, void* stream);
  * call sites as vf_igemm_f32's 3x3 modes (torch.nn.Conv2d in vqgan_th.py:23-32,60-70,197,249).
  * Same vf_igemm_args and shape rules as vf_conv3_halo_bf16; w_packed points to the 3-plane bf16 packing.
  * ------------------------------------------------------------------------------------- */
+/* partial-statistics slots per image the halo kernels write for an Hout x Wout map (2 per 8x16 tile; 2 for an 8x8 map) */
+int vf_conv3_halo_gn_slots(int Hout, int Wout);
 size_t vf_conv3_x6_packed_elems(int Cin, int Cout);       /* number of bf16 elements (3 planes) */
 int vf_conv3_x6_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
 int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);

@@ -74,3 +74,42 @@ def test_x6_refuses_unsupported_shapes(dev):
     with pytest.raises(ops._lib.VfError):        # W % 16 != 0: refused, never rerouted
         ops.igemm(x, w, 2 * 16 * 12, 64, 128, out, mode=ops.MODE_CONV3_S1, Hin=16, Win=12, Hout=16, Wout=12, x6=True)
     assert not ops.conv3_x6_supported(ops.MODE_CONV3_S2PAD, 128, 128, 64, 64)
+
+
+@pytest.mark.parametrize('kernel', ['x6', 'bf16'])
+@pytest.mark.parametrize('mode,cin,cout,H,n', [('s1', 64, 128, 16, 2), ('up', 32, 256, 8, 2), ('s1', 64, 512, 8, 3), ('s1', 32, 128, 8, 4),
+                                                ('s1', 32, 1024, 32, 1)])
+def test_fused_groupnorm_partials_match_the_standalone_statistics(dev, kernel, mode, cin, cout, H, n):
+    """the conv epilogue's partial {sum, sumsq} -> finalize == groupnorm_stats of the stored output (pair tiles with an odd
+    image count included: the duplicated half must not be counted)"""
+    from viewformer_amd import ops
+    x = (_rand((n, H, H, cin), 31) * 1.3 + 0.1).to(dev)
+    w, b = _rand((cout, cin, 3, 3), 32, 0.08).to(dev), _rand((cout,), 33).to(dev)
+    gamma = (_rand((cout,), 34) * 0.3 + 1).to(dev)
+    m, Ho = (ops.MODE_CONV3_S1, H) if mode == 's1' else (ops.MODE_CONV3_UP2, 2 * H)
+    res = _rand((n * Ho * Ho, cout), 35).to(dev)
+    out = torch.empty((n * Ho * Ho, cout), device=dev)
+    part = ops.new_gn_part(n, Ho, Ho, dev)
+    part.fill_(float('nan'))                              # every slot must be written
+    wp = ops.pack_conv3_x6(w) if kernel == 'x6' else ops.pack_conv3_bf16(w)
+    ops.igemm(x, wp, n * Ho * Ho, cin, cout, out, bias=b, res=res, mode=m, Hin=H, Win=H, Hout=Ho, Wout=Ho,
+              x6=kernel == 'x6', bf16=kernel == 'bf16', gn_part=part)
+    assert torch.isfinite(part).all()
+    mean_f, scale_f = ops.groupnorm_finalize(part, gamma, n, Ho * Ho, cout)
+    mean_s, scale_s = ops.groupnorm_stats(out, gamma, n, Ho * Ho, cout)
+    assert (mean_f - mean_s).abs().max().item() < 2e-6 * (1 + mean_s.abs().max().item())
+    assert ((scale_f - scale_s).abs() / scale_s.abs()).max().item() < 5e-6
+    # and the stored output is the same with and without the statistics
+    out2 = torch.empty_like(out)
+    ops.igemm(x, wp, n * Ho * Ho, cin, cout, out2, bias=b, res=res, mode=m, Hin=H, Win=H, Hout=Ho, Wout=Ho,
+              x6=kernel == 'x6', bf16=kernel == 'bf16')
+    assert torch.equal(out, out2)
+
+
+def test_fused_statistics_are_refused_by_the_generic_kernels(dev):
+    from viewformer_amd import ops
+    x = torch.zeros((256, 64), device=dev)
+    out = torch.empty((256, 128), device=dev)
+    part = torch.zeros((1, 2, 32, 2), device=dev)
+    with pytest.raises(ops._lib.VfError):
+        ops.igemm(x, ops.pack_dense_kn(torch.zeros((64, 128), device=dev)), 256, 64, 128, out, gn_part=part)

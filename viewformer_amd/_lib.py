@@ -23,6 +23,7 @@ class VfIgemmArgs(ctypes.Structure):
         ('Hin', c_int32), ('Win', c_int32), ('Hout', c_int32), ('Wout', c_int32),
         ('lda', c_int32), ('ldc', c_int32), ('ldr', c_int32), ('batch', c_int32),
         ('stride_x', c_int64), ('stride_w', c_int64), ('stride_out', c_int64), ('stride_res', c_int64),
+        ('gn_part', c_void_p), ('gn_slots', c_int32), ('reserved0', c_int32),
     ]
 
 
@@ -37,6 +38,8 @@ EXPORTS = {
     'vf_conv_in_u8_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'vf_groupnorm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vf_groupnorm_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
+    'vf_groupnorm_finalize_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P]),
+    'vf_conv3_halo_gn_slots': (c_int, [c_int, c_int]),
     'vf_groupnorm_apply_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'vf_vq_packed_floats': (c_size_t, [c_int, c_int]),
     'vf_vq_pack_codebook_f32': (c_int, [P, P, c_int, c_int, P]),

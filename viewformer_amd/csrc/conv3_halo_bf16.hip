@@ -6,9 +6,7 @@
 // arm trades 2^-9 operand rounding for the 16x faster matrix pipe; the encoder never uses it.
 // Patch pixel stride 80 B (64 B of bf16 + 16 B pad): 16 consecutive patch pixels -> 16 distinct 16-byte LDS
 // slots for every ds_read_b128 lane group, for every tap shift.
-#include "vf_common.h"
-#include "epilogue.h"
-#include "../../include/vf_hip.h"
+#include "halo_common.h"
 
 namespace {
 
@@ -20,11 +18,6 @@ constexpr int P_LDB = 80;           // bytes per patch pixel in LDS
 constexpr int TH = 8, TW = 16;
 constexpr int BN = 128;
 constexpr int TAP_BYTES = CK * BN * 2;   // one (chunk, tap, n-block) weight tile: 8 KB
-
-__host__ __device__ constexpr int perm_row(int i) { return (i < 4) ? 0 : (i < 12) ? 1 : (i < 16) ? 0 : (i < 20) ? 1 : (i < 28) ? 0 : 1; }
-__host__ __device__ constexpr int perm_px(int i) {
-    return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
-}
 
 // PAIR: one 8x16 tile = two 8x8 images side by side, each with its own 10x10 halo patch (patch width 20)
 template <bool UP2, bool PAIR = false>
@@ -123,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
         *reinterpret_cast<bf16x4*>(dst + s_lds[q]) = o;
     };
 
-    const int trow = perm_row(l31), tpx = perm_px(l31);
+    const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
     int a_base[2], a_r[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -196,28 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
         __syncthreads();
     }
 
-    float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
-    const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int py = y0 + wave_m * 4 + mi * 2;
-            auto pix = [&](int r) {
-                const int i0 = (r & 3) + 8 * (r >> 2);
-                const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
-                const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
-                if (PAIR) return (ppx >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx & 7);
-                return (py + prow) * p.Wout + x0 + ppx;
-            };
-            auto oo = [&](int r) { return pix(r) * p.ldc; };
-            auto ro = [&](int r) { return pix(r) * p.ldr; };
-            if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
-            else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
-        }
-    }
+    vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
 __global__ void pack_conv_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks) {
@@ -290,6 +262,7 @@ int vf_conv3_halo_bf16(const vf_igemm_args* args, void* stream) {
     if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
     if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+    if (int st = vf_halo_gn_check(a)) return st;
     hipStream_t s = (hipStream_t)stream;
     if (pair) return dispatch_pro<false, true>(a, s);
     return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);

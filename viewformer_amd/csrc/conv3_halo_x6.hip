@@ -14,9 +14,7 @@
 // time into three fragment-packed bf16 planes and streamed L2 -> VGPR one (tap, k-step) stage ahead.
 // Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,197,249) with
 // GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
-#include "vf_common.h"
-#include "epilogue.h"
-#include "../../include/vf_hip.h"
+#include "halo_common.h"
 
 // tuning knobs (tools/variants.sh builds side-by-side libraries with different values for A/B timing on the GPU)
 #ifndef VF_X6_BD
@@ -49,11 +47,6 @@ constexpr int BN = 128;
 constexpr int PLANE_BYTES = 2 * BN * 16;      // one (k-step, plane): [half(2)][n(128)][8 bf16] = 4 KB
 constexpr int KS_BYTES = 3 * PLANE_BYTES;     // one k-step of 16 channels: 3 planes
 constexpr int TAP_BYTES = 2 * KS_BYTES;       // one (chunk, tap, n-block) weight tile: 24 KB
-
-__host__ __device__ constexpr int perm_row(int i) { return (i < 4) ? 0 : (i < 12) ? 1 : (i < 16) ? 0 : (i < 20) ? 1 : (i < 28) ? 0 : 1; }
-__host__ __device__ constexpr int perm_px(int i) {
-    return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
-}
 
 // PAIR: one 8x16 tile = two 8x8 images side by side, each with its own 10x10 halo patch (patch width 20)
 template <bool UP2, bool PAIR = false>
@@ -174,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
         *reinterpret_cast<bf16x4*>(dst + 128) = ol;
     };
 
-    const int trow = perm_row(l31), tpx = perm_px(l31);
+    const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
     int a_base[2], a_r[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -263,28 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
         __syncthreads();
     }
 
-    float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
-    const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int py = y0 + wave_m * 4 + mi * 2;
-            auto pix = [&](int r) {
-                const int i0 = (r & 3) + 8 * (r >> 2);
-                const int prow = half ? perm_row(i0 + 4) : perm_row(i0);
-                const int ppx = half ? perm_px(i0 + 4) : perm_px(i0);
-                if (PAIR) return (ppx >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx & 7);
-                return (py + prow) * p.Wout + x0 + ppx;
-            };
-            auto oo = [&](int r) { return pix(r) * p.ldc; };
-            auto ro = [&](int r) { return pix(r) * p.ldr; };
-            if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
-            else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
-        }
-    }
+    vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
 __global__ void pack_conv_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks) {
@@ -334,6 +306,8 @@ int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
 
 extern "C" {
 
+int vf_conv3_halo_gn_slots(int Hout, int Wout) { return vf_halo_gn_slots(Hout, Wout); }
+
 size_t vf_conv3_x6_packed_elems(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
     return (size_t)((Cin + CK - 1) / CK) * 9 * ((Cout + BN - 1) / BN) * CK * BN * 3;
@@ -362,6 +336,7 @@ int vf_conv3_halo_x6(const vf_igemm_args* args, void* stream) {
     if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
     if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+    if (int st = vf_halo_gn_check(a)) return st;
     hipStream_t s = (hipStream_t)stream;
     if (pair) return dispatch_pro<false, true>(a, s);
     return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);

@@ -62,3 +62,44 @@ __device__ __forceinline__ void vf_store_tile_ragged(const f32x16& acc, float bi
         if (row < rows_left) out[(long long)row * ldc] = v[r];
     }
 }
+
+// ---- fused GroupNorm statistics of the stored tile -------------------------------------------------------------
+// Same tile store as vf_store_tile<0, HAS_RES>, additionally accumulating the sum and the sum of squares of the values it
+// stores into s[sel(r)] / q[sel(r)] (sel(r) in {0, 1}: which of the two images of a pair tile row r belongs to; always 0
+// for ordinary tiles).
+template <bool HAS_RES, typename OffOut, typename OffRes, typename Sel>
+__device__ __forceinline__ void vf_store_tile_stats(const f32x16& acc, float bias, float* __restrict__ out,
+                                                    const float* __restrict__ res, OffOut off_out, OffRes off_res, Sel sel,
+                                                    float (&s)[2], float (&q)[2]) {
+    float v[16];
+    if (HAS_RES) {
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rr[r] = res[off_res(r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias + rr[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = sel(r);
+        s[k] += v[r];
+        q[k] += v[r] * v[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[off_out(r)] = v[r];
+}
+
+// Reduce a lane's per-column (s, q) over the cg adjacent columns of a GroupNorm group (cg = C/32 in {4, 8, 16, 32},
+// columns = the 32 lanes of a half-wave) and over the two half-waves (the other 16 rows of the tile); the first lane of each
+// group then owns the group's partial of this wave's 64 x 32 sub-tile.  Fixed shuffle tree -> deterministic.
+__device__ __forceinline__ void vf_gn_group_reduce(float& s, float& q, int cg) {
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    for (int o = 1; o < cg; o <<= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+}

@@ -195,6 +195,7 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
+    if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
     if (a.mode != VF_MODE_GEMM || a.pro_mean) return VF_ERR_UNSUPPORTED;
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;

@@ -151,6 +151,16 @@ int vf_groupnorm_stats_f32(const float* x, const float* gamma, int n_img, int HW
     return vf_last_status();
 }
 
+int vf_groupnorm_finalize_f32(const float* part, const float* gamma, int n_img, int HW, int C, int groups, int nslots,
+                              float eps, float* mean_c, float* scale_c, void* stream) {
+    if (!part || !gamma || !mean_c || !scale_c || n_img <= 0 || HW <= 0 || nslots <= 0) return VF_ERR_BAD_ARG;
+    if (C <= 0 || groups <= 0 || C % groups != 0) return VF_ERR_UNSUPPORTED;
+    const int n = n_img * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, part, gamma, mean_c,
+                       scale_c, n_img, HW, C, groups, nslots, eps);
+    return vf_last_status();
+}
+
 int vf_groupnorm_apply_f32(const float* x, const float* mean_c, const float* scale_c, const float* beta, float* out,
                            int n_img, int HW, int C, int swish, void* stream) {
     if (!x || !mean_c || !scale_c || !beta || !out || n_img <= 0 || HW <= 0 || C <= 0 || (C & 3)) return VF_ERR_BAD_ARG;

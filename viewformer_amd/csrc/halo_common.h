@@ -1,0 +1,82 @@
+// Shared by the halo-tile convolution kernels (conv3_halo_x6.hip, conv3_halo_bf16.hip): the MFMA-row -> pixel permutation and
+// the epilogue (bias, residual, store, optional fused GroupNorm partial statistics of the stored values).
+#pragma once
+#include "vf_common.h"
+#include "epilogue.h"
+#include "../../include/vf_hip.h"
+
+// MFMA row i (0..31) -> (tile row 0/1, pixel 0..15) such that each hardware ds_read_b128 16-lane group
+// ({0-3,12-15,20-27} / {4-11,16-19,28-31}) covers 16 CONSECUTIVE patch pixels
+__host__ __device__ constexpr int vf_perm_row(int i) { return (i < 4) ? 0 : (i < 12) ? 1 : (i < 16) ? 0 : (i < 20) ? 1 : (i < 28) ? 0 : 1; }
+__host__ __device__ constexpr int vf_perm_px(int i) {
+    return (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
+}
+
+// partial-statistics slots per image: one per (8x16 tile, wave row-half); an 8x8 map (pair tiles) has 2
+static inline int vf_halo_gn_slots(int Hout, int Wout) {
+    if (Hout == 8 && Wout == 8) return 2;
+    if (Hout <= 0 || Wout <= 0 || Hout % 8 || Wout % 16) return 0;
+    return (Hout / 8) * (Wout / 16) * 2;
+}
+
+// host-side check of the fused-statistics request (0 = ok)
+static inline int vf_halo_gn_check(const vf_igemm_args& a) {
+    if (!a.gn_part) return VF_OK;
+    const int cg = a.Cout / 32;
+    if (a.Cout % 32 || !(cg == 4 || cg == 8 || cg == 16 || cg == 32)) return VF_ERR_UNSUPPORTED;
+    if (a.gn_slots != vf_halo_gn_slots(a.Hout, a.Wout)) return VF_ERR_BAD_ARG;
+    return VF_OK;
+}
+
+// One workgroup's epilogue: wave (wave_m, wave_n) owns rows [wave_m*4, +4) x 16 px of the 8x16 tile and 64 output channels,
+// as acc[mi][j] = (2 tile rows) x (32 channels).  PAIR: the tile is two 8x8 images (img, img1) side by side.
+template <bool PAIR>
+__device__ __forceinline__ void vf_halo_epilogue(const vf_igemm_args& p, const f32x16 (&acc)[2][2], int img, int img1, int y0,
+                                                 int x0, int tile_slot, int nblk, int wave_m, int wave_n, int half, int l31) {
+    constexpr int BN = 128;
+    float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
+    const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
+    const bool stats = p.gn_part != nullptr;
+    const int cg = p.Cout >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int py = y0 + wave_m * 4 + mi * 2;
+            auto ppx = [&](int r) { const int i0 = (r & 3) + 8 * (r >> 2); return half ? vf_perm_px(i0 + 4) : vf_perm_px(i0); };
+            auto pix = [&](int r) {
+                const int i0 = (r & 3) + 8 * (r >> 2);
+                const int prow = half ? vf_perm_row(i0 + 4) : vf_perm_row(i0);
+                if (PAIR) return (ppx(r) >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx(r) & 7);
+                return (py + prow) * p.Wout + x0 + ppx(r);
+            };
+            auto oo = [&](int r) { return pix(r) * p.ldc; };
+            auto ro = [&](int r) { return pix(r) * p.ldr; };
+            auto sel = [&](int r) { return PAIR ? (ppx(r) >> 3) : 0; };
+            if (stats) {
+                if (Res) vf_store_tile_stats<true>(acc[mi][j], bias, Out + n, Res + n, oo, ro, sel, s, q);
+                else vf_store_tile_stats<false>(acc[mi][j], bias, Out + n, Res, oo, ro, sel, s, q);
+            } else {
+                if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
+                else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
+            }
+        }
+        if (stats) {
+#pragma unroll
+            for (int k = 0; k < (PAIR ? 2 : 1); ++k) {
+                float ss = s[k], qq = q[k];
+                vf_gn_group_reduce(ss, qq, cg);
+                // an odd image count duplicates the last image into the second half of its pair tile: that half is not a new image
+                if (half == 0 && (l31 & (cg - 1)) == 0 && (k == 0 || img1 != img)) {
+                    const int im = k ? img1 : img;
+                    float* dst = p.gn_part + ((((size_t)im * p.gn_slots) + tile_slot + wave_m) * 32 + n / cg) * 2;
+                    dst[0] = ss;
+                    dst[1] = qq;
+                }
+            }
+        }
+    }
+}

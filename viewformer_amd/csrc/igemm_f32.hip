@@ -311,7 +311,7 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 
 extern "C" {
 
-int vf_abi_version(void) { return 4; }
+int vf_abi_version(void) { return 5; }
 const char* vf_build_arch(void) { return "gfx950"; }
 
 size_t vf_igemm_packed_floats(int K, int N, int taps) {
@@ -332,6 +332,7 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
+    if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.mode < VF_MODE_GEMM || a.mode > VF_MODE_CONV3_UP2) return VF_ERR_BAD_ARG;
     if (a.mode != VF_MODE_GEMM) {

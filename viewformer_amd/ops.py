@@ -126,11 +126,13 @@ def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
 
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
-          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False):
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
-    split-bf16 kernel (vf_conv3_halo_x6)."""
+    split-bf16 kernel (vf_conv3_halo_x6).
+    ``gn_part``: fp32 [Nimg][halo_gn_slots(Hout, Wout)][32][2] buffer that receives the GroupNorm partial statistics of the
+    output (halo kernels only; reduce with groupnorm_finalize)."""
     lib = _lib.load()
     a = VfIgemmArgs()
     a.x = x.data_ptr()
@@ -151,6 +153,9 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     a.ldr = (Cout if ldr is None else ldr)
     a.batch = batch
     a.stride_x, a.stride_w, a.stride_out, a.stride_res = stride_x, stride_w, stride_out, stride_res
+    if gn_part is not None:
+        a.gn_part = _f32(gn_part).data_ptr()
+        a.gn_slots = gn_part.shape[1]
     for t in (x, out, bias, res):
         if t is not None:
             _f32(t)
@@ -192,6 +197,26 @@ def groupnorm_stats(x, gamma, n_img, HW, C, groups=32, eps=1e-6):
     ws = torch.empty(int(lib.vf_groupnorm_workspace_bytes(n_img, HW, C)), dtype=torch.uint8, device=x.device)
     check(lib.vf_groupnorm_stats_f32(_p(_f32(x)), _p(_f32(gamma)), n_img, HW, C, groups, eps, _p(mean_c), _p(scale_c),
                                      _p(ws), _stream()), 'vf_groupnorm_stats_f32')
+    return mean_c, scale_c
+
+
+def halo_gn_slots(Hout, Wout):
+    """partial-statistics slots per image the halo conv kernels write for an Hout x Wout output (0 = not a halo shape)"""
+    return int(_lib.load().vf_conv3_halo_gn_slots(Hout, Wout))
+
+
+def new_gn_part(n_img, Hout, Wout, device):
+    """buffer for igemm(..., gn_part=...): every slot is written by the producing conv, no initialisation needed"""
+    return torch.empty((n_img, halo_gn_slots(Hout, Wout), 32, 2), dtype=torch.float32, device=device)
+
+
+def groupnorm_finalize(part, gamma, n_img, HW, C, groups=32, eps=1e-6):
+    """second half of groupnorm_stats from partials written by a conv's fused epilogue (the activation is not re-read)"""
+    lib = _lib.load()
+    mean_c = torch.empty((n_img, C), dtype=torch.float32, device=part.device)
+    scale_c = torch.empty((n_img, C), dtype=torch.float32, device=part.device)
+    check(lib.vf_groupnorm_finalize_f32(_p(_f32(part)), _p(_f32(gamma)), n_img, HW, C, groups, part.shape[1], eps,
+                                        _p(mean_c), _p(scale_c), _stream()), 'vf_groupnorm_finalize_f32')
     return mean_c, scale_c
 
 
