@@ -203,6 +203,13 @@ int vf_conv3_halo_gn_slots(int Hout, int Wout);
 size_t vf_conv3_x6_packed_elems(int Cin, int Cout);       /* number of bf16 elements (3 planes) */
 int vf_conv3_x6_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
 int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);
+/* dense / 1x1 sibling: VF_MODE_GEMM, Cin % 64 == 0, batch == 1, optional GroupNorm(+swish) prologue, bias / exact-erf GELU /
+ * residual epilogue.  Replaces the same call sites as vf_igemm_f32's GEMM mode (Conv1D.call migt.py:89-96,
+ * SharedEmbeddings._linear :51-56, the 1x1 convolutions of vqgan_th.py:72-76,99-118,332-333).
+ * pack: element (k, n) of the weight at src[k*sk + n*sn] (Conv1D [K][N]: sk=N, sn=1; [N][K]: sk=1, sn=K). */
+size_t vf_gemm_x6_packed_elems(int K, int N);             /* number of bf16 elements (3 planes) */
+int vf_gemm_x6_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, void* stream);
+int vf_gemm_x6(const vf_igemm_args* args /* host */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).

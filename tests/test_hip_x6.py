@@ -113,3 +113,66 @@ def test_fused_statistics_are_refused_by_the_generic_kernels(dev):
     part = torch.zeros((1, 2, 32, 2), device=dev)
     with pytest.raises(ops._lib.VfError):
         ops.igemm(x, ops.pack_dense_kn(torch.zeros((64, 128), device=dev)), 256, 64, 128, out, gn_part=part)
+
+
+@pytest.mark.parametrize('M,K,N,epi,res', [(128, 64, 128, 0, False), (300, 128, 64, 0, True), (448, 768, 2304, 0, False),
+                                           (1000, 3072, 768, 0, True), (70, 256, 1024, 1, True), (513, 768, 3072, 1, False)])
+def test_gemm_x6_is_fp32_equivalent(dev, M, K, N, epi, res):
+    from viewformer_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((K, N), 2, 0.1), _rand((N,), 3), _rand((M, N), 4)
+    pre = x.double() @ w.double() + b.double()
+    ref = F.gelu(pre) if epi else pre
+    mag = x.double().abs() @ w.double().abs() + b.double().abs()
+    if res:
+        ref, mag = ref + r.double(), mag + r.double().abs()
+    kw = dict(bias=b.to(dev), res=r.to(dev) if res else None, epilogue=ops.EPI_GELU if epi else ops.EPI_NONE)
+    o6, o32, o6t = (torch.empty((M, N), device=dev) for _ in range(3))
+    ops.igemm(x.to(dev), ops.pack_dense_kn_x6(w.to(dev)), M, K, N, o6, x6=True, **kw)
+    ops.igemm(x.to(dev), ops.pack_dense_nk_x6(w.t().contiguous().to(dev)), M, K, N, o6t, x6=True, **kw)
+    ops.igemm(x.to(dev), ops.pack_dense_kn(w.to(dev)), M, K, N, o32, **kw)
+    assert torch.equal(o6, o6t)                       # both packings describe the same matrix
+    (mx6, rms6), (mx32, rms32) = _err(o6, ref, mag), _err(o32, ref, mag)
+    print(f'gemm {M}x{K}x{N} epi={epi}: x6 max {mx6:.2e} rms {rms6:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
+    assert mx6 < 6e-7 and rms6 < 1.25 * rms32 + 1e-9
+    with pytest.raises(ops._lib.VfError):             # K % 64 != 0 is refused, never rerouted
+        ops.igemm(x[:, :32].contiguous().to(dev), ops.pack_dense_kn_x6(w[:32].contiguous().to(dev)), M, 32, N, o6, x6=True)
+
+
+def test_gemm_x6_groupnorm_prologue(dev):
+    """1x1 convolution with the fused GroupNorm-apply (AttnBlock q/k/v: no swish; and with swish)"""
+    from viewformer_amd import ops
+    n, HW, C, N = 3, 64, 256, 768
+    x = (_rand((n * HW, C), 41) * 1.5 + 0.3).to(dev)
+    gamma, beta = (_rand((C,), 42) * 0.3 + 1).to(dev), (_rand((C,), 43) * 0.2).to(dev)
+    w, b = _rand((C, N), 44, 0.05).to(dev), _rand((N,), 45).to(dev)
+    mean_c, scale_c = ops.groupnorm_stats(x, gamma, n, HW, C)
+    for swish in (False, True):
+        o6, o32 = torch.empty((n * HW, N), device=dev), torch.empty((n * HW, N), device=dev)
+        kw = dict(bias=b, pro=(mean_c, scale_c, beta), pro_swish=swish, pro_rows_per_img=HW)
+        ops.igemm(x, ops.pack_dense_kn_x6(w), n * HW, C, N, o6, x6=True, **kw)
+        ops.igemm(x, ops.pack_dense_kn(w), n * HW, C, N, o32, **kw)
+        assert (o6 - o32).abs().max().item() < 2e-5 * o32.abs().max().item()
+
+
+def test_migt_logits_x6_vs_native_f32(dev):
+    """full-size transformer: the x6 dense arm is as close to the fp64 oracle as the native f32-MFMA arm"""
+    from oracle import migt_oracle as mg
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    cfg = MIGTConfig(sequence_size=4, localization_weight='1', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=0)
+    g = np.random.Generator(np.random.PCG64(17))
+    B, S = 2, 4
+    codes = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 6)
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], 1024)], 1)
+    ref = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)['logits'][:, -1]
+    errs = {}
+    for arith in ('f32', 'x6'):
+        m = MIGT(cfg, dense_arith=arith).load_state_dict(sd).to(dev)
+        lg, _ = m.generate_and_localize(codes.to(dev), cams.to(dev))
+        errs[arith] = ((lg.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    print(f'logit error vs fp64 (relative to max |logit|): native f32 {errs["f32"]:.2e}, x6 {errs["x6"]:.2e}')
+    assert errs['x6'] < 1e-4 and errs['x6'] < 2.0 * errs['f32'] + 1e-6

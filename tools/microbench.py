@@ -47,13 +47,14 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False):
     print(f'conv3x3{" x6" if x6 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 
 
-def gemm(M=7168, K=768, N=3072, epi=0):
+def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
     x = torch.randn(M, K, device=dev)
-    wp = ops.pack_dense_kn(torch.randn(K, N, device=dev) * 0.02)
+    w = torch.randn(K, N, device=dev) * 0.02
+    wp = {'f32': ops.pack_dense_kn, 'x6': ops.pack_dense_kn_x6, 'bf16': ops.pack_dense_kn_bf16}[arith](w)
     b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
-    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi))
-    print(f'gemm {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
+    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi, x6=arith == 'x6', bf16=arith == 'bf16'))
+    print(f'gemm[{arith}] {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
 
 
 def vq(M=64 * 448):
@@ -91,7 +92,10 @@ def convin(n_img=224, H=128, C=128):
     print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
-ALL = dict(convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
+ALL = dict(gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
+           gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
+           gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
+           convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),

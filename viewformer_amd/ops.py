@@ -117,6 +117,27 @@ def pack_conv3_x6(w_oihw):
     return out
 
 
+def pack_dense_kn_x6(w):
+    """Conv1D weight [nx][nf] -> 3-plane split packing for vf_gemm_x6"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    k, n = w.shape
+    out = torch.empty(int(lib.vf_gemm_x6_packed_elems(k, n)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_gemm_x6_pack(_p(w), _p(out), k, n, n, 1, _stream()), 'vf_gemm_x6_pack')
+    return out
+
+
+def pack_dense_nk_x6(w, n_rows=None):
+    """transposed weight [N][K] (x @ W^T; tied LM head, 1x1 conv [Cout][Cin]) -> 3-plane split packing"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    n, k = w.shape
+    n = n if n_rows is None else n_rows
+    out = torch.empty(int(lib.vf_gemm_x6_packed_elems(k, n)), dtype=torch.bfloat16, device=w.device)
+    check(lib.vf_gemm_x6_pack(_p(w), _p(out), k, n, 1, k, _stream()), 'vf_gemm_x6_pack')
+    return out
+
+
 def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
     """shape rules of vf_conv3_halo_x6 (host-side mirror so callers can pick the packing up front)"""
     if mode not in (MODE_CONV3_S1, MODE_CONV3_UP2) or Cin % 32 or Cout % 128:
@@ -161,7 +182,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
             _f32(t)
     if x6:
         _chk(w_packed, torch.bfloat16, 'w_packed')
-        check(lib.vf_conv3_halo_x6(ctypes.byref(a), _stream()), 'vf_conv3_halo_x6')
+        if mode == MODE_GEMM:
+            check(lib.vf_gemm_x6(ctypes.byref(a), _stream()), 'vf_gemm_x6')
+        else:
+            check(lib.vf_conv3_halo_x6(ctypes.byref(a), _stream()), 'vf_conv3_halo_x6')
         return out
     if bf16:
         _chk(w_packed, torch.bfloat16, 'w_packed')

@@ -126,6 +126,11 @@ class MIGTTrainer:
 
     def repack(self):
         m, c = self.model, self.cfg
+        # training runs the native f32-MFMA packings, which are rewritten in place after every update; drop the model's
+        # split-bf16 (x6) inference packings so that no forward can read stale weights
+        m._lm_head6 = None
+        for dn in m._dense.values():
+            dn.wp6 = None
         nE, d = c.n_embeddings, c.d_model
         for name, dn in m._dense.items():
             if dn.k % 32 == 0:

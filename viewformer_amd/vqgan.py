@@ -130,6 +130,8 @@ class VQGAN:
             c.wp6 = None
             if self.conv_arith == 'x6' and c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                 c.wp6 = ops.pack_conv3_x6(w)
+            elif self.conv_arith == 'x6' and c.k == 1 and c.cin % 64 == 0 and c.cout >= 64:
+                c.wp6 = ops.pack_dense_nk_x6(w.reshape(c.cout, c.cin))
             if self.decoder_precision == 'bf16' and (name.startswith('decoder.') or name == 'post_quant_conv'):
                 if c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                     c.wp16 = ops.pack_conv3_bf16(w)
@@ -153,7 +155,7 @@ class VQGAN:
                 # fused q|k|v projection: one [C][3C] GEMM
                 w = torch.cat([dev_t(f'{name}.{p}.weight').reshape(c, c) for p in ('q', 'k', 'v')], 0)   # [3C][C] (out,in)
                 b = torch.cat([dev_t(f'{name}.{p}.bias') for p in ('q', 'k', 'v')], 0)
-                self._qkv[name] = (ops.pack_dense_nk(w), b)
+                self._qkv[name] = (ops.pack_dense_nk_x6(w) if self.conv_arith == 'x6' and c % 64 == 0 else ops.pack_dense_nk(w), b)
                 conv(name + '.proj_out')
             elif kind == 'norm_swish':
                 norm(name)
@@ -191,8 +193,9 @@ class VQGAN:
         c = self._conv[name]
         out = torch.empty((M, c.cout), dtype=torch.float32, device=x.device)
         bf16 = c.wp16 is not None and pro is None
-        ops.igemm(x, c.wp16 if bf16 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro, pro_swish=pro_swish,
-                  pro_rows_per_img=rows_per_img, bf16=bf16)
+        x6 = not bf16 and c.wp6 is not None
+        ops.igemm(x, c.wp16 if bf16 else c.wp6 if x6 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro,
+                  pro_swish=pro_swish, pro_rows_per_img=rows_per_img, bf16=bf16, x6=x6)
         return out
 
     def _gn(self, x, name, n, HW, C):
@@ -222,7 +225,7 @@ class VQGAN:
         pro = self._gn(x, name + '.norm', n, HW, C)
         wp, b = self._qkv[name]
         qkv = torch.empty((M, 3 * C), dtype=torch.float32, device=x.device)
-        ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW)
+        ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW, x6=wp.dtype == torch.bfloat16)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         # scores[b] = q_b @ k_b^T : B[kk=c][nn=key] = k[key][c]
         kp = ops.pack(k, C, HW, 1, sk=1, sn=3 * C, st=0, batch=n, src_bstride=HW * 3 * C)
