@@ -228,7 +228,7 @@ def main():
         x6 = args.conv_arith == 'x6'
         # HBM bytes per launch from the PMC passes (profiles/r1_conv_x6_pmc.txt / r1_conv_halo_pmc.txt: 2*FETCH_SIZE +
         # WRITE_SIZE with the gfx950 unit correction), measured on a 56-image launch of this shape, scaled by pixels
-        fetch_kb, write_kb = (530840e3, 458750e3) if x6 else (497520e3, 458750e3)
+        fetch_kb, write_kb = (516830e3, 458750e3) if x6 else (497520e3, 458750e3)
         is_dom_shape = dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
         pmc_bytes_per_pixel = (2 * fetch_kb + write_kb) * 1.024 / (56 * 128 * 128) if is_dom_shape else None
         # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6

@@ -97,6 +97,13 @@ int vf_igemm_f32(const vf_igemm_args* args /* host */, void* stream);
 int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* w_oihw, const float* bias,
                       float* out, int n_img, int H, int W, int Cout, void* stream);
 
+/* 3x3 stride-1 pad-1 convolution to 1..4 output channels (the decoder's conv_out, vqgan_th.py:285-289,316-318) with
+ * the GroupNorm-apply(+swish) of the preceding norm_out (:313-315) fused; plain fp32 fmaf arithmetic.  x NHWC
+ * [n_img][H][W][Cin], w OIHW, out NHWC [n_img][H][W][Cout].  Cin % 32 == 0, H % 8 == 0, W % 32 == 0. */
+int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bias, const float* pro_mean,
+                            const float* pro_scale, const float* pro_beta, int pro_swish, float* out, int n_img, int H, int W,
+                            int Cin, int Cout, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32 groups) statistics.  Replaces torch.nn.GroupNorm vqgan_th.py:16-17.
  * Produces mean_c/scale_c [Nimg][C] (scale = rstd*gamma) consumed by the igemm prologue or

@@ -304,3 +304,27 @@ def test_gemm_small_tile_variant(dev, M, K, N):
     ops.igemm(xi.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_conv_oihw(wc.to(dev)), n * H * H, C, C, o2, bias=bc.to(dev),
               mode=ops.MODE_CONV3_S1, Hin=H, Win=H, Hout=H, Wout=H)
     _close(o2.view(n, H, H, C).permute(0, 3, 1, 2), ref, 2e-5, 2e-5, 'small-tile conv 8x8')
+
+
+@pytest.mark.parametrize('cin,cout,H,W,pro', [(128, 3, 16, 32, True), (64, 3, 8, 64, False), (32, 1, 8, 32, True), (128, 4, 24, 32, True)])
+def test_conv3_small_cout(dev, cin, cout, H, W, pro):
+    """decoder conv_out: 3x3 conv to a few channels with the fused GroupNorm+swish"""
+    from viewformer_amd import ops
+    n = 2
+    x = _rand((n, cin, H, W), 51) * 1.4 + 0.2
+    w, b = _rand((cout, cin, 3, 3), 52, 0.05), _rand((cout,), 53)
+    gamma, beta = _rand((cin,), 54) * 0.3 + 1, _rand((cin,), 55) * 0.2
+    a = x.double()
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    prol = None
+    if pro:
+        a = F.group_norm(a, 32, gamma.double(), beta.double(), eps=1e-6)
+        a = a * torch.sigmoid(a)
+        mean_c, scale_c = ops.groupnorm_stats(xn, gamma.to(dev), n, H * W, cin)
+        prol = (mean_c, scale_c, beta.to(dev))
+    ref = F.conv2d(a, w.double(), b.double(), padding=1)
+    assert ops.conv3_small_cout_supported(ops.MODE_CONV3_S1, cin, cout, H, W)
+    out = ops.conv3_small_cout(xn.view(-1, cin), w.to(dev), b.to(dev), n, H, W, cin, cout, pro=prol)
+    _close(out.view(n, H, W, cout).permute(0, 3, 1, 2), ref, 3e-5, 3e-5, 'conv_out')
+    with pytest.raises(ops._lib.VfError):
+        ops.conv3_small_cout(xn.view(-1, cin), _rand((8, cin, 3, 3), 1).to(dev), None, n, H, W, cin, 8)

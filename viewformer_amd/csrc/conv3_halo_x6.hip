@@ -58,21 +58,6 @@ struct Geo {
     static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
 };
 
-__device__ __forceinline__ float swish_1ulp(float v) {
-    // x * sigmoid(x) to ~1.5 ulp without the library expf / IEEE-division sequences (25 -> 11 VALU per element):
-    // exp(-v) = exp2(t_hi) * (1 + t_lo ln2) with t = -v log2(e) carried as hi + lo (the rounding of t would otherwise
-    // cost |t| 2^-24 relative), v_exp_f32 (1 ulp); 1/(1+e) = v_rcp_f32 + one Newton step.
-    const float LH = -1.4426950408889634f, LL = -1.9259629911266175e-8f;      // -log2(e) = LH + LL
-    float th = v * LH;
-    const float tl = __builtin_fmaf(v, LH, -th) + v * LL;
-    th = fminf(th, 126.0f);                                                    // keeps 1 + e finite (v < -87: result ~ -0)
-    const float e0 = __builtin_amdgcn_exp2f(th);
-    const float d = 1.0f + __builtin_fmaf(e0 * tl, 0.6931471805599453f, e0);
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    return v * r;
-}
-
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     // exact 3-way split: h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m); both subtractions are exact
     h = (__bf16)x;
@@ -156,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
                 const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
                 const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
                 t = (t - mu) * sc + pbeta[e];
-                if (SWISH) t = VF_X6_PRECISE_SWISH ? vf_swish(t) : swish_1ulp(t);
+                if (SWISH) t = VF_X6_PRECISE_SWISH ? vf_swish(t) : vf_swish_1ulp(t);
             }
             __bf16 h, m, l;
             split3(s_ok[q] ? t : 0.f, h, m, l);

@@ -1,0 +1,122 @@
+// 3x3 stride-1 convolution to a handful of output channels (the decoder's conv_out: 128 -> 3 @128x128,
+// vqgan_th.py:285-289,316-318 with the norm_out GroupNorm + swish of :313-315 fused), gfx950.
+//
+// With 3 output channels the implicit-GEMM kernels pad N to 32 and waste 10x of the matrix pipe (0.45 ms per 32 images
+// at 79 "TF" of padded work).  The algorithmic work is tiny (3456 MAC per pixel), so this is a plain VALU kernel bounded by
+// the one read of the activation: one workgroup = an 8x32 pixel tile; per 32-channel chunk the (8+2)x(32+2) patch goes
+// through the GroupNorm-apply(+swish) ONCE into LDS (fp32, 36-float pixel stride: conflict-free b128 reads), the chunk's
+// [tap][c][4] weights sit next to it (wave-uniform broadcast reads), and each thread accumulates its pixel's outputs in
+// fp32 fmaf order (chunk, tap, channel).
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+constexpr int CK = 32, TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, P_LD = 36;
+constexpr int SLOTS = (NPIX * 8 + 255) / 256;          // float4 staging slots per thread (11)
+constexpr int MAXCO = 4;
+
+template <bool PRO, bool SWISH>
+__global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ pro_mean,
+                                                               const float* __restrict__ pro_scale,
+                                                               const float* __restrict__ pro_beta, float* __restrict__ out,
+                                                               int H, int W, int Cin, int Cout) {
+    __shared__ __attribute__((aligned(16))) float patch[NPIX * P_LD];
+    __shared__ __attribute__((aligned(16))) float wl[9 * CK * MAXCO];
+    const int tid = threadIdx.x;
+    const int tilesX = W / TW, tilesY = H / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int img = bid / tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* __restrict__ X = x + (size_t)img * H * W * Cin;
+    const int c4 = tid & 7;
+    const int px = tid & 31, py = tid >> 5;
+
+    float acc[MAXCO];
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) acc[co] = (co < Cout && bias) ? bias[co] : 0.f;
+
+    for (int chunk = 0; chunk < Cin / CK; ++chunk) {
+        __syncthreads();                                   // the previous chunk's readers are done
+        f32x4 pm = {0.f, 0.f, 0.f, 0.f}, ps = pm, pb = pm;
+        if (PRO) {
+            pm = *reinterpret_cast<const f32x4*>(pro_mean + (size_t)img * Cin + chunk * CK + c4 * 4);
+            ps = *reinterpret_cast<const f32x4*>(pro_scale + (size_t)img * Cin + chunk * CK + c4 * 4);
+            pb = *reinterpret_cast<const f32x4*>(pro_beta + chunk * CK + c4 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int pix = (tid >> 3) + 32 * q;
+            if (pix < NPIX) {
+                const int pr = pix / PW, pc = pix - pr * PW;
+                const int sy = y0 - 1 + pr, sx = x0 - 1 + pc;
+                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    v = *reinterpret_cast<const f32x4*>(X + ((size_t)sy * W + sx) * Cin + chunk * CK + c4 * 4);
+                    if (PRO) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = (v[e] - pm[e]) * ps[e] + pb[e];
+                            if (SWISH) t = vf_swish_1ulp(t);
+                            v[e] = t;
+                        }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(patch + pix * P_LD + c4 * 4) = v;
+            }
+        }
+        // weights of this chunk: wl[tap][c][co] from OIHW w[co][Cin][3][3]
+        for (int i = tid; i < 9 * CK * MAXCO; i += 256) {
+            const int co = i & (MAXCO - 1), c = (i >> 2) & (CK - 1), tap = i / (CK * MAXCO);
+            wl[i] = co < Cout ? w[((size_t)co * Cin + chunk * CK + c) * 9 + tap] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* a = patch + ((py + tap / 3) * PW + px + tap % 3) * P_LD;
+            const float* wt = wl + tap * CK * MAXCO;
+#pragma unroll
+            for (int k4 = 0; k4 < CK / 4; ++k4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + k4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + (k4 * 4 + e) * MAXCO);
+#pragma unroll
+                    for (int co = 0; co < MAXCO; ++co) acc[co] = __builtin_fmaf(av[e], wv[co], acc[co]);
+                }
+            }
+        }
+    }
+    float* o = out + (((size_t)img * H + y0 + py) * W + x0 + px) * Cout;
+    for (int co = 0; co < Cout; ++co) o[co] = acc[co];
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bias, const float* pro_mean,
+                            const float* pro_scale, const float* pro_beta, int pro_swish, float* out, int n_img, int H, int W,
+                            int Cin, int Cout, void* stream) {
+    if (!x || !w_oihw || !out || n_img <= 0 || H <= 0 || W <= 0) return VF_ERR_BAD_ARG;
+    if (Cout < 1 || Cout > MAXCO || Cin % CK != 0 || H % TH != 0 || W % TW != 0) return VF_ERR_UNSUPPORTED;
+    if ((pro_mean || pro_scale || pro_beta) && !(pro_mean && pro_scale && pro_beta)) return VF_ERR_BAD_ARG;
+    const dim3 grid((unsigned)((long long)n_img * (H / TH) * (W / TW)));
+    hipStream_t s = (hipStream_t)stream;
+    if (!pro_mean)
+        hipLaunchKernelGGL((conv3_small_cout_kernel<false, false>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+                           pro_beta, out, H, W, Cin, Cout);
+    else if (pro_swish)
+        hipLaunchKernelGGL((conv3_small_cout_kernel<true, true>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+                           pro_beta, out, H, W, Cin, Cout);
+    else
+        hipLaunchKernelGGL((conv3_small_cout_kernel<true, false>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+                           pro_beta, out, H, W, Cin, Cout);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(vf_igemm_args p) {
             float t = areg[q][e];
             if (PRO) {
                 t = (t - pmean[q][e]) * pscale[q][e] + pbeta[e];
-                if (SWISH) t = vf_swish(t);
+                if (SWISH) t = vf_swish_1ulp(t);
             }
             __bf16 h, m, l;
             split3(t, h, m, l);

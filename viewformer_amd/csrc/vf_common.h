@@ -22,6 +22,21 @@ __device__ __forceinline__ float vf_swish(float v) {
     return v / (1.0f + expf(-v));
 }
 
+__device__ __forceinline__ float vf_swish_1ulp(float v) {
+    // x * sigmoid(x) to ~1.5 ulp without the library expf / IEEE-division sequences (25 -> 11 VALU per element):
+    // exp(-v) = exp2(t_hi) * (1 + t_lo ln2) with t = -v log2(e) carried as hi + lo (the rounding of t would otherwise
+    // cost |t| 2^-24 relative), v_exp_f32 (1 ulp); 1/(1+e) = v_rcp_f32 + one Newton step.
+    const float LH = -1.4426950408889634f, LL = -1.9259629911266175e-8f;      // -log2(e) = LH + LL
+    float th = v * LH;
+    const float tl = __builtin_fmaf(v, LH, -th) + v * LL;
+    th = fminf(th, 126.0f);                                                    // keeps 1 + e finite (v < -87: result ~ -0)
+    const float e0 = __builtin_amdgcn_exp2f(th);
+    const float d = 1.0f + __builtin_fmaf(e0 * tl, 0.6931471805599453f, e0);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return v * r;
+}
+
 __device__ __forceinline__ float vf_gelu_erf(float v) {
     // tf.nn.gelu(approximate=False): 0.5 x (1 + erf(x / sqrt 2))
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));

@@ -199,6 +199,23 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     return out
 
 
+def conv3_small_cout_supported(mode, Cin, Cout, H, W):
+    return mode == MODE_CONV3_S1 and 1 <= Cout <= 4 and Cin % 32 == 0 and H % 8 == 0 and W % 32 == 0
+
+
+def conv3_small_cout(x, w_oihw, bias, n_img, H, W, Cin, Cout, pro=None, pro_swish=True, out=None):
+    """3x3 conv to <= 4 channels (decoder conv_out) with the fused GroupNorm(+swish) prologue; x NHWC rows"""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((n_img * H * W, Cout), dtype=torch.float32, device=x.device)
+    pm, ps, pb = (None, None, None) if pro is None else pro
+    check(lib.vf_conv3_small_cout_f32(_p(_f32(x)), _p(_f32(w_oihw)), _p(_f32(bias)) if bias is not None else None,
+                                      _p(pm) if pm is not None else None, _p(ps) if ps is not None else None,
+                                      _p(pb) if pb is not None else None, 1 if pro_swish else 0, _p(out), n_img, H, W, Cin, Cout,
+                                      _stream()), 'vf_conv3_small_cout_f32')
+    return out
+
+
 def conv_in(img, w_oihw, bias, n_img, H, W, Cout, out=None):
     """img: uint8 NHWC [n,H,W,3] (TF evaluator entry) or float32 NHWC already in [-1,1]"""
     lib = _lib.load()

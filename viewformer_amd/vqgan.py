@@ -174,6 +174,9 @@ class VQGAN:
             Ho, Wo = H * 2, W * 2
         else:
             Ho, Wo = H, W
+        if res is None and ops.conv3_small_cout_supported(mode, c.cin, c.cout, Ho, Wo):      # conv_out (-> 3 channels)
+            self._stats_of = None
+            return ops.conv3_small_cout(x, c.w_raw, c.bias, n, H, W, c.cin, c.cout, pro=pro, pro_swish=pro_swish), Ho, Wo
         out = torch.empty((n * Ho * Wo, c.cout), dtype=torch.float32, device=x.device)
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
