@@ -29,7 +29,9 @@ def _err(out, ref, mag):
 
 @pytest.mark.parametrize('mode,cin,cout,H,pro', [('s1', 128, 128, 16, True), ('s1', 64, 256, 32, False), ('up', 128, 128, 8, False),
                                                   ('up', 32, 128, 16, True), ('s1', 128, 128, 64, True),
-                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True)])
+                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True),
+                                                  # Downsample: pad (right, bottom) + stride 2
+                                                  ('s2', 128, 128, 32, False), ('s2', 64, 256, 64, False), ('s2', 32, 128, 32, False)])
 def test_conv3_halo_x6_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
     from viewformer_amd import ops
     n = 3 if H == 8 else 2
@@ -46,11 +48,16 @@ def test_conv3_halo_x6_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
         sc = scale_c.double().cpu().view(n, cin, 1, 1)
         a = (a - mu) * sc + beta.double().view(1, cin, 1, 1)
         a = a * torch.sigmoid(a)
-    m, Ho = (ops.MODE_CONV3_S1, H) if mode == 's1' else (ops.MODE_CONV3_UP2, 2 * H)
+    m, Ho = {'s1': (ops.MODE_CONV3_S1, H), 'up': (ops.MODE_CONV3_UP2, 2 * H), 's2': (ops.MODE_CONV3_S2PAD, H // 2)}[mode]
     if mode == 'up':
         a = F.interpolate(a, scale_factor=2.0, mode='nearest')
-    ref = F.conv2d(a, w.double(), None, padding=1)
-    mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1)
+    if mode == 's2':
+        ap = F.pad(a, (0, 1, 0, 1))
+        ref = F.conv2d(ap, w.double(), None, stride=2)
+        mag = F.conv2d(ap.abs(), w.double().abs(), None, stride=2)
+    else:
+        ref = F.conv2d(a, w.double(), None, padding=1)
+        mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1)
     res = _rand((n * Ho * Ho, cout), 16)
     ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + b.double() + res.double()
     mag = mag.permute(0, 2, 3, 1).reshape(-1, cout) + b.double().abs() + res.double().abs()
@@ -73,7 +80,8 @@ def test_x6_refuses_unsupported_shapes(dev):
     out = torch.empty((2 * 16 * 12, 128), device=dev)
     with pytest.raises(ops._lib.VfError):        # W % 16 != 0: refused, never rerouted
         ops.igemm(x, w, 2 * 16 * 12, 64, 128, out, mode=ops.MODE_CONV3_S1, Hin=16, Win=12, Hout=16, Wout=12, x6=True)
-    assert not ops.conv3_x6_supported(ops.MODE_CONV3_S2PAD, 128, 128, 64, 64)
+    assert not ops.conv3_x6_supported(ops.MODE_CONV3_S2PAD, 128, 128, 8, 8)       # 16x16 -> 8x8 stays on the generic kernel
+    assert not ops.conv3_x6_supported(ops.MODE_CONV3_S1, 128, 64, 64, 64)
 
 
 @pytest.mark.parametrize('kernel', ['x6', 'bf16'])

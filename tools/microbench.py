@@ -29,6 +29,18 @@ def timeit(fn, iters=8, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
+def conv_s2(n_img=224, C=128, H=128, x6=True):
+    x = torch.randn(n_img * H * H, C, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.03
+    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
+    b = torch.randn(C, device=dev)
+    Ho = H // 2
+    M = n_img * Ho * Ho
+    out = torch.empty(M, C, device=dev)
+    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, mode=ops.MODE_CONV3_S2PAD, Hin=H, Win=H, Hout=Ho, Wout=Ho, x6=x6))
+    print(f'conv3x3 s2{" x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
+
+
 def conv(n_img=56, C=128, H=128, pro=True, x6=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
@@ -92,7 +104,8 @@ def convin(n_img=224, H=128, C=128):
     print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
-ALL = dict(gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
+ALL = dict(convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
+           gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),

@@ -140,7 +140,7 @@ def pack_dense_nk_x6(w, n_rows=None):
 
 def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
     """shape rules of vf_conv3_halo_x6 (host-side mirror so callers can pick the packing up front)"""
-    if mode not in (MODE_CONV3_S1, MODE_CONV3_UP2) or Cin % 32 or Cout % 128:
+    if mode not in (MODE_CONV3_S1, MODE_CONV3_UP2, MODE_CONV3_S2PAD) or Cin % 32 or Cout % 128:
         return False
     return (Hout % 8 == 0 and Wout % 16 == 0) or (mode == MODE_CONV3_S1 and Hout == 8 and Wout == 8)
 
