@@ -161,6 +161,11 @@ int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, flo
 int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out,
                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
                             float scale, int skip_masked, int twin_view, void* stream);
+/* same contract on the bf16 matrix pipe (Q, K, V and the probabilities rounded to bf16, fp32 sums and softmax): the
+ * tolerance-bounded transformer arm.  fp32 tensors in, fp32 out. */
+int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, float* out,
+                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                             float scale, int skip_masked, int twin_view, void* stream);
 /* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
 int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
 

@@ -154,3 +154,31 @@ def test_pipeline_bf16_arm(dev, full_vq):
     assert torch.equal(got['codes'].cpu(), ref['codes'])
     assert _rel(got['logits_last'], ref['logits_last']) < LOGIT_TOL_REL
     assert got['generated_images'].dtype == torch.uint8
+
+
+ATTN_TOL = 1.5e-2       # max |attention output error| / max |output|: bf16 Q, K, V and probabilities, fp32 softmax and sums
+
+
+@pytest.mark.parametrize('B,H,S,L,mode', [(2, 2, 4, 16, 'causal'), (1, 12, 7, 64, 'causal'), (1, 2, 5, 48, 'causal'),
+                                          (2, 3, 8, 64, 'twin'), (1, 2, 3, 64, 'streams')])
+def test_attention_bf16_all_mask_modes(dev, B, H, S, L, mode):
+    """bf16-MFMA attention against the SAME kernel contract in exact fp32 (vf_attn_blockcausal_f32, itself pinned to the
+    oracle's compute_causal_block[_multiend]_attention): plain block-causal, twin views, streams; skip == dense."""
+    from viewformer_amd import ops
+    d = H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = {'causal': -1, 'twin': S - 2, 'streams': -S}[mode]
+    qkv = _rand((B * T, 3 * d), 71, 0.35).to(dev)
+    ref = torch.empty((B * T, d), device=dev)
+    ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], ref, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec)
+    outs = []
+    for skip in (True, False):
+        out = torch.empty((B * T, d), device=dev)
+        ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, skip, spec,
+                             bf16=True)
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        assert err < ATTN_TOL, (mode, skip, err)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])        # skipping fully masked tiles == the dense "-1e4" form, also in bf16
+    print(f'bf16 attention {mode} B={B} H={H} S={S} L={L}: rel err {err:.2e}')

@@ -78,14 +78,14 @@ def vq(M=64 * 448):
     print(f'vq_argmin M={M}: {ms:.4f} ms  {2.0 * M * 256 * 1024 / ms / 1e9:.1f} TF  {by / ms / 1e6:.1f} GB/s algorithmic')
 
 
-def attn(B=32, H=12, S=7, L=64):
+def attn(B=32, H=12, S=8, L=64, bf16=False):
     d, T = H * 64, S * L
     qkv = torch.randn(B * T, 3 * d, device=dev) * 0.3
     out = torch.empty(B * T, d, device=dev)
     ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
-                                             3 * d, d, 1.0, True))
+                                             3 * d, d, 1.0, True, bf16=bf16))
     useful = 4.0 * H * 64 * L * L * S * (S + 1) / 2 * B
-    print(f'attn B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
+    print(f'attn{"[bf16]" if bf16 else ""} B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
 
 
 def gn(n_img=56, C=128, HW=16384):
@@ -104,7 +104,8 @@ def convin(n_img=224, H=128, C=128):
     print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
-ALL = dict(convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
+ALL = dict(attnbf16=lambda: attn(bf16=True),
+           convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),

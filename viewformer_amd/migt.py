@@ -33,7 +33,8 @@ class MIGT:
         """``dense_arith`` picks how the fp32 dense layers are evaluated (precision='f32' only): 'f32' = native f32 MFMA,
         'x6' = the fp32-EQUIVALENT six-term split-bf16 GEMM (csrc/gemm_x6.hip: same error against fp64, ~1.8x faster).
         ``precision='bf16'``: the dense layers (c_attn, c_proj, MLP, LM head, pose MLPs) run on the bf16-MFMA arm with
-        fp32 activations / accumulation; LayerNorm, attention, softmax, residual stream and arg-max stay fp32.
+        fp32 activations / accumulation, and the attention contractions (q.k^T, p.v) on bf16 MFMA with an fp32 softmax;
+        LayerNorm, the residual stream and the arg-max stay fp32.
         Logits are then tolerance-bounded (tests state the bound), as the north star allows for the transformer."""
         assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6')
         self.precision = precision
@@ -187,7 +188,7 @@ class MIGT:
             self._dense_launch(a, ca, M, qkv)
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
-                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec)
+                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16')
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
