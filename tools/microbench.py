@@ -41,10 +41,10 @@ def conv_s2(n_img=224, C=128, H=128, x6=True):
     print(f'conv3x3 s2{" x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
 
 
-def conv(n_img=56, C=128, H=128, pro=True, x6=False):
+def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
-    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
+    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv3_bf16(w) if bf16 else ops.pack_conv_oihw(w)
     b = torch.randn(C, device=dev)
     out = torch.empty_like(x)
     prol = None
@@ -54,9 +54,9 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False):
         prol = (m, s, torch.zeros(C, device=dev))
     M = n_img * H * H
     ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
-                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6))
+                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16))
     fl = 2.0 * M * C * C * 9
-    print(f'conv3x3{" x6" if x6 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
+    print(f'conv3x3{" x6" if x6 else " bf16" if bf16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 
 
 def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
@@ -104,7 +104,9 @@ def convin(n_img=224, H=128, C=128):
     print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
-ALL = dict(attnbf16=lambda: attn(bf16=True),
+ALL = dict(convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
+           convbf16_256=lambda: conv(32, 256, 32, bf16=True),
+           attnbf16=lambda: attn(bf16=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),

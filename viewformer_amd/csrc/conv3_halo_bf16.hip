@@ -130,14 +130,38 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
     const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
-    bf16x8 bc[4], bn[4];
-    auto b_load = [&](bf16x8 (&dst)[4], int stage) {
-        const unsigned char* src = Wb + (size_t)stage * tap_stride;
+    // software pipeline over taps (g = chunk*9 + tap): weight fragments BD taps ahead in a register ring, LDS fragments one
+    // tap ahead; sched_barrier pins the distances (the scheduler otherwise sinks the loads next to their uses)
+#ifndef VF_BF16_BD
+#define VF_BF16_BD 2
+#endif
+    constexpr int BD = VF_BF16_BD, RING = BD + 1;
+    static_assert(9 % RING == 0, "ring indices must repeat per chunk");
+    bf16x8 bring[RING][4];
+    bf16x8 aring[2][2][2];
+    const int last_g = nchunks * 9 - 1;
+    auto b_load = [&](bf16x8 (&dst)[4], int g) {
+        const unsigned char* src = Wb + (size_t)min(g, last_g) * tap_stride;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 dst[ks * 2 + j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16 + b_lane);
+    };
+    auto a_load = [&](bf16x8 (&dst)[2][2], const unsigned char* patch, int tap) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            int aoff;
+            if (UP2) {
+                const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
+                aoff = (pr * G::PW + pc) * P_LDB + half * 16;
+            } else {
+                aoff = a_base[mi] + (dy * G::PW + dx) * P_LDB;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[mi][ks] = *reinterpret_cast<const bf16x8*>(patch + aoff + ks * 32);
+        }
     };
 
     f32x16 acc[2][2];
@@ -149,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     patch_load(0);
-    b_load(bc, 0);
+#pragma unroll
+    for (int g = 0; g < BD; ++g) b_load(bring[g], g);
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
     __syncthreads();
@@ -157,34 +182,20 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
         patch_load(min(chunk + 1, nchunks - 1));
+        a_load(aring[0], patch, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            b_load(bn, min(chunk * 9 + tap + 1, last_stage));
-            int aoff[2];
+            b_load(bring[(tap + BD) % RING], chunk * 9 + tap + BD);
+            if (tap + 1 < 9) a_load(aring[(tap + 1) & 1], patch, tap + 1);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                if (UP2) {
-                    const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
-                    aoff[mi] = (pr * G::PW + pc) * P_LDB + half * 16;
-                } else {
-                    aoff[mi] = a_base[mi] + (dy * G::PW + dx) * P_LDB;
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(patch + aoff[mi] + ks * 32);
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bc[ks * 2 + j], acc[mi][j], 0, 0, 0);
-            }
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[tap & 1][mi][ks], bring[tap % RING][ks * 2 + j], acc[mi][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (tap >= 1 && tap <= G::SLOTS) patch_store_slot((chunk + 1) & 1, tap - 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bc[q] = bn[q];
         }
         __syncthreads();
     }
