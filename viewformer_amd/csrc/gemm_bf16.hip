@@ -149,6 +149,136 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vf_igemm_args p) {
     }
 }
 
+// Second-generation kernel (K % 128 == 0): the weight fragments no longer pass through LDS — the packed layout already
+// is fragment-major, so a lane's B fragment is one 16-byte L2 load — and are fetched one whole 64-deep stage ahead into a
+// register ring pinned with sched_barrier (the recipe of conv3_halo_x6.hip).  LDS then carries only the A tile: half the
+// LDS traffic of the kernel above, which was LDS-bandwidth-bound (16 ds_read_b128 per 16 MFMAs per wave).
+__global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][A_BYTES]
+    unsigned char* As = smem_b;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = (p.Cout + BN - 1) / BN;
+    const int nblk = blockIdx.x % nb;
+    const int mtile = blockIdx.x / nb;
+    const float* __restrict__ X = p.x;
+    const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * B_BYTES;
+    const size_t stage_stride = (size_t)nb * B_BYTES;
+    const int nstages = p.Cin / CK;
+
+    const int a_c4 = tid & 15, a_r0 = tid >> 4;
+    const float* arow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int m = mtile * BM + a_r0 + 16 * q;
+        m = m < p.M ? m : p.M - 1;
+        arow[q] = X + (size_t)m * p.lda + a_c4 * 4;
+    }
+    f32x4 areg[8];
+    auto a_fetch = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const f32x4*>(arow[q] + s * CK);
+    };
+    auto a_park = [&](int buf, int q) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[q][e];
+        *reinterpret_cast<bf16x4*>(As + buf * A_BYTES + (a_r0 + 16 * q) * A_LDB + a_c4 * 8) = v;
+    };
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    bf16x8 bring[2][4][2];             // [stage parity][ks][j]
+    auto b_load = [&](bf16x8 (&dst)[4][2], int s) {
+        const unsigned char* src = Wp + (size_t)min(s, nstages - 1) * stage_stride + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[ks][j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    a_fetch(0);
+    b_load(bring[0], 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a_park(0, q);
+    __syncthreads();
+
+    auto stage_body = [&](int s, bf16x8 (&bcur)[4][2], bf16x8 (&bnext)[4][2]) {
+        const unsigned char* a_src = As + (s & 1) * A_BYTES + (wave_m * 64 + l31) * A_LDB + half * 16;
+        a_fetch(min(s + 1, nstages - 1));
+        b_load(bnext, s + 1);
+        bf16x8 a[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(a_src + i * 32 * A_LDB + ks * 32);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], bcur[ks][j], acc[i][j], 0, 0, 0);
+            a_park((s + 1) & 1, ks * 2);
+            a_park((s + 1) & 1, ks * 2 + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    for (int s = 0; s < nstages; s += 2) {          // nstages is even (Cin % 128 == 0)
+        stage_body(s, bring[0], bring[1]);
+        stage_body(s + 1, bring[1], bring[0]);
+    }
+
+    float* __restrict__ Out = p.out;
+    const float* __restrict__ Res = p.res;
+    const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);
+    const long long ldc = p.ldc, ldr = p.ldr;
+    const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
+            const int nn = nok ? n : 0;
+            float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
+            const float* rs = Res ? Res + (size_t)(m0 < p.M ? m0 : 0) * ldr + nn : nullptr;
+            const int rows_left = nok ? p.M - m0 : 0;
+            if (full) {
+                auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
+                auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
+                if (gelu) {
+                    if (Res) vf_store_tile<1, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<1, false>(acc[i][j], bias, o, rs, oo, ro);
+                } else {
+                    if (Res) vf_store_tile<0, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<0, false>(acc[i][j], bias, o, rs, oo, ro);
+                }
+            } else if (gelu) {
+                if (Res) vf_store_tile_ragged<1, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<1, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+            } else {
+                if (Res) vf_store_tile_ragged<0, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<0, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+            }
+        }
+    }
+}
+
 // pack fp32 [K][N] (strided) -> bf16 fragment-major [K/64][nb][ks(4)][half(2)][n(128)][8]
 __global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N, long long sk,
                                  long long sn, int nb, int nchunks, long long src_bstride, long long dst_bstride) {
@@ -208,6 +338,13 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
         attr_set = true;
     }
     const int nb = (a.Cout + BN - 1) / BN, mt = (a.M + BM - 1) / BM;
+#ifndef VF_GEMM_BF16_DIRECT
+#define VF_GEMM_BF16_DIRECT 1
+#endif
+    if (VF_GEMM_BF16_DIRECT && a.Cin % (2 * CK) == 0 && a.batch <= 1) {
+        hipLaunchKernelGGL(gemm_bf16_direct_kernel, dim3((unsigned)(mt * nb)), dim3(256), (size_t)2 * A_BYTES, (hipStream_t)stream, a);
+        return vf_last_status();
+    }
     dim3 grid((unsigned)(mt * nb), 1, (unsigned)(a.batch > 0 ? a.batch : 1));
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), smem, (hipStream_t)stream, a);
     return vf_last_status();
