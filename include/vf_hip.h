@@ -183,6 +183,9 @@ int vf_dense_small_k_gelu_f32(const float* x, const float* W, const float* b, fl
                               int64_t rows, int K, int N, int gelu, void* stream);
 /* first-max index over each row of n floats (tf.argmax, evaluate_transformer.py:123; ties -> lowest) */
 int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx, void* stream);
+/* host-side CRC-32C (Castagnoli) of a HOST buffer, for the TFRecord / TensorBundle files of the reference's datasets and
+ * Keras checkpoints (viewformer_amd/codes_dataset.py, checkpoint.py); crc = 0 starts a new checksum */
+uint32_t vf_crc32c(const void* data, size_t n, uint32_t crc);
 /* clip[-1,1] -> /2+0.5 -> trunc(x*255.5) uint8  (evaluate_transformer.py:128-129, TF semantics) */
 int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 

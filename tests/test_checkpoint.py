@@ -1,0 +1,111 @@
+"""CPU: checkpoint ingestion (viewformer_amd/checkpoint.py).  The torch half is pinned by a model directory
+written by the reference's own classes (tests/golden/vqgan_tiny_model, make_ckpt_golden.py); the TensorBundle half is
+checked against its own writer + the published format constants (parity unpinned: no TensorFlow in the image)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from viewformer_amd import checkpoint as ck
+from viewformer_amd.config import MIGTConfig, VQGANConfig, load_config
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TINY_DIR = os.path.join(HERE, 'golden', 'vqgan_tiny_model')
+
+
+def test_reference_written_model_directory_loads():
+    cfg = load_config(json.load(open(os.path.join(TINY_DIR, 'config.json'))))
+    assert isinstance(cfg, VQGANConfig) and cfg.ch == 32 and cfg.n_embed == 64 and cfg.image_size == 32
+    sd = ck.read_torch_checkpoint(os.path.join(TINY_DIR, 'model.ckpt'))
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_vqgan_weights
+    m = VQGAN(cfg)
+    m.load_state_dict(sd)                                    # strict: loss sub-module keys are ignored, nothing missing
+    want = make_vqgan_weights(cfg, seed=3, codebook_scale=0.05)
+    got = m.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(np.asarray(got[k]).reshape(-1), np.asarray(want[k]).reshape(-1)), k   # (the reference's counter is [1])
+    assert sd['encoder.conv_in.weight'].shape == (32, 3, 3, 3)               # OIHW, as the reference ships them
+
+
+def test_tensor_bundle_roundtrip_and_format_constants(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {f'h/{i}/attn/c_attn/weight/.ATTRIBUTES/VARIABLE_VALUE': rng.normal(size=(4, 6)).astype(np.float32) for i in range(700)}
+    tensors['save_counter/.ATTRIBUTES/VARIABLE_VALUE'] = np.array(3, dtype=np.int64)
+    tensors['wpe/.ATTRIBUTES/VARIABLE_VALUE'] = rng.normal(size=(256, 16)).astype(np.float32)
+    prefix = str(tmp_path / 'model')
+    ck.write_tensor_bundle(prefix, tensors)
+    raw = open(prefix + '.index', 'rb').read()
+    assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57           # leveldb table magic
+    assert os.path.getsize(prefix + '.data-00000-of-00001') == sum(t.nbytes for t in tensors.values())
+    table = ck._read_table(prefix + '.index')
+    assert list(table)[0] == b'' and list(table)[1:] == sorted(k.encode() for k in tensors)   # header first, keys sorted
+    assert len(raw) > 2 * 4096                                               # several data blocks -> the index block is exercised
+    back = ck.read_tensor_bundle(prefix)
+    assert set(back) == set(tensors)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v)
+    # a flipped data byte is caught by the per-tensor CRC
+    with open(prefix + '.data-00000-of-00001', 'r+b') as f:
+        f.seek(100)
+        b = f.read(1)
+        f.seek(100)
+        f.write(bytes([b[0] ^ 1]))
+    with pytest.raises(IOError):
+        ck.read_tensor_bundle(prefix)
+    # and a flipped index byte by the block CRC
+    ck.write_tensor_bundle(prefix, tensors)
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[50] ^= 1
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(IOError):
+        ck.read_tensor_bundle(prefix)
+
+
+def test_keras_key_mapping_both_conventions():
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(n_layer=2, d_model=64, n_head=1, localization_weight='1')
+    sd = make_migt_weights(cfg, seed=0)
+    obj = ck.state_dict_to_keras(sd)                                          # object-graph keys (model.save_weights)
+    assert 'h/1/attn/c_attn/weight/.ATTRIBUTES/VARIABLE_VALUE' in obj and 'wpe/.ATTRIBUTES/VARIABLE_VALUE' in obj
+    assert obj['h/0/mlp/c_fc/bias/.ATTRIBUTES/VARIABLE_VALUE'].shape == (1, 4 * 64)          # Conv1D bias is [1, nf] (migt.py:87)
+    obj['optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE'] = np.array(7, np.int64)
+    obj['h/0/attn/c_attn/weight/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((64, 192), np.float32)
+    back = ck.keras_to_state_dict(obj)
+    assert set(back) == set(sd)
+    for k in sd:
+        assert np.array_equal(back[k], np.asarray(sd[k])), k
+    # name-based keys: 'migt/h.0/attn/c_attn/weight', 'migt/wte/weight', 'migt/wpe/embeddings'
+    named = {}
+    for k, v in sd.items():
+        parts = k.split('.')
+        key = ('h.' + parts[1] + '/' + '/'.join(parts[2:])) if parts[0] == 'h' else '/'.join(parts)
+        named['migt/' + key] = np.asarray(v)
+    back2 = ck.keras_to_state_dict(named)
+    assert set(back2) == set(sd)
+
+
+def test_load_model_reads_config_overrides_and_refuses_missing_dirs(tmp_path):
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(n_layer=1, d_model=64, n_head=1, localization_weight='1', pose_multiplier=1.0)
+    d = tmp_path / 'tr'
+    d.mkdir()
+    from dataclasses import asdict
+    cj = asdict(cfg)
+    cj['model'] = 'migt'
+    json.dump(cj, open(d / 'config.json', 'w'))
+    ck.write_tensor_bundle(str(d / 'model'), ck.state_dict_to_keras(make_migt_weights(cfg, seed=1)))
+    m = ck.load_model(str(d / 'model'), pose_multiplier=0.2)                 # evaluate_transformer.py:205-208
+    assert m.config.pose_multiplier == 0.2 and m.config.n_layer == 1
+    assert np.array_equal(np.asarray(m.state_dict()['wte.weight']), np.asarray(make_migt_weights(cfg, seed=1)['wte.weight']))
+    with pytest.raises(FileNotFoundError):
+        ck.load_model('interiornet-transformer-tf')                          # named checkpoints need the network
+    # a checkpoint with a missing tensor is refused by load_state_dict
+    sd = make_migt_weights(cfg, seed=1)
+    sd.pop('ln_f.gamma')
+    ck.write_tensor_bundle(str(d / 'broken'), ck.state_dict_to_keras(sd))
+    with pytest.raises(RuntimeError):
+        ck.load_model(str(d / 'broken'))

@@ -212,3 +212,36 @@ def test_fused_generate_and_localize_is_bit_identical_to_two_passes(dev, full_vq
         assert torch.equal(a['pose_last'], b['pose_last'])
         assert torch.equal(a['generated_images'], b['generated_images'])
         assert torch.equal(a['generated_cameras'], b['generated_cameras'])
+
+
+def test_generate_codes_dataset_with_the_gpu_codebook(dev, tiny_vq, tmp_path):
+    """generate-codes end to end: frames -> VQGAN.encode on the GPU -> TFRecord code dataset -> read back"""
+    from viewformer_amd import codes_dataset as cd
+    cfg, sd, g = tiny_vq
+    m = _vq_model(cfg, sd, dev, 'NHWC')
+    frames = g['frames']                                    # [N,H,W,3] uint8
+    n = frames.shape[0] // 2 * 2
+    seqs = [dict(frames=frames[:n // 2], cameras=np.arange(n // 2 * 7, dtype=np.float32).reshape(-1, 7)),
+            dict(frames=frames[n // 2:n], cameras=-np.arange(n // 2 * 7, dtype=np.float32).reshape(-1, 7))]
+    out = str(tmp_path / 'codes' / 'tiny')
+    info = cd.generate_codes(seqs, out, m, split='test', max_sequences_per_shard=1, batch_size=3)
+    assert info['token_image_size'] == g['codes'].shape[-1] and info['test_size'] == 2
+    back = list(cd.read_code_dataset(str(tmp_path / 'codes'), 'test'))
+    got = np.concatenate([b['codes'] for b in back], 0)
+    assert np.array_equal(got, g['codes'][:n])              # = the reference's own codes for these frames
+    assert np.array_equal(back[1]['cameras'], seqs[1]['cameras'])
+
+
+def test_load_model_from_a_reference_written_directory(dev, tiny_vq):
+    """load_model on tests/golden/vqgan_tiny_model — config.json + Lightning-style model.ckpt written by the
+    reference's own classes — reproduces the reference's codes for the golden frames"""
+    import os
+    from viewformer_amd.checkpoint import load_model
+    _, _, g = tiny_vq
+    here = os.path.dirname(os.path.abspath(__file__))
+    m = load_model(os.path.join(here, 'golden', 'vqgan_tiny_model', 'model.ckpt'), device=dev)
+    assert m.config.image_size == 32 and m.config.n_embed == 64 and m.config.stride == 2
+    codes = m.encode(torch.from_numpy(g['frames']).to(dev))[-1]          # TF-convention entry (NHWC uint8), as the evaluators use
+    assert np.array_equal(codes.cpu().numpy(), g['codes'])
+    dec = m.decode_code(torch.from_numpy(g['codes']).to(dev)).permute(0, 3, 1, 2)
+    assert _maxerr(dec, g['decoded']) < 2e-5

@@ -1,0 +1,334 @@
+"""Checkpoint ingestion without TensorFlow / Lightning (reference ``load_model``:
+``viewformer/utils/torch.py:9-18``, ``utils/tensorflow.py:20-68``, ``models/__init__.py:62-78``).
+
+A model directory holds ``config.json`` plus either
+
+* a **Lightning / torch checkpoint** (``*.ckpt`` / ``*.pth``): ``torch.load(...)['state_dict']`` with the key names of
+  ``vqgan_th.py`` (OIHW conv weights) — what the codebook models ship as; or
+* a **Keras TF-format checkpoint** (``model.index`` + ``model.data-00000-of-00001``): a TensorBundle — an SSTable
+  (LevelDB table format) mapping tensor keys to ``BundleEntryProto`` records over raw little-endian tensor shards — with
+  the object-graph keys of ``model.save_weights`` (``h/0/attn/c_attn/weight/.ATTRIBUTES/VARIABLE_VALUE``, ``wpe/...``,
+  ``migt.py:288-292,306-315``) or the older name-based keys (``h.0/attn/c_attn/weight``).
+
+``load_model(path, **config_overrides)`` mirrors the reference call: it returns the build's ``VQGAN`` / ``MIGT`` object
+with ``.config`` populated and weights loaded through ``load_state_dict`` (missing / unexpected keys raise).
+
+PINNING: the torch half is pinned by ``tests/golden/vqgan_tiny_model/`` (config.json + model.ckpt), written by the
+reference's own classes (``tests/golden/make_ckpt_golden.py``).  The TensorBundle half is **parity unpinned**: TensorFlow is not in the image, so the
+reader is checked against this module's own writer, the published format constants (table magic, block trailer, proto
+field numbers of tensor_bundle.proto) and the CRCs; it has never seen a file written by TensorFlow itself.
+"""
+import json
+import os
+import struct
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import codes_dataset as _wire
+from .config import MIGTConfig, VQGANConfig, load_config
+
+_TABLE_MAGIC = 0xdb4775248b80fb57
+_HEADER_KEY = b''
+# tensorflow/core/framework/types.proto
+_DT = {1: np.dtype('<f4'), 2: np.dtype('<f8'), 3: np.dtype('<i4'), 4: np.dtype('u1'), 5: np.dtype('<i2'), 6: np.dtype('i1'),
+       9: np.dtype('<i8'), 10: np.dtype('?'), 19: np.dtype('<f2')}
+_DT_INV = {v: k for k, v in _DT.items()}
+_DT_STRING, _DT_BFLOAT16 = 7, 14
+
+
+def _crc32c(data) -> int:
+    """fast path through the library's host function (350 MB of weights), else the pure-Python implementation"""
+    if isinstance(data, np.ndarray):
+        data = np.ascontiguousarray(data).reshape(-1).view(np.uint8)
+    else:
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+    if data.size == 0:
+        return 0
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except Exception:
+        return _wire.crc32c(data.tobytes())
+    return int(lib.vf_crc32c(data.ctypes.data, data.size, 0))
+
+
+def _mask(c: int) -> int:
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------ LevelDB-format table
+def _read_block(buf: bytes, offset: int, size: int, what: str) -> bytes:
+    contents = buf[offset:offset + size]
+    ctype = buf[offset + size]
+    (crc,) = struct.unpack('<I', buf[offset + size + 1:offset + size + 5])
+    if _mask(_wire.crc32c(contents + bytes([ctype]))) != crc:
+        raise IOError(f'tensor bundle index: corrupted {what} block')
+    if ctype != 0:
+        raise IOError('tensor bundle index: compressed table blocks are not supported (TensorFlow writes them uncompressed)')
+    return contents
+
+
+def _block_entries(block: bytes):
+    (num_restarts,) = struct.unpack('<I', block[-4:])
+    end = len(block) - 4 - 4 * num_restarts
+    pos, key = 0, b''
+    while pos < end:
+        shared, pos = _wire._read_varint(block, pos)
+        non_shared, pos = _wire._read_varint(block, pos)
+        vlen, pos = _wire._read_varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def _read_table(path: str) -> "OrderedDict[bytes, bytes]":
+    buf = open(path, 'rb').read()
+    if len(buf) < 48 or struct.unpack('<Q', buf[-8:])[0] != _TABLE_MAGIC:
+        raise IOError(f'{path}: not a TensorFlow checkpoint index (bad table magic)')
+    footer = buf[-48:]
+    pos = 0
+    _, pos = _wire._read_varint(footer, pos)            # metaindex handle
+    _, pos = _wire._read_varint(footer, pos)
+    ioff, pos = _wire._read_varint(footer, pos)
+    isize, pos = _wire._read_varint(footer, pos)
+    out = OrderedDict()
+    for _, handle in _block_entries(_read_block(buf, ioff, isize, 'index')):
+        boff, p2 = _wire._read_varint(handle, 0)
+        bsize, _ = _wire._read_varint(handle, p2)
+        for k, v in _block_entries(_read_block(buf, boff, bsize, 'data')):
+            out[bytes(k)] = bytes(v)
+    return out
+
+
+def _build_block(entries, restart_interval: int = 16) -> bytes:
+    out, restarts, prev = bytearray(), [], b''
+    for i, (k, v) in enumerate(entries):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(out))
+        else:
+            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                shared += 1
+        out += _wire._varint(shared) + _wire._varint(len(k) - shared) + _wire._varint(len(v)) + k[shared:] + v
+        prev = k
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack('<I', r)
+    out += struct.pack('<I', len(restarts))
+    return bytes(out)
+
+
+def _write_table(path: str, items, block_bytes: int = 4096) -> None:
+    f = bytearray()
+    index = []
+
+    def emit(block: bytes) -> bytes:
+        off = len(f)
+        f.extend(block)
+        f.append(0)                                                     # kNoCompression
+        f.extend(struct.pack('<I', _mask(_wire.crc32c(block + b'\x00'))))
+        return _wire._varint(off) + _wire._varint(len(block))
+    cur, cur_bytes = [], 0
+    for k, v in items:                                                  # keys must arrive sorted
+        cur.append((k, v))
+        cur_bytes += len(k) + len(v) + 3
+        if cur_bytes >= block_bytes:
+            index.append((cur[-1][0], emit(_build_block(cur))))
+            cur, cur_bytes = [], 0
+    if cur:
+        index.append((cur[-1][0], emit(_build_block(cur))))
+    meta = emit(_build_block([]))
+    idx = emit(_build_block(index, restart_interval=1))
+    footer = meta + idx
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', _TABLE_MAGIC)
+    f.extend(footer)
+    with open(path, 'wb') as out:
+        out.write(bytes(f))
+
+
+# ------------------------------------------------------------------------------------------------ tensor bundle
+def _shape_proto(shape) -> bytes:
+    return b''.join(_wire._ld(2, _wire._varint((1 << 3) | 0) + _wire._varint(int(d))) for d in shape)
+
+
+def _entry_proto(dtype: int, shape, shard: int, offset: int, size: int, crc: int) -> bytes:
+    out = _wire._varint((1 << 3) | 0) + _wire._varint(dtype) + _wire._ld(2, _shape_proto(shape))
+    if shard:
+        out += _wire._varint((3 << 3) | 0) + _wire._varint(shard)
+    if offset:
+        out += _wire._varint((4 << 3) | 0) + _wire._varint(offset)
+    out += _wire._varint((5 << 3) | 0) + _wire._varint(size)
+    out += _wire._varint((6 << 3) | 5) + struct.pack('<I', crc)
+    return out
+
+
+def _parse_entry(buf: bytes):
+    e = dict(dtype=0, shape=[], shard=0, offset=0, size=0, crc=None, sliced=False)
+    for field, wt, val in _wire._fields(memoryview(buf)):
+        if field == 1:
+            e['dtype'] = val
+        elif field == 2:
+            for f2, _, dim in _wire._fields(val):
+                if f2 == 2:
+                    size = 0
+                    for f3, _, v3 in _wire._fields(dim):
+                        if f3 == 1:
+                            size = v3
+                    e['shape'].append(size)
+        elif field == 3:
+            e['shard'] = val
+        elif field == 4:
+            e['offset'] = val
+        elif field == 5:
+            e['size'] = val
+        elif field == 6:
+            (e['crc'],) = struct.unpack('<I', bytes(val))
+        elif field == 7:
+            e['sliced'] = True
+    return e
+
+
+def read_tensor_bundle(prefix: str, check_crc: bool = True) -> "OrderedDict[str, np.ndarray]":
+    """every numeric tensor of ``<prefix>.index`` / ``<prefix>.data-?????-of-?????`` (string tensors — the object graph —
+    are skipped)"""
+    table = _read_table(prefix + '.index')
+    num_shards = 1
+    if _HEADER_KEY in table:
+        for field, _, val in _wire._fields(memoryview(table[_HEADER_KEY])):
+            if field == 1:
+                num_shards = val
+            elif field == 2 and val != 0:
+                raise IOError('big-endian tensor bundles are not supported')
+    shards = {}
+    out = OrderedDict()
+    for key, raw in table.items():
+        if key == _HEADER_KEY:
+            continue
+        e = _parse_entry(raw)
+        if e['dtype'] == _DT_STRING or e['sliced']:
+            continue
+        if e['dtype'] == _DT_BFLOAT16:
+            dt = np.dtype('<u2')
+        elif e['dtype'] in _DT:
+            dt = _DT[e['dtype']]
+        else:
+            raise IOError(f'{key!r}: unsupported tensor dtype {e["dtype"]}')
+        if e['shard'] not in shards:
+            shards[e['shard']] = np.memmap(f'{prefix}.data-{e["shard"]:05d}-of-{num_shards:05d}', dtype=np.uint8, mode='r')
+        blob = shards[e['shard']][e['offset']:e['offset'] + e['size']]
+        if check_crc and e['crc'] is not None and _mask(_crc32c(np.ascontiguousarray(blob))) != e['crc']:
+            raise IOError(f'{key!r}: tensor data corrupted (CRC mismatch)')
+        arr = np.frombuffer(bytes(blob), dtype=dt).reshape(e['shape'])
+        if e['dtype'] == _DT_BFLOAT16:
+            arr = (arr.astype(np.uint32) << 16).view(np.float32)
+        out[key.decode('utf-8')] = arr
+    return out
+
+
+def write_tensor_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
+    """one-shard TensorBundle with the same layout TensorFlow's BundleWriter produces (keys sorted, header entry first)"""
+    os.makedirs(os.path.dirname(prefix) or '.', exist_ok=True)
+    items, offset = [], 0
+    with open(prefix + '.data-00000-of-00001', 'wb') as data:
+        for key in sorted(tensors):
+            arr = np.asarray(tensors[key])
+            if not arr.flags.c_contiguous:
+                arr = arr.copy(order='C')                              # (ascontiguousarray would turn a scalar into [1])
+            arr = arr.astype(arr.dtype.newbyteorder('<')) if arr.dtype.byteorder == '>' else arr
+            raw = arr.tobytes()
+            data.write(raw)
+            items.append((key.encode('utf-8'), _entry_proto(_DT_INV[np.dtype(arr.dtype.str.replace('=', '<'))] if arr.dtype != np.bool_
+                                                            else 10, arr.shape, 0, offset, len(raw), _mask(_crc32c(arr)))))
+            offset += len(raw)
+    # BundleHeaderProto: num_shards = 1, endianness = LITTLE (0, omitted), version { producer = 1 }
+    header = _wire._varint((1 << 3) | 0) + _wire._varint(1) + _wire._ld(3, _wire._varint((1 << 3) | 0) + _wire._varint(1))
+    _write_table(prefix + '.index', [(_HEADER_KEY, header)] + items)
+
+
+# ------------------------------------------------------------------------------------------------ name mapping
+_SUFFIX = '/.ATTRIBUTES/VARIABLE_VALUE'
+_IGNORED_PREFIXES = ('optimizer', '_CHECKPOINTABLE_OBJECT_GRAPH', 'save_counter', 'global_step', 'pose_loss_weighting_criterion')
+
+
+def keras_to_state_dict(bundle: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """TF checkpoint keys -> the state-dict keys of ``viewformer_amd.MIGT`` (= the reference's Keras attribute paths,
+    migt.py:288-292): object-graph keys (``h/0/attn/c_attn/weight/.ATTRIBUTES/VARIABLE_VALUE``) and name-based keys
+    (``migt/h.0/attn/c_attn/weight``) both map to ``h.0.attn.c_attn.weight``; ``wpe`` (a bare variable, :306-315) maps to
+    ``wpe.embeddings``; Conv1D biases are stored ``[1, nf]`` (:87) and come back flat; optimizer slots are dropped."""
+    out = OrderedDict()
+    for key, arr in bundle.items():
+        k = key[:-len(_SUFFIX)] if key.endswith(_SUFFIX) else key
+        if '.OPTIMIZER_SLOT' in k or k.split('/')[0] in _IGNORED_PREFIXES:
+            continue
+        parts = k.split('/')
+        while parts and parts[0] not in ('h', 'wte', 'wpe', 'ln_f', 'pose_embedding', 'pose_criterion') \
+                and not parts[0].startswith('h.'):
+            parts = parts[1:]                                           # leading model / name scopes
+        if not parts:
+            continue
+        name = '.'.join(parts)
+        if name in ('wpe', 'wpe.wpe'):
+            name = 'wpe.embeddings'
+        if name.endswith('.bias') and arr.ndim == 2 and arr.shape[0] == 1:
+            arr = arr.reshape(-1)
+        out[name] = np.asarray(arr, dtype=np.float32)
+    return out
+
+
+def state_dict_to_keras(sd: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """inverse of :func:`keras_to_state_dict` (object-graph keys), for exporting weights to the reference"""
+    out = OrderedDict()
+    for name, arr in sd.items():
+        arr = np.asarray(arr.detach().cpu().numpy() if hasattr(arr, 'detach') else arr, dtype=np.float32)
+        key = 'wpe' if name == 'wpe.embeddings' else name.replace('.', '/')
+        if name.endswith('.bias') and ('.c_' in name):
+            arr = arr.reshape(1, -1)
+        out[key + _SUFFIX] = arr
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ torch checkpoints
+def read_torch_checkpoint(path: str) -> "OrderedDict[str, np.ndarray]":
+    """``torch.load(path)['state_dict']`` (Lightning ``.ckpt``; a bare state dict ``.pth`` is accepted too) as numpy"""
+    import torch
+    data = torch.load(path, map_location='cpu', weights_only=True)
+    sd = data['state_dict'] if isinstance(data, dict) and 'state_dict' in data else data
+    return OrderedDict((k, v.detach().cpu().numpy()) for k, v in sd.items() if hasattr(v, 'detach'))
+
+
+# ------------------------------------------------------------------------------------------------ load_model
+def load_model(checkpoint: str, device=None, **config_overrides):
+    """``load_model(path_or_name, **config_overrides)`` (utils/tensorflow.py:20, utils/torch.py:9): ``checkpoint`` is
+    ``<model dir>/<file>`` where the file is ``*.ckpt`` / ``*.pth`` (torch) or the TF prefix (``model`` for
+    ``model.index``).  Overrides update ``config.json`` before the config object is built (``pose_multiplier``,
+    evaluate_transformer.py:205-208).  Network checkpoint names cannot be pulled here (no egress): a missing directory raises."""
+    model_path, ckpt = os.path.split(checkpoint)
+    cfg_file = os.path.join(model_path, 'config.json')
+    if not os.path.exists(cfg_file):
+        raise FileNotFoundError(f'{cfg_file} not found (downloading named checkpoints is not available offline)')
+    with open(cfg_file) as f:
+        cfg = json.load(f)
+    cfg.update(config_overrides)
+    config = load_config(cfg)
+    is_th = ckpt.endswith('.pth') or ckpt.endswith('.ckpt')
+    if isinstance(config, VQGANConfig):
+        from .vqgan import VQGAN
+        if not is_th:
+            raise RuntimeError('codebook models ship as torch checkpoints (*.ckpt); got a TF prefix')
+        model = VQGAN(config, data_format='NHWC')           # evaluators use the TF (NHWC) convention
+        model.load_state_dict(read_torch_checkpoint(os.path.join(model_path, ckpt)))
+    elif isinstance(config, MIGTConfig):
+        from .migt import MIGT
+        model = MIGT(config)
+        if is_th:
+            sd = read_torch_checkpoint(os.path.join(model_path, ckpt))
+        else:
+            sd = keras_to_state_dict(read_tensor_bundle(os.path.join(model_path, ckpt)))
+        model.load_state_dict(sd)
+    else:
+        raise RuntimeError(f'unsupported model config {type(config).__name__}')
+    return model.to(device) if device is not None else model

@@ -293,4 +293,32 @@ int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* 
     return vf_last_status();
 }
 
+/* host-side CRC-32C (Castagnoli, reflected; slicing-by-8) for the TFRecord / TensorBundle wire formats the reference's
+ * datasets and Keras checkpoints use (tensorflow/core/lib/hash/crc32c.h).  crc = 0 starts a new checksum. */
+uint32_t vf_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+            T[0][i] = c;
+        }
+        for (int t = 1; t < 8; ++t)
+            for (uint32_t i = 0; i < 256; ++i) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    crc = ~crc;
+    while (n >= 8) {
+        const uint32_t lo = crc ^ ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+        crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^ T[3][p[4]] ^ T[2][p[5]] ^
+              T[1][p[6]] ^ T[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+
 }  // extern "C"

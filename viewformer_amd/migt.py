@@ -95,6 +95,9 @@ class MIGT:
             self._upload()
         return self
 
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(v)) for k, v in self._sd_host.items())
+
     def _upload(self):
         dev, h, c = self.device, self._sd_host, self.config
 
