@@ -166,6 +166,11 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
 int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, float* out,
                              int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
                              float scale, int skip_masked, int twin_view, void* stream);
+/* same contract, fp32-EQUIVALENT on the bf16 pipe (x6: every operand split into three bf16 pieces, six partial products per
+ * fp32 product, fp32 softmax) — the default attention of the fp32 transformer arm */
+int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float* out,
+                           int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                           float scale, int skip_masked, int twin_view, void* stream);
 /* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
 int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
 

@@ -184,3 +184,47 @@ def test_migt_logits_x6_vs_native_f32(dev):
         errs[arith] = ((lg.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     print(f'logit error vs fp64 (relative to max |logit|): native f32 {errs["f32"]:.2e}, x6 {errs["x6"]:.2e}')
     assert errs['x6'] < 1e-4 and errs['x6'] < 2.0 * errs['f32'] + 1e-6
+
+
+def _attn_oracle(qkv, B, H, T, L, d):
+    from oracle import migt_oracle as mg
+    x = qkv.double().view(B, T // L, L, 3 * d)
+    v, q, k = x.chunk(3, -1)
+    sp = lambda t: mg._split_heads(t, H)
+    return mg._merge_heads(mg.compute_causal_block_attention(sp(k), sp(v), sp(q))).reshape(B * T, d)
+
+
+@pytest.mark.parametrize('B,H,S,L,scale', [(2, 2, 4, 16, 0.35), (1, 12, 7, 64, 0.35), (1, 2, 5, 48, 0.35), (1, 2, 4, 64, 2.0)])
+def test_attention_x6_is_fp32_equivalent(dev, B, H, S, L, scale):
+    """x6 attention vs the fp64 oracle: error no larger than the native f32-MFMA kernel's (incl. |q.k| in the hundreds)"""
+    from viewformer_amd import ops
+    d, T = H * 64, S * L
+    qkv = _rand((B * T, 3 * d), 71, scale)
+    ref = _attn_oracle(qkv, B, H, T, L, d)
+    g = qkv.to(dev)
+    o6, o32, o6d = (torch.empty((B * T, d), device=dev) for _ in range(3))
+    a = (g[:, d:2 * d], g[:, 2 * d:], g[:, :d])
+    ops.attn_blockcausal(*a, o6, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, x6=True)
+    ops.attn_blockcausal(*a, o6d, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, False, x6=True)
+    ops.attn_blockcausal(*a, o32, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True)
+    assert torch.equal(o6, o6d)                          # skipping masked tiles == the dense "-1e4" form
+    e6 = (o6.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    e32 = (o32.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'attention B={B} H={H} S={S} L={L} scale={scale}: x6 {e6:.2e} | native f32 {e32:.2e}')
+    assert e6 < 1e-4 and e6 < 1.5 * e32 + 1e-7
+
+
+@pytest.mark.parametrize('mode', ['twin', 'streams'])
+def test_attention_x6_masks(dev, mode):
+    from viewformer_amd import ops
+    B, H, S, L = 2, 3, 4, 64
+    d = H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = S - 2 if mode == 'twin' else -S
+    qkv = _rand((B * T, 3 * d), 5, 0.35).to(dev)
+    a = (qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d])
+    o6, o32 = torch.empty((B * T, d), device=dev), torch.empty((B * T, d), device=dev)
+    ops.attn_blockcausal(*a, o6, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec, x6=True)
+    ops.attn_blockcausal(*a, o32, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec)
+    assert (o6 - o32).abs().max().item() < 2e-5 * o32.abs().max().item()

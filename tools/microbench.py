@@ -78,14 +78,14 @@ def vq(M=64 * 448):
     print(f'vq_argmin M={M}: {ms:.4f} ms  {2.0 * M * 256 * 1024 / ms / 1e9:.1f} TF  {by / ms / 1e6:.1f} GB/s algorithmic')
 
 
-def attn(B=32, H=12, S=8, L=64, bf16=False):
+def attn(B=32, H=12, S=8, L=64, bf16=False, x6=False):
     d, T = H * 64, S * L
     qkv = torch.randn(B * T, 3 * d, device=dev) * 0.3
     out = torch.empty(B * T, d, device=dev)
     ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
-                                             3 * d, d, 1.0, True, bf16=bf16))
+                                             3 * d, d, 1.0, True, bf16=bf16, x6=x6))
     useful = 4.0 * H * 64 * L * L * S * (S + 1) / 2 * B
-    print(f'attn{"[bf16]" if bf16 else ""} B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
+    print(f'attn{"[bf16]" if bf16 else "[x6]" if x6 else ""} B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
 
 
 def gn(n_img=56, C=128, HW=16384):
@@ -106,7 +106,7 @@ def convin(n_img=224, H=128, C=128):
 
 ALL = dict(convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True),
-           attnbf16=lambda: attn(bf16=True),
+           attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),

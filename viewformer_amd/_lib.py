@@ -52,6 +52,8 @@ EXPORTS = {
                                         c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_float, c_int, c_int, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
     'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),

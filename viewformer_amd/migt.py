@@ -191,7 +191,8 @@ class MIGT:
             self._dense_launch(a, ca, M, qkv)
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
-                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16')
+                                 3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16',
+                                 x6=self.precision == 'f32' and self.dense_arith == 'x6')
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)

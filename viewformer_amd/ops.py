@@ -301,8 +301,13 @@ def codebook_gather(E, idx, D, Kc):
 
 
 # ------------------------------------------------------------------ attention / transformer glue
-def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1, bf16=False):
+def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1, bf16=False, x6=False):
     lib = _lib.load()
+    if x6:
+        check(lib.vf_attn_blockcausal_x6(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
+                                         ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
+              'vf_attn_blockcausal_x6')
+        return out
     if bf16:
         check(lib.vf_attn_blockcausal_bf16(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
                                            ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
