@@ -31,6 +31,10 @@
 #define VF_X6_SB 1        // 1: __builtin_amdgcn_sched_barrier(0) at every stage boundary (pins the prefetch distance: the
                           // scheduler otherwise sinks the ring loads next to their uses); 2: also between loads and MFMAs
 #endif
+#ifndef VF_X6_PRIO
+#define VF_X6_PRIO 0      // > 0: raise the wave priority (s_setprio) while a stage's MFMAs issue (measured: 215 -> 180 TF);
+                          // < 0: raise it for everything BUT the MFMAs (loads, staging)
+#endif
 #ifndef VF_X6_PRECISE_SWISH
 #define VF_X6_PRECISE_SWISH 0
 #endif
@@ -226,6 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
             // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            if (VF_X6_PRIO > 0) __builtin_amdgcn_s_setprio(VF_X6_PRIO);
+            if (VF_X6_PRIO < 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -233,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi][PA[t]], bring[s % RING][PB[t]][j], acc[mi][j], 0, 0, 0);
+            if (VF_X6_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+            if (VF_X6_PRIO < 0) __builtin_amdgcn_s_setprio(-VF_X6_PRIO);
             // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
             if (VF_X6_SB == 1) __builtin_amdgcn_sched_barrier(0);
             if ((s & 1) && (s >> 1) >= VF_X6_STORE && (s >> 1) - VF_X6_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X6_STORE);

@@ -26,8 +26,11 @@ def init_from_env(backend: str = None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available() and backend != 'gloo':
+        torch.cuda.set_device(local)                      # bind this rank's GPU BEFORE RCCL creates its communicator
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (the host driver has no legacy IPC)
         dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
                                 rank=rank, world_size=world)
     return rank, local, world
