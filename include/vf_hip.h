@@ -77,7 +77,8 @@ typedef struct vf_igemm_args {
      * vf_groupnorm_finalize_f32.  gn_slots must equal vf_conv3_halo_gn_slots(Hout, Wout). */
     float* gn_part;
     int32_t gn_slots;
-    int32_t reserved0;
+    int32_t reserved0;       /* vf_gemm_x6 only: split-K count S > 1 -> S raw partial slabs at out + s*stride_out (no bias /
+                              * residual / epilogue), to be summed by vf_sum_slabs_f32; 0 or 1 = off */
 } vf_igemm_args;
 
 /* floats needed for the packed form of a [taps][K][N] weight (K,N padded to the tile) */
@@ -230,12 +231,28 @@ int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);
 size_t vf_gemm_x6_packed_elems(int K, int N);             /* number of bf16 elements (3 planes) */
 int vf_gemm_x6_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, void* stream);
 int vf_gemm_x6(const vf_igemm_args* args /* host */, void* stream);
+/* dst[i] (+)= sum_s slabs[s*stride + i], s ascending (fixed order): the reduction of a split-K GEMM */
+int vf_sum_slabs_f32(const float* slabs, int nslabs, int64_t stride, int64_t n, float* dst, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.
  * ------------------------------------------------------------------------------------- */
+/* attention of the training graph with its backward (flash-style: probabilities re-materialised per tile from the saved
+ * per-query log-sum-exp, masked tiles skipped, deterministic — no atomics).  Replaces the autograd of compute_attention /
+ * compute_causal_block_multiend_attention (branching_attention.py:5-18,82-126) inside MIGT.train_step (migt.py:464-505).
+ *   forward with statistics: vf_attn_blockcausal_f32 + lse[B][H][T] = log sum_k exp(score)
+ *   prep:  D[B][H][T] = rowsum(dOut * Out)
+ *   bwd:   dq, dk, dv [B*T][ld*] (any column offsets / strides: the (V,Q,K) thirds of one buffer are fine) */
+int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                                int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                                float scale, int skip_masked, int twin_view, void* stream);
+int vf_attn_bwd_prep_f32(const float* dout, const float* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
+int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* D,
+                    float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo,
+                    int lddq, int lddk, int lddv, float scale, int twin_view, void* stream);
+
 /* dst[c][r] = src[r][c], `batch` matrices with strides (floats) */
 int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
                      int64_t bs_src, int64_t bs_dst, void* stream);

@@ -228,3 +228,26 @@ def test_attention_x6_masks(dev, mode):
     ops.attn_blockcausal(*a, o6, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec, x6=True)
     ops.attn_blockcausal(*a, o32, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec)
     assert (o6 - o32).abs().max().item() < 2e-5 * o32.abs().max().item()
+
+
+@pytest.mark.parametrize('M,K,N,S', [(768, 4096, 768, 4), (256, 1920, 384, 7), (128, 64, 128, 3)])
+def test_gemm_x6_split_k(dev, M, K, N, S):
+    """split-K (the training step's dW GEMMs): slabs + ordered sum == the unsplit GEMM to fp32 rounding, accumulate semantics"""
+    from viewformer_amd import ops
+    x, w = _rand((M, K), 1), _rand((K, N), 2, 0.1)
+    wp = ops.pack_dense_kn_x6(w.to(dev))
+    base = _rand((M, N), 3).to(dev)
+    dst = base.clone()
+    ops.gemm_x6_splitk(x.to(dev), wp, M, K, N, dst, S)
+    ref = base.double().cpu() + x.double() @ w.double()
+    mag = base.double().cpu().abs() + x.double().abs() @ w.double().abs()
+    assert ((dst.double().cpu() - ref).abs() / mag).max().item() < 6e-7
+    dst2 = torch.full((M, N), float('nan'), device=dev)
+    ops.gemm_x6_splitk(x.to(dev), wp, M, K, N, dst2, S, accumulate=False)
+    one = torch.empty((M, N), device=dev)
+    ops.igemm(x.to(dev), wp, M, K, N, one, x6=True)
+    assert (dst2 - one).abs().max().item() < 1e-5 * one.abs().max().item()
+    ops.gemm_x6_splitk(x.to(dev), wp, M, K, N, dst2, S, accumulate=False)          # deterministic
+    d3 = dst2.clone()
+    ops.gemm_x6_splitk(x.to(dev), wp, M, K, N, dst2, S, accumulate=False)
+    assert torch.equal(d3, dst2)

@@ -236,3 +236,69 @@ def test_per_tensor_gradient_clipping(dev):
         from viewformer_amd.weights import make_migt_weights
         c2 = MIGTConfig(**TINY_MIGT)                           # default dropout 0.1
         MIGTTrainer(MIGT(c2).load_state_dict(make_migt_weights(c2)).to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,S,L,mode', [(2, 2, 3, 64, 'streams'), (1, 3, 4, 64, 'causal'), (2, 1, 5, 16, 'streams'),
+                                          (1, 2, 3, 48, 'causal'), (1, 2, 4, 64, 'twin')])
+def test_flash_attention_backward_matches_autograd(dev, B, H, S, L, mode):
+    """vf_attn_bwd_f32 (probabilities re-materialised from the saved log-sum-exp, masked tiles skipped) against fp64 autograd of
+    the oracle's compute_causal_block[_multiend]_attention — every mask mode, tile-aligned (L = 64) and ragged (L = 16, 48) views"""
+    from oracle import migt_oracle as mg
+    from viewformer_amd import train_ops as T
+    d = H * 64
+    NS = 3 if mode == 'streams' else 1
+    Tn = NS * S * L
+    spec = {'causal': -1, 'twin': S - 2, 'streams': -S}[mode]
+    g = np.random.Generator(np.random.PCG64(3))
+    qkv = torch.from_numpy((g.standard_normal((B * Tn, 3 * d)) * 0.4).astype(np.float32))
+    dout = torch.from_numpy(g.standard_normal((B * Tn, d)).astype(np.float32))
+    x = qkv.double().requires_grad_(True)
+    if mode == 'streams':
+        xs = x.view(B, NS, S, L, 3 * d)
+        ks, vs, qs = [], [], []
+        for s in range(NS):
+            v, q, k = xs[:, s].chunk(3, -1)
+            ks.append(mg._split_heads(k, H)); vs.append(mg._split_heads(v, H)); qs.append(mg._split_heads(q, H))
+        out = torch.stack([mg._merge_heads(a) for a in mg.compute_causal_block_multiend_attention(ks, vs, qs)], 1).reshape(B * Tn, d)
+    else:
+        v, q, k = x.view(B, S, L, 3 * d).chunk(3, -1)
+        sp = lambda t: mg._split_heads(t, H)
+        if mode == 'twin':
+            # twin views Vc.. : each sees views < Vc and itself -> dense attention with that mask
+            view = torch.arange(S).repeat_interleave(L)
+            Vc = spec
+            vis = (view[None, :] == view[:, None]) | (torch.minimum(view[None, :], torch.tensor(Vc)) < torch.minimum(view[:, None], torch.tensor(Vc)))
+            qh, kh, vh = (sp(t).reshape(B, H, S * L, 64) for t in (q, k, v))
+            w = qh @ kh.transpose(-1, -2)
+            m = vis.double()
+            w = w * m - 1e4 * (1 - m)
+            a = torch.softmax(w, -1) @ vh
+            out = a.permute(0, 2, 1, 3).reshape(B * Tn, d)
+        else:
+            out = mg._merge_heads(mg.compute_causal_block_attention(sp(k), sp(v), sp(q))).reshape(B * Tn, d)
+    out.backward(dout.double())
+    ref = x.grad
+    gq = qkv.to(dev)
+    att = torch.empty((B * Tn, d), device=dev)
+    lse = T.attn_fwd_lse(gq[:, d:2 * d], gq[:, 2 * d:], gq[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec)
+    assert (att.double().cpu() - out.detach()).abs().max().item() < 3e-5
+    dqkv = torch.full((B * Tn, 3 * d), float('nan'), device=dev)
+    T.attn_bwd(gq[:, d:2 * d], gq[:, 2 * d:], gq[:, :d], att, dout.to(dev), lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
+               B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+    err = (dqkv.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'flash attention backward {mode} L={L}: rel err {err:.2e}')
+    assert err < 2e-5
+
+
+@pytest.mark.gpu
+def test_flash_and_dense_attention_backward_agree_in_the_train_step(dev):
+    grads = {}
+    for mode in ('flash', 'dense'):
+        cfg, sd, tokens, poses, tr = _setup(True, dev)
+        tr.attention_backward = mode
+        tr.step_count = 3
+        tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+        grads[mode] = tr.flat_g.clone()
+    rel = ((grads['flash'] - grads['dense']).abs().max() / grads['dense'].abs().max()).item()
+    assert rel < 2e-5, rel

@@ -54,6 +54,11 @@ EXPORTS = {
                                          c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_float, c_int, c_int, P]),
+    'vf_attn_bwd_prep_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_float, c_int, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
     'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
@@ -74,6 +79,7 @@ EXPORTS = {
     'vf_gemm_x6_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_gemm_x6_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, P]),
     'vf_gemm_x6': (c_int, [POINTER(VfIgemmArgs), P]),
+    'vf_sum_slabs_f32': (c_int, [P, c_int, c_int64, c_int64, P, c_int, P]),
     # ---- training step
     'vf_transpose_f32': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, c_int64, P]),
     'vf_colsum_workspace_bytes': (c_size_t, [c_int]),

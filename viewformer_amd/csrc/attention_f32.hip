@@ -29,7 +29,7 @@ constexpr int VT_LD = 68;    // V is parked TRANSPOSED ([feature][key]) so a lan
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int skip_masked, int twin) {
+                                                                  float scale, int skip_masked, int twin, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vt[DH * VT_LD];
 
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
 
     // ---- normalise and store: lane = query, regs 4j..4j+3 = 4 consecutive features -------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    // log-sum-exp of the (scaled, masked) scores of this query: what the backward pass needs to re-materialise P
+    if (lse && qvalid && half == 0) lse[((size_t)b * gridDim.y + h) * T + qrow] = m_run + logf(l_tot);
     if (qvalid) {
         float* orow = ob + (size_t)qrow * ldo + 4 * half;
 #pragma unroll
@@ -253,7 +255,19 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view);
+                       ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr);
+    return vf_last_status();
+}
+
+int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int T,
+                                int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
+                                void* stream) {
+    if (!q || !k || !v || !out || !lse || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
+    if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
+    if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
+    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
+                       ldv, ldo, scale, skip_masked, twin_view, lse);
     return vf_last_status();
 }
 

@@ -53,7 +53,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(vf_igemm_args p) {
     const float* __restrict__ X = p.x;
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * CHUNK_BYTES;
     const size_t chunk_stride = (size_t)nb * CHUNK_BYTES;
-    const int nchunks = p.Cin / CK;
+    // split-K (reserved0 = number of splits, blockIdx.y = split): each split reduces an even-sized range of the 32-deep chunks
+    // into its own [M][ldc] slab at out + split * stride_out (the caller sums the slabs in a fixed order: deterministic)
+    const int nsplit = p.reserved0 > 1 ? p.reserved0 : 1;
+    const int total_chunks = p.Cin / CK;
+    const int per = ((total_chunks + nsplit - 1) / nsplit + 1) & ~1;
+    const int c0 = min((int)blockIdx.y * per, total_chunks);
+    const int nchunks = min(c0 + per, total_chunks);            // exclusive end of this split's range
 
     // A staging: thread -> float4 column (tid & 7) of rows (tid >> 3) + 32 q
     const int c4 = tid & 7, r0 = tid >> 3;
@@ -123,14 +129,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(vf_igemm_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    a_fetch(0);
-    b_load(bring[0], 0);
+    a_fetch(min(c0, total_chunks - 1));
+    b_load(bring[0], c0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) a_park(0, q);
     __syncthreads();
 
     auto chunk_body = [&](int chunk, bf16x8 (&bcur)[2][3][2], bf16x8 (&bnext)[2][3][2]) {
-        const unsigned char* a_src = smem_g + (chunk & 1) * A_BYTES + a_lane;
+        const unsigned char* a_src = smem_g + ((chunk - c0) & 1) * A_BYTES + a_lane;
         a_fetch(min(chunk + 1, nchunks - 1));
         b_load(bnext, chunk + 1);
         bf16x8 a[2][2][3];             // [ks][mi][plane]
@@ -152,18 +158,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(vf_igemm_args p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi][PA[t]], bcur[ks][PB[t]][j], acc[mi][j], 0, 0, 0);
-            a_park((chunk + 1) & 1, ks * 2);
-            a_park((chunk + 1) & 1, ks * 2 + 1);
+            a_park((chunk - c0 + 1) & 1, ks * 2);
+            a_park((chunk - c0 + 1) & 1, ks * 2 + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {          // nchunks is even (Cin % 64 == 0)
+    for (int chunk = c0; chunk < nchunks; chunk += 2) {          // ranges are even-sized (Cin % 64 == 0, per is even)
         chunk_body(chunk, bring[0], bring[1]);
         chunk_body(chunk + 1, bring[1], bring[0]);
     }
 
-    float* __restrict__ Out = p.out;
+    float* __restrict__ Out = p.out + (size_t)blockIdx.y * p.stride_out;
     const float* __restrict__ Res = p.res;
     const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);
     const long long ldc = p.ldc, ldr = p.ldr;
@@ -227,11 +233,21 @@ __global__ void pack_gemm_x6_kernel(const float* __restrict__ src, __bf16* __res
     }
 }
 
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long n4,
+                                 float* __restrict__ dst, int accumulate) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(dst + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nslabs; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + s * stride + i * 4);
+        *reinterpret_cast<f32x4*>(dst + i * 4) = acc;
+    }
+}
+
 template <bool PRO, bool SWISH>
 int launch(const vf_igemm_args& a, hipStream_t stream) {
     const size_t smem = (size_t)2 * A_BYTES;
     const int nb = (a.Cout + BN - 1) / BN, mt = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((gemm_x6_kernel<PRO, SWISH>), dim3((unsigned)(mt * nb)), dim3(256), smem, stream, a);
+    const int nsplit = a.reserved0 > 1 ? a.reserved0 : 1;
+    hipLaunchKernelGGL((gemm_x6_kernel<PRO, SWISH>), dim3((unsigned)(mt * nb), (unsigned)nsplit), dim3(256), smem, stream, a);
     return vf_last_status();
 }
 
@@ -254,6 +270,16 @@ int vf_gemm_x6_pack(const float* src, void* dst, int K, int N, int64_t sk, int64
     return vf_last_status();
 }
 
+int vf_sum_slabs_f32(const float* slabs, int nslabs, int64_t stride, int64_t n, float* dst, int accumulate, void* stream) {
+    if (!slabs || !dst || nslabs <= 0 || n <= 0 || (n & 3) || (stride & 3)) return VF_ERR_BAD_ARG;
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs,
+                       (long long)stride, n4, dst, accumulate);
+    return vf_last_status();
+}
+
 int vf_gemm_x6(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
@@ -261,6 +287,8 @@ int vf_gemm_x6(const vf_igemm_args* args, void* stream) {
     if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
     if (a.mode != VF_MODE_GEMM || a.batch > 1) return VF_ERR_UNSUPPORTED;
     if (a.Cin % 64 != 0) return VF_ERR_UNSUPPORTED;  // two 32-deep chunks per pipeline round
+    if (a.reserved0 > 1 && (a.bias || a.res || a.epilogue != VF_EPI_NONE || a.pro_mean || a.stride_out < (int64_t)a.M * a.ldc))
+        return VF_ERR_BAD_ARG;                       // split-K writes raw partial slabs
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta && a.pro_rows_per_img > 0))
         return VF_ERR_BAD_ARG;

@@ -138,6 +138,17 @@ def pack_dense_nk_x6(w, n_rows=None):
     return out
 
 
+def gemm_x6_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulate=True):
+    """dst[M][Cout] (+)= x @ W with the reduction split over ``splits`` workgroup groups (deterministic: slabs summed in order);
+    for GEMMs whose output has too few 128x128 tiles to fill the chip but a long reduction (the training step's dW)"""
+    lib = _lib.load()
+    slabs = torch.empty((splits, M, Cout), dtype=torch.float32, device=x.device)
+    igemm(x, w_packed, M, Cin, Cout, slabs, lda=lda, x6=True, split_k=splits, stride_out=M * Cout)
+    check(lib.vf_sum_slabs_f32(_p(slabs), splits, M * Cout, M * Cout, _p(_f32(dst)), 1 if accumulate else 0, _stream()),
+          'vf_sum_slabs_f32')
+    return dst
+
+
 def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
     """shape rules of vf_conv3_halo_x6 (host-side mirror so callers can pick the packing up front)"""
     if mode not in (MODE_CONV3_S1, MODE_CONV3_UP2, MODE_CONV3_S2PAD) or Cin % 32 or Cout % 128:
@@ -147,7 +158,7 @@ def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
 
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
-          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None):
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
@@ -174,6 +185,7 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     a.ldr = (Cout if ldr is None else ldr)
     a.batch = batch
     a.stride_x, a.stride_w, a.stride_out, a.stride_res = stride_x, stride_w, stride_out, stride_res
+    a.reserved0 = split_k                     # vf_gemm_x6: number of split-K slabs written at out + s*stride_out
     if gn_part is not None:
         a.gn_part = _f32(gn_part).data_ptr()
         a.gn_slots = gn_part.shape[1]

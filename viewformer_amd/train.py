@@ -125,18 +125,23 @@ class MIGTTrainer:
         self.repack()
 
     def repack(self):
+        """refresh every packed form of the (just updated) weights: native-f32 packings always (odd shapes, the LM head, the
+        pose heads), and with ``dense_arith='x6'`` the fp32-equivalent split packings the dense layers actually run on —
+        forward W, and W^T for dX (x6 GEMMs are ~1.8x the native ones; the packers are a few launches per layer)"""
         m, c = self.model, self.cfg
-        # training runs the native f32-MFMA packings, which are rewritten in place after every update; drop the model's
-        # split-bf16 (x6) inference packings so that no forward can read stale weights
-        m._lm_head6 = None
-        for dn in m._dense.values():
-            dn.wp6 = None
         nE, d = c.n_embeddings, c.d_model
+        x6 = m.dense_arith == 'x6'
+        self.wpT6 = getattr(self, 'wpT6', {})
+        m._lm_head6 = None                                  # the LM head / pose heads stay on the native kernel in training
         for name, dn in m._dense.items():
             if dn.k % 32 == 0:
                 dn.wp = ops.pack(dn.w_raw, dn.k, dn.n, 1, sk=dn.n, sn=1, st=0, out=dn.wp)                  # forward: x @ W
             if dn.n % 32 == 0:                                                                                # dX = dY @ W^T
                 self.wpT[name] = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0, out=self.wpT.get(name))
+            dn.wp6 = None
+            if x6 and dn.wp is not None and dn.k % 64 == 0 and dn.n % 64 == 0:
+                dn.wp6 = ops.pack_dense_kn_x6(dn.w_raw)
+                self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
         self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
 
@@ -154,25 +159,47 @@ class MIGTTrainer:
         if Mp != M:
             xt = torch.zeros((1, K, Mp), dtype=torch.float32, device=x.device)
         xt = T.transpose(x, M, K, out=xt, ld_dst=Mp)                                 # [K][Mp]
-        dyp = ops.pack(dy, M, N, 1, sk=N, sn=1, st=0)                                # rows >= M are zero-filled by the packer
         gw = self.g(name + '.weight')
-        ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                             # dW += X^T dY
+        x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
+        if x6:
+            # dW += X^T dY: [K][N] has only (K/128)(N/128) = 36..144 tiles for 256 CUs but a reduction of M = 19200 rows
+            tiles = ((K + 127) // 128) * ((N + 127) // 128)
+            splits = max(1, min(16, 768 // tiles, M // 1024))
+            if splits > 1 and (K * N) % 4 == 0:
+                ops.gemm_x6_splitk(xt, ops.pack_dense_kn_x6(dy), K, M, N, gw, splits, lda=Mp)
+            else:
+                ops.igemm(xt, ops.pack_dense_kn_x6(dy), K, M, N, gw, res=gw, lda=Mp, x6=True)
+        else:
+            dyp = ops.pack(dy, M, N, 1, sk=N, sn=1, st=0)                            # rows >= M are zero-filled by the packer
+            ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                         # dW += X^T dY
         if not need_dx:
             return None
         dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
-        ops.igemm(dy, self.wpT[name], M, N, K, dx, res=res)
+        if x6:
+            ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
+        else:
+            ops.igemm(dy, self.wpT[name], M, N, K, dx, res=res)
         return dx
 
     def _ln_bwd(self, name, dy, x, M):
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
 
-    def _attn_bwd(self, qkv, datt, B, Tn, L, spec):
-        """dQKV from dA by re-materialising P per head (branching_attention.py:82-126 semantics)"""
+    attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
+
+    def _attn_bwd(self, qkv, datt, B, Tn, L, spec, att=None, lse=None):
+        """dQKV from dA (branching_attention.py:82-126 semantics).  'flash': one pair of kernels per layer re-materialises the
+        probabilities tile by tile from the saved log-sum-exp and skips masked tiles; 'dense': per head with batched GEMMs."""
         c = self.cfg
         d, H = c.d_model, c.n_head
         M = B * Tn
         dqkv = torch.empty((M, 3 * d), dtype=torch.float32, device=qkv.device)
+        if self.attention_backward == 'flash' and att is not None and lse is not None:
+            # thirds are (V, Q, K) (migt.py:207-213): gradients land in the same thirds of dqkv
+            T.attn_bwd(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse,
+                       dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d], B, H, Tn, L,
+                       3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+            return dqkv
         S = torch.empty((B, Tn, Tn), dtype=torch.float32, device=qkv.device)
         dP = torch.empty_like(S)
         pf_T = ops.packed_floats(64, Tn)
@@ -242,14 +269,13 @@ class MIGTTrainer:
             n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d)
             qkv = self._linear(n1, p + '.attn.c_attn', M)
             att = torch.empty((M, d), dtype=torch.float32, device=dev)
-            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0,
-                                 True, -S)
+            lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S)
             h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
             n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d)
             u = self._linear(n2, p + '.mlp.c_fc', M)
             f = T.gelu(u)
             h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
-            saved.append((h, n1, qkv, att, h_mid, n2, u, f))
+            saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
             h = h_out
         hf = ops.layernorm(h, *m._ln['ln_f'], M, d).view(B, NS, S, L, d)
 
@@ -309,13 +335,13 @@ class MIGTTrainer:
         overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
-            h_in, n1, qkv, att, h_mid, n2, u, f = saved[i]
+            h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
             df = self._linear_bwd(p + '.mlp.c_proj', f, dh, M)
             du = T.gelu_bwd(u, df)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
             dh_mid = T.add_(self._ln_bwd(p + '.ln_2', dn2, h_mid, M), dh)
             datt = self._linear_bwd(p + '.attn.c_proj', att, dh_mid, M)
-            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S)
+            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse)
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
             dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
             saved[i] = None

@@ -115,3 +115,22 @@ def add_(a, b):
 def clip_by_norm_(x, clip, scratch1):
     check(_lib.load().vf_clip_by_norm_f32(_p(_f32(x)), x.numel(), clip, _p(scratch1), _stream()), 'vf_clip_by_norm_f32')
     return x
+
+
+def attn_fwd_lse(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1):
+    """forward attention that also returns the per-query log-sum-exp [B,H,T] the flash backward needs"""
+    lib = _lib.load()
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    check(lib.vf_attn_blockcausal_lse_f32(_p(q), _p(k), _p(v), _p(out), _p(lse), B, H, T, L, ldq, ldk, ldv, ldo, scale, 1,
+                                          mask_spec, _stream()), 'vf_attn_blockcausal_lse_f32')
+    return lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0,
+             mask_spec=-1):
+    """dQ, dK, dV of the block-causal / streams attention (written in place; the tensors may be column views)"""
+    lib = _lib.load()
+    D = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    check(lib.vf_attn_bwd_prep_f32(_p(dout), _p(out), _p(D), B, H, T, lddo, ldo, _stream()), 'vf_attn_bwd_prep_f32')
+    check(lib.vf_attn_bwd_f32(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), B, H, T, L, ldq, ldk, ldv,
+                              lddo, lddq, lddk, lddv, scale, mask_spec, _stream()), 'vf_attn_bwd_f32')
