@@ -22,6 +22,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=10)
     ap.add_argument('--seq', type=int, default=10)
+    ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
+                    help='bf16: dense GEMMs of the forward and backward pass on bf16 MFMA (fp32 master weights, fp32 attention / '
+                         'normalisation / losses / optimizer), like the reference\'s --fp16')
     args = ap.parse_args()
     from viewformer_amd import sharding
     from viewformer_amd.config import MIGTConfig
@@ -34,7 +37,7 @@ def main():
     dev = torch.device('cuda', local)
     cfg = MIGTConfig(sequence_size=args.seq, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.0,
                      learning_rate=1e-4, weight_decay=0.05, total_steps=40000, batch_size=80)
-    model = MIGT(cfg).load_state_dict(make_migt_weights(cfg, seed=0)).to(dev)
+    model = MIGT(cfg, precision=args.precision).load_state_dict(make_migt_weights(cfg, seed=0)).to(dev)
     tr = MIGTTrainer(model)
     g = np.random.Generator(np.random.PCG64(rank))
     B, S = args.batch, args.seq
@@ -56,7 +59,7 @@ def main():
         tf = 3 * 0.37 * B * world
         print(json.dumps({'metric': 'MIGT training step (fwd+bwd+AdamW), CO3D-10cat config', 'ms_per_step': round(dt * 1e3, 1),
                           'samples_per_s': round(B * world / dt, 2), 'n_gpus': world, 'scenes_per_gpu': B,
-                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': 'f32',
+                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': args.precision,
                           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -337,17 +337,24 @@ int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t l
     return vf_last_status();
 }
 
-size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)64 * N * sizeof(float) : 0; }
+size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)256 * N * sizeof(float) : 0; }
 
-int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream) {
+// rows per split 128, at most max_split splits (= rows of the [split][N] scratch the caller provides): the bias gradients of
+// the training step reduce 19200 x 768..3072 matrices, which 64 splits x 3..12 column blocks left on a fraction of the CUs
+static int colsum_launch(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, int max_split,
+                         void* stream) {
     if (!x || !out || !ws || M <= 0 || N <= 0 || ld < N) return VF_ERR_BAD_ARG;
-    int nsplit = (int)((M + 511) / 512);
-    if (nsplit > 64) nsplit = 64;
+    int nsplit = (int)((M + 127) / 128);
+    if (nsplit > max_split) nsplit = max_split;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, s, x, (float*)ws, (long long)M, N,
                        (long long)ld, nsplit);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ws, out, N, nsplit, accumulate);
     return vf_last_status();
+}
+
+int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream) {
+    return colsum_launch(x, out, M, N, ld, accumulate, ws, 256, stream);
 }
 
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
@@ -374,7 +381,7 @@ int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, fl
     // column sums of a [prow][2d] matrix -> [2d]; dgamma = first d, dbeta = second d.  Reuse colsum with a private tail of ws.
     float* tmp = (float*)ws + (size_t)prow * 2 * d;    // caller sized ws via vf_layernorm_bwd_workspace_bytes + colsum ws
     float* outv = tmp + (size_t)64 * 2 * d;
-    st = vf_colsum_f32((const float*)ws, outv, prow, 2 * d, 2 * d, 0, tmp, stream);
+    st = colsum_launch((const float*)ws, outv, prow, 2 * d, 2 * d, 0, tmp, 64, stream);     // tmp holds 64 split rows
     if (st) return st;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv, dgamma, d, 1, accumulate);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv + d, dbeta, d, 1, accumulate);

@@ -130,15 +130,21 @@ class MIGTTrainer:
         forward W, and W^T for dX (x6 GEMMs are ~1.8x the native ones; the packers are a few launches per layer)"""
         m, c = self.model, self.cfg
         nE, d = c.n_embeddings, c.d_model
-        x6 = m.dense_arith == 'x6'
+        bf16 = m.precision == 'bf16'          # the reference trains with --fp16 (mixed_float16): bf16 MFMA, fp32 master weights
+        x6 = m.dense_arith == 'x6' and not bf16
         self.wpT6 = getattr(self, 'wpT6', {})
+        self.wpT16 = getattr(self, 'wpT16', {})
+        m._lm_head16 = None
         m._lm_head6 = None                                  # the LM head / pose heads stay on the native kernel in training
         for name, dn in m._dense.items():
             if dn.k % 32 == 0:
                 dn.wp = ops.pack(dn.w_raw, dn.k, dn.n, 1, sk=dn.n, sn=1, st=0, out=dn.wp)                  # forward: x @ W
             if dn.n % 32 == 0:                                                                                # dX = dY @ W^T
                 self.wpT[name] = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0, out=self.wpT.get(name))
-            dn.wp6 = None
+            dn.wp6 = dn.wp16 = None
+            if bf16 and dn.wp is not None and dn.k % 128 == 0 and dn.n % 128 == 0:
+                dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
+                self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
             if x6 and dn.wp is not None and dn.k % 64 == 0 and dn.n % 64 == 0:
                 dn.wp6 = ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
@@ -161,7 +167,10 @@ class MIGTTrainer:
         xt = T.transpose(x, M, K, out=xt, ld_dst=Mp)                                 # [K][Mp]
         gw = self.g(name + '.weight')
         x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
-        if x6:
+        bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
+        if bf16:
+            ops.igemm(xt, ops.pack_dense_kn_bf16(dy), K, M, N, gw, res=gw, lda=Mp, bf16=True)        # dW += X^T dY
+        elif x6:
             # dW += X^T dY: [K][N] has only (K/128)(N/128) = 36..144 tiles for 256 CUs but a reduction of M = 19200 rows
             tiles = ((K + 127) // 128) * ((N + 127) // 128)
             splits = max(1, min(16, 768 // tiles, M // 1024))
@@ -175,7 +184,9 @@ class MIGTTrainer:
         if not need_dx:
             return None
         dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
-        if x6:
+        if bf16:
+            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True)
+        elif x6:
             ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
         else:
             ops.igemm(dy, self.wpT[name], M, N, K, dx, res=res)
