@@ -191,12 +191,14 @@ def main():
         value = views / dt
         gf = flops_per_view(S, localization)
         line = {
-            'metric': 'novel views/sec (encode->AR transformer->decode), 128px 6-ctx',
+            'metric': f'novel views/sec (encode->AR transformer->decode), 128px {S - 1}-ctx',
             'value': round(value, 3), 'unit': 'novel views/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32' if args.precision == 'f32' else 'bf16'), 'data': 'synthetic',
-            'config': {'workload': 'SM7 codebook+transformer, 6 context views -> 1 novel view, 128x128 '
-                                   '(BASELINE.json configs[1])',
+            'config': {'workload': ('SM7 codebook+transformer, 6 context views -> 1 novel view, 128x128 '
+                                    '(BASELINE.json configs[1])' if S == 7 else
+                                    f'InteriorNet-style {S - 1}-view context -> 1 novel view, image + localization heads, 128x128 '
+                                    '(BASELINE.json configs[2])'),
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'localization_pass': localization,
                        'target_view_encoded': True, 'parallelism': f'scene-shard x{world}, no collective',
                        'precision': ('fp32 everywhere' if args.precision == 'f32' else
