@@ -31,9 +31,8 @@
 #define VF_X6_SB 1        // 1: __builtin_amdgcn_sched_barrier(0) at every stage boundary (pins the prefetch distance: the
                           // scheduler otherwise sinks the ring loads next to their uses); 2: also between loads and MFMAs
 #endif
-#ifndef VF_X6_PRIO
-#define VF_X6_PRIO 0      // > 0: raise the wave priority (s_setprio) while a stage's MFMAs issue (measured: 215 -> 180 TF);
-                          // < 0: raise it for everything BUT the MFMAs (loads, staging)
+#ifndef VF_X6_AMID
+#define VF_X6_AMID 2      // VF_X6_SB == 3: the next stage's LDS fragments are issued before product t = AMID of this stage
 #endif
 #ifndef VF_X6_PRECISE_SWISH
 #define VF_X6_PRECISE_SWISH 0
@@ -225,24 +224,25 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
         for (int s = 0; s < 18; ++s) {
             b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
             if (AD == 0) a_load(aring[s & 1], patch, s);
-            else if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+            else if (VF_X6_SB != 3 && s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
             if (VF_X6_SB == 2) __builtin_amdgcn_sched_barrier(0);      // loads are issued before this stage's MFMAs
             // the six partial products of a*b, smallest magnitude first (plane 0 = h, 1 = m, 2 = l)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-            if (VF_X6_PRIO > 0) __builtin_amdgcn_s_setprio(VF_X6_PRIO);
-            if (VF_X6_PRIO < 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 6; ++t) {
+                if (VF_X6_SB == 3 && t == VF_X6_AMID) {                // LDS fragments of the next stage issued mid-stage
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi][PA[t]], bring[s % RING][PB[t]][j], acc[mi][j], 0, 0, 0);
-            if (VF_X6_PRIO > 0) __builtin_amdgcn_s_setprio(0);
-            if (VF_X6_PRIO < 0) __builtin_amdgcn_s_setprio(-VF_X6_PRIO);
+            }
             // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
-            if (VF_X6_SB == 1) __builtin_amdgcn_sched_barrier(0);
+            if (VF_X6_SB == 1 || VF_X6_SB == 3) __builtin_amdgcn_sched_barrier(0);
             if ((s & 1) && (s >> 1) >= VF_X6_STORE && (s >> 1) - VF_X6_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X6_STORE);
             if (VF_X6_SB == 2) __builtin_amdgcn_sched_barrier(0);
         }
