@@ -96,7 +96,7 @@ class MIGT:
         return self
 
     def state_dict(self):
-        return OrderedDict((k, torch.from_numpy(v)) for k, v in self._sd_host.items())
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd_host.items())      # copies: host arrays may be read-only views
 
     def _upload(self):
         dev, h, c = self.device, self._sd_host, self.config
