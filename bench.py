@@ -134,7 +134,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=32, help='scenes per GPU per step')
+    ap.add_argument('--batch', type=int, default=128,
+                    help='scenes per GPU per step (measured 602 / 628 / 641 views/s at 32 / 64 / 128; the encoder runs in chunks of 256 images)')
     ap.add_argument('--views', type=int, default=7, help='views per scene (6 context + 1 novel)')
     ap.add_argument('--no-localization', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
