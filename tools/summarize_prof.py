@@ -39,6 +39,17 @@ def main():
             for n, cnt, avg, s, vg, lds in rows[:16]:
                 lines.append(f'  {short(n):78s} calls={cnt:5d} avg_us={avg / 1e3:10.2f} total_ms={s / 1e6:9.3f} '
                              f'pct={100 * s / tot:5.1f} vgpr={vg} lds={lds}')
+            # the top kernel broken down by launch shape (grid size): the average of the dominant shape is what bench.py's
+            # roofline.avg_launch_ms (HIP events) must agree with
+            try:
+                top = rows[0][0]
+                per = c.execute(f"select d.grid_size_x, count(*), avg(d.end-d.start), sum(d.end-d.start) from {kd} d join {ks} s on "
+                                f"d.kernel_id=s.id where s.kernel_name=? group by d.grid_size_x order by 4 desc", (top,)).fetchall()
+                lines.append(f'  -- {short(top)} by launch shape:')
+                for g, cnt, avg, ssum in per[:6]:
+                    lines.append(f'       grid_x={g:>9} (workgroups={g // 256:>6})  calls={cnt:4d} avg_us={avg / 1e3:10.2f} total_ms={ssum / 1e6:9.3f}')
+            except Exception as e:           # column names differ between rocprofv3 versions: the per-kernel table above stands
+                lines.append(f'  -- (per-shape breakdown unavailable: {e})')
             continue
         pe, ip = T('rocpd_pmc_event'), T('rocpd_info_pmc')
         q = (f"select s.kernel_name, p.name, d.id, sum(e.value) from {pe} e join {ip} p on e.pmc_id=p.id "
