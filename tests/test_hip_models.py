@@ -157,20 +157,21 @@ def test_migt_full_config_matches_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ pipeline
-def test_generate_batch_predictions_matches_oracle(dev, full_vq):
+@pytest.mark.parametrize('B,S', [(2, 3), (1, 2), (3, 5)])          # (1, 2): a single context view; odd image counts hit the pair tiles' tail
+def test_generate_batch_predictions_matches_oracle(dev, full_vq, B, S):
     from oracle import pipeline_oracle as po
     from viewformer_amd.config import MIGTConfig
     from viewformer_amd.evaluate import generate_batch_predictions
     from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
     vcfg, vsd, _ = full_vq
-    mcfg = MIGTConfig(sequence_size=3, localization_weight='1', pose_multiplier=0.2, n_layer=4)
+    mcfg = MIGTConfig(sequence_size=S, localization_weight='1', pose_multiplier=0.2, n_layer=4)
     msd = make_migt_weights(mcfg, seed=1, std=0.05)
-    frames, cams = synthetic_scene_batch(2, 3, 128, seed=3)
+    frames, cams = synthetic_scene_batch(B, S, 128, seed=3)
     ref = po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames, cams, return_intermediates=True)
     vq_m = _vq_model(vcfg, vsd, dev, 'NHWC')
     tr_m = _migt(mcfg, msd, dev)
     got = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True)
-    assert got['generated_images'].dtype == torch.uint8 and tuple(got['generated_images'].shape) == (2, 128, 128, 3)
+    assert got['generated_images'].dtype == torch.uint8 and tuple(got['generated_images'].shape) == (B, 128, 128, 3)
     assert torch.equal(got['codes'].cpu(), ref['codes'])                         # context tokens bit-exact
     assert _maxerr(got['logits_last'], ref['logits_last']) < 1e-3
     same = got['generated_codes'].cpu() == ref['generated_codes']
