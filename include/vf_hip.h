@@ -244,14 +244,23 @@ int vf_sum_slabs_f32(const float* slabs, int nslabs, int64_t stride, int64_t n, 
  * compute_causal_block_multiend_attention (branching_attention.py:5-18,82-126) inside MIGT.train_step (migt.py:464-505).
  *   forward with statistics: vf_attn_blockcausal_f32 + lse[B][H][T] = log sum_k exp(score)
  *   prep:  D[B][H][T] = rowsum(dOut * Out)
- *   bwd:   dq, dk, dv [B*T][ld*] (any column offsets / strides: the (V,Q,K) thirds of one buffer are fine) */
+ *   bwd:   dq, dk, dv [B*T][ld*] (any column offsets / strides: the (V,Q,K) thirds of one buffer are fine)
+ *   dropout (attn_dropout, branching_attention.py:15-17): drop_rate in [0, 1); element (b, h, q, k) of softmax(w) is kept iff
+ *   vf_dropout_hash(drop_seed, drop_site, ((b*H + h)*T + q)*T + k) >= floor(rate * 2^32) (csrc/vf_common.h) and scaled by 1/(1-rate);
+ *   the backward recomputes the same mask.  rate 0 = off. */
 int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                                 int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                float scale, int skip_masked, int twin_view, void* stream);
+                                float scale, int skip_masked, int twin_view, float drop_rate, uint32_t drop_seed,
+                                uint32_t drop_site, void* stream);
 int vf_attn_bwd_prep_f32(const float* dout, const float* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
 int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* D,
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo,
-                    int lddq, int lddk, int lddv, float scale, int twin_view, void* stream);
+                    int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
+                    uint32_t drop_site, void* stream);
+/* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403): out = keep ? x/(1-rate) : 0 [+ res],
+ * keep = vf_dropout_hash(seed, site, flat index) >= floor(rate * 2^32); applying it to a gradient gives the backward */
+int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
+                       void* stream);
 
 /* dst[c][r] = src[r][c], `batch` matrices with strides (floats) */
 int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,

@@ -103,6 +103,26 @@ def reduce_cameras(x, axis=-2):
 
 
 # ------------------------------------------------------------------ layers
+# Training-mode dropout hook (tests only): ``with dropout_masks(obj):`` makes the forward multiply by obj's masks at the four
+# Dropout sites of the reference (migt.py:72 MLP, :216 resid, :403 embeddings; branching_attention.py:15-17 attention weights).
+# obj.elem(kind, layer, stream, x) -> mask like x;  obj.attn(layer, stream, w, key_index) -> mask like w (see train_oracle).
+_DROP = None
+
+
+class dropout_masks:
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __enter__(self):
+        global _DROP
+        self.prev, _DROP = _DROP, self.obj
+        return self.obj
+
+    def __exit__(self, *exc):
+        global _DROP
+        _DROP = self.prev
+
+
 def gelu(x):
     """tf.nn.gelu default (approximate=False): 0.5 x (1 + erf(x / sqrt 2))."""
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
@@ -124,16 +144,18 @@ def layer_norm(sd, name, x, dtype):
 
 
 # ------------------------------------------------------------------ attention (branching_attention.py)
-def compute_attention(k, v, q, attention_mask=None):
-    """branching_attention.py:5-18 — no 1/sqrt(d) scale; mask as w*m - 1e4*(1-m)."""
+def compute_attention(k, v, q, attention_mask=None, wmask=None):
+    """branching_attention.py:5-18 — no 1/sqrt(d) scale; mask as w*m - 1e4*(1-m); ``wmask`` = attn_dropout (:15-17)."""
     w = q @ k.transpose(-1, -2)
     if attention_mask is not None:
         w = w * attention_mask - 1e4 * (1 - attention_mask)
     w = torch.softmax(w, dim=-1)
+    if wmask is not None:
+        w = w * wmask
     return w @ v
 
 
-def compute_causal_block_attention(k, v, q):
+def compute_causal_block_attention(k, v, q, wmask=None):
     """branching_attention.py:41-61 — block-causal over views, full inside a view."""
     b, h, ns, l, _ = k.shape
     nd = q.shape[-3]
@@ -141,14 +163,15 @@ def compute_causal_block_attention(k, v, q):
     j = torch.arange(ns).repeat_interleave(l)
     m = (i >= j - ns + nd).to(k.dtype)
     a = compute_attention(k.reshape(b, h, ns * l, -1), v.reshape(b, h, ns * l, -1),
-                          q.reshape(b, h, nd * l, -1), attention_mask=m)
+                          q.reshape(b, h, nd * l, -1), attention_mask=m, wmask=wmask)
     return a.reshape(b, h, nd, l, -1)
 
 
-def compute_causal_block_multiend_attention(kset, vset, qset):
-    """branching_attention.py:82-126."""
+def compute_causal_block_multiend_attention(kset, vset, qset, layer=None):
+    """branching_attention.py:82-126.  With a dropout hook installed, ``layer`` selects the attention-dropout masks."""
     k, v = kset[0], vset[0]
-    outputs = [compute_causal_block_attention(k, v, qset[0])]
+    drop = _DROP if layer is not None else None
+    outputs = [compute_causal_block_attention(k, v, qset[0], wmask=drop.attn(layer, 0, 'main') if drop else None)]
     b, h, ns, l, dh = k.shape
     # (explicit head dim instead of the reference's -1 so that a one-view sequence, which
     # the reference cannot reshape, is still defined here)
@@ -165,6 +188,8 @@ def compute_causal_block_multiend_attention(kset, vset, qset):
         w_old = w_old * m - 1e4 * (1 - m)
         w_new = (q @ k_new.transpose(-1, -2)).reshape(b, h, -1, l)
         w = torch.softmax(torch.cat([w_old, w_new], -1), dim=-1)
+        if drop:
+            w = w * drop.attn(layer, len(outputs), 'branch')
         attn_old = (w[:, :, :, :(ns - 1) * l] @ v_flat).reshape(b, h, nd, l, -1)
         w_new = w[:, :, :, (ns - 1) * l:].reshape(b, h, nd, l, l)
         attn_new = torch.einsum('ijklm,ijkmv->ijklv', w_new, v_new)
@@ -184,6 +209,10 @@ def _merge_heads(x):
     return x.permute(0, 2, 3, 1, 4).reshape(b, s, l, h * dh)
 
 
+def _layer_of(name):
+    return int(name.split('.')[1]) if _DROP is not None else None
+
+
 def branching_attention(sd, name, xs, n_head, dtype):
     """BranchingAttention.call, migt.py:207-217: c_attn thirds are (V, Q, K)."""
     vs, qs, ks = [], [], []
@@ -193,8 +222,11 @@ def branching_attention(sd, name, xs, n_head, dtype):
         vs.append(_split_heads(v, n_head))
         qs.append(_split_heads(q, n_head))
         ks.append(_split_heads(k, n_head))
-    a = compute_causal_block_multiend_attention(ks, vs, qs)
-    return [conv1d(sd, name + '.c_proj', _merge_heads(y), dtype) for y in a]
+    a = compute_causal_block_multiend_attention(ks, vs, qs, layer=_layer_of(name))
+    out = [conv1d(sd, name + '.c_proj', _merge_heads(y), dtype) for y in a]
+    if _DROP is not None:                                       # resid_dropout, migt.py:216
+        out = [y * _DROP.elem('resid', _layer_of(name), s, y) for s, y in enumerate(out)]
+    return out
 
 
 def block(sd, name, xs, n_head, dtype):
@@ -202,6 +234,8 @@ def block(sd, name, xs, n_head, dtype):
     a = branching_attention(sd, name + '.attn', [layer_norm(sd, name + '.ln_1', x, dtype) for x in xs], n_head, dtype)
     xs = [x + y for x, y in zip(xs, a)]
     m = [mlp(sd, name + '.mlp', layer_norm(sd, name + '.ln_2', x, dtype), dtype) for x in xs]
+    if _DROP is not None:                                       # MLP dropout, migt.py:72
+        m = [y * _DROP.elem('mlp', _layer_of(name), s, y) for s, y in enumerate(m)]
     return [x + y for x, y in zip(xs, m)]
 
 
@@ -271,6 +305,8 @@ def migt_forward(sd, cfg, input_ids, poses, localization_tokens=None, output_pos
             streams.append(loc_emb + pos_emb + wte[loc_token].reshape(1, 1, 1, -1))
             pose_ptr = len(streams) - 1
 
+        if _DROP is not None:                                  # self.drop, :403
+            streams = [x * _DROP.elem('embed', 0, s, x) for s, x in enumerate(streams)]
         for i in range(cfg.n_layer):                           # :405-406
             streams = block(sd, f'h.{i}', streams, cfg.n_head, dtype)
         streams = [layer_norm(sd, 'ln_f', x, dtype) for x in streams]   # :408

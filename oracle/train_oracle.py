@@ -79,3 +79,85 @@ def adam_weight_decay_step(params, grads, m, v, step, cfg, warmup_steps=2000, b1
         v[k] = b2 * v[k] + (1 - b2) * grads[k] ** 2
         params[k] -= lr_t * m[k] / (np.sqrt(v[k]) + eps)
     return lr
+
+
+# ---------------------------------------------------------------------------------------------------------------- dropout
+def dropout_hash(seed, site, idx):
+    """numpy restatement of vf_dropout_hash (viewformer_amd/csrc/vf_common.h): uint32 arithmetic with wrap-around"""
+    idx = np.asarray(idx, dtype=np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    mul = lambda a, c: (a * np.uint64(c)) & M
+    h = np.uint64((int(seed) ^ ((int(site) * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    h = h ^ (idx & M)
+    h = mul(h, 0x85EBCA6B)
+    h = h ^ (h >> np.uint64(13))
+    h = (h + mul(idx >> np.uint64(32), 0xC2B2AE35) + np.uint64(0x27D4EB2F)) & M
+    h = h ^ (h >> np.uint64(16))
+    h = mul(h, 0x165667B1)
+    h = h ^ (h >> np.uint64(15))
+    h = mul(h, 0xD3A2646C)
+    h = h ^ (h >> np.uint64(16))
+    return h.astype(np.uint32)
+
+
+class DropoutMasks:
+    """the masks MIGTTrainer applies (train.py: SITE_EMBED, site_attn/resid/mlp; element index conventions of the kernels) in the
+    shapes the restated forward of migt_oracle needs.  Hidden states are [B, V = NS*S, L, d] row-major in the build, a list of
+    NS tensors [B, S, L, d] here; attention weights are indexed by absolute (query, key) token positions in the V*L sequence."""
+
+    def __init__(self, rate, seed, B, NS, S, L, d, H, dtype=torch.float64):
+        self.rate, self.seed, self.B, self.NS, self.S, self.L, self.d, self.H, self.dtype = rate, seed, B, NS, S, L, d, H, dtype
+        self.thresh = int(rate * 4294967296.0)
+        self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))      # fp32 like the kernels
+        self._attn_cache = {}
+
+    def _mask(self, site, idx):
+        keep = dropout_hash(self.seed, site, idx) >= np.uint32(self.thresh)
+        return torch.from_numpy(keep.astype(np.float64) * self.scale).to(self.dtype)
+
+    def elem(self, kind, layer, stream, x):
+        site = {'embed': 1, 'resid': 17 + 4 * layer, 'mlp': 18 + 4 * layer}[kind]
+        B, S, L, d = self.B, self.S, self.L, self.d
+        V = self.NS * S
+        b, i, t, c = np.meshgrid(np.arange(B), np.arange(S), np.arange(L), np.arange(d), indexing='ij')
+        idx = ((b.astype(np.uint64) * V + stream * S + i) * L + t) * d + c
+        return self._mask(site, idx).reshape(x.shape)
+
+    def _full(self, layer):
+        if layer not in self._attn_cache:
+            B, H = self.B, self.H
+            T = self.NS * self.S * self.L
+            b, h, q, k = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing='ij')
+            idx = ((b.astype(np.uint64) * H + h) * T + q) * T + k
+            self._attn_cache = {layer: self._mask(16 + 4 * layer, idx)}
+        return self._attn_cache[layer]
+
+    def attn(self, layer, stream, kind):
+        full = self._full(layer)                                   # [B, H, T, T] over absolute token positions
+        S, L = self.S, self.L
+        r0 = stream * S * L
+        rows = full[:, :, r0:r0 + S * L]
+        if kind == 'main':
+            return rows[:, :, :, :S * L]
+        # branch stream: keys = main views 0..S-2, then the query's own view tokens (branching_attention.py:96-124)
+        old = rows[:, :, :, :(S - 1) * L]
+        q = torch.arange(S * L)
+        own_cols = (r0 + (q // L) * L)[:, None] + torch.arange(L)[None, :]            # [S*L, L] absolute key index
+        own = torch.gather(rows, 3, own_cols[None, None].expand(rows.shape[0], rows.shape[1], -1, -1))
+        return torch.cat([old, own], -1)
+
+
+def losses_with_dropout(sd, cfg, poses, tokens, step, rate, seed, dtype=torch.float64):
+    B, S = tokens.shape[:2]
+    L = int(np.prod(tokens.shape[2:]))
+    NS = 3 if cfg.use_localization else 2
+    with mg.dropout_masks(DropoutMasks(rate, seed, B, NS, S, L, cfg.d_model, cfg.n_head, dtype)):
+        return losses(sd, cfg, poses, tokens, step, dtype)
+
+
+def gradients_with_dropout(sd_np, cfg, poses, tokens, step, rate, seed):
+    sd = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd_np.items()}
+    total, metrics = losses_with_dropout(sd, cfg, torch.as_tensor(poses), torch.as_tensor(tokens), step, rate, seed)
+    total.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+    return grads, {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in metrics.items()}

@@ -234,7 +234,7 @@ def test_per_tensor_gradient_clipping(dev):
         from viewformer_amd.migt import MIGT
         from viewformer_amd.train import MIGTTrainer
         from viewformer_amd.weights import make_migt_weights
-        c2 = MIGTConfig(**TINY_MIGT)                           # default dropout 0.1
+        c2 = MIGTConfig(**TINY_MIGT, label_smoothing=0.1)      # unsupported options are refused, never ignored
         MIGTTrainer(MIGT(c2).load_state_dict(make_migt_weights(c2)).to(dev))
 
 
@@ -329,3 +329,116 @@ def test_bf16_training_step_gradients_within_stated_tolerance(dev):
     tr.apply_gradients()                                   # the update refreshes the bf16 packings from the fp32 master weights
     m2 = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     assert float(m2['loss']) < float(metrics['loss'])
+
+
+def test_dropout_hash_restatement_statistics():
+    """CPU: the numpy restatement of the counter-based mask behaves like a uniform generator and is index-sensitive"""
+    from oracle import train_oracle as to
+    idx = np.arange(1 << 18, dtype=np.uint64)
+    h = to.dropout_hash(123, 17, idx)
+    assert h.dtype == np.uint32
+    keep = (h >= np.uint32(int(0.1 * 4294967296.0))).mean()
+    assert abs(keep - 0.9) < 3e-3
+    assert abs((to.dropout_hash(123, 18, idx) == h).mean()) < 1e-3                 # another site = another mask
+    assert abs((to.dropout_hash(124, 17, idx) == h).mean()) < 1e-3                 # another seed = another mask
+    hi = to.dropout_hash(123, 17, idx + (np.uint64(1) << np.uint64(32)))           # the high word matters
+    assert abs((hi == h).mean()) < 1e-3
+    bits = np.unpackbits(h.view(np.uint8)).mean()
+    assert abs(bits - 0.5) < 2e-3
+
+
+@pytest.mark.gpu
+def test_dropout_kernels_use_the_restated_mask(dev):
+    from oracle import train_oracle as to
+    from viewformer_amd import train_ops as T
+    n, rate, seed, site = 100003, 0.25, 0xDEADBEEF, 21
+    x, r = _rand((n,), 1), _rand((n,), 2)
+    keep = to.dropout_hash(seed, site, np.arange(n, dtype=np.uint64)) >= np.uint32(int(rate * 4294967296.0))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    want = np.where(keep, x.numpy() * scale, np.float32(0)) + r.numpy()
+    got = T.dropout_add(x.to(dev), rate, seed, site, res=r.to(dev))
+    assert np.array_equal(got.cpu().numpy(), want.astype(np.float32))
+    xd = x.to(dev).clone()
+    T.dropout_add(xd, rate, seed, site, out=xd)                                    # in place, no residual
+    assert np.array_equal(xd.cpu().numpy(), np.where(keep, x.numpy() * scale, np.float32(0)).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['streams', 'causal'])
+def test_flash_attention_with_dropout_matches_autograd(dev, mode):
+    """attention-weight dropout inside the forward and both backward kernels == autograd with the same masks"""
+    from oracle import migt_oracle as mg
+    from oracle import train_oracle as to
+    from viewformer_amd import train_ops as T
+    B, H, S, L, rate, seed, layer = 2, 2, 3, 64, 0.2, 777, 1
+    d = H * 64
+    NS = 3 if mode == 'streams' else 1
+    Tn = NS * S * L
+    spec = -S if mode == 'streams' else -1
+    g = np.random.Generator(np.random.PCG64(5))
+    qkv = torch.from_numpy((g.standard_normal((B * Tn, 3 * d)) * 0.4).astype(np.float32))
+    dout = torch.from_numpy(g.standard_normal((B * Tn, d)).astype(np.float32))
+    masks = to.DropoutMasks(rate, seed, B, NS, S, L, d, H)
+    x = qkv.double().requires_grad_(True)
+    with mg.dropout_masks(masks):
+        if mode == 'streams':
+            xs = x.view(B, NS, S, L, 3 * d)
+            ks, vs, qs = [], [], []
+            for s in range(NS):
+                v, q, k = xs[:, s].chunk(3, -1)
+                ks.append(mg._split_heads(k, H)); vs.append(mg._split_heads(v, H)); qs.append(mg._split_heads(q, H))
+            outs = mg.compute_causal_block_multiend_attention(ks, vs, qs, layer=layer)
+            out = torch.stack([mg._merge_heads(a) for a in outs], 1).reshape(B * Tn, d)
+        else:
+            v, q, k = x.view(B, S, L, 3 * d).chunk(3, -1)
+            sp = lambda t: mg._split_heads(t, H)
+            out = mg._merge_heads(mg.compute_causal_block_attention(sp(k), sp(v), sp(q), wmask=masks.attn(layer, 0, 'main'))).reshape(B * Tn, d)
+    out.backward(dout.double())
+    gq = qkv.to(dev)
+    drop = (rate, seed, 16 + 4 * layer)
+    att = torch.empty((B * Tn, d), device=dev)
+    lse = T.attn_fwd_lse(gq[:, d:2 * d], gq[:, 2 * d:], gq[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec, drop=drop)
+    assert (att.double().cpu() - out.detach()).abs().max().item() < 5e-5
+    dqkv = torch.full((B * Tn, 3 * d), float('nan'), device=dev)
+    T.attn_bwd(gq[:, d:2 * d], gq[:, 2 * d:], gq[:, :d], att, dout.to(dev), lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
+               B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec, drop=drop)
+    err = (dqkv.double().cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.gpu
+def test_train_step_with_dropout_matches_autograd_with_the_same_masks(dev):
+    """the reference's default dropout = 0.1 at all four sites: loss and every gradient vs fp64 autograd over the oracle with the
+    build's masks; deterministic per (seed, step); a different step draws different masks"""
+    from oracle import train_oracle as to
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    cfg = MIGTConfig(**TINY_MIGT, dropout=0.1, n_loss_skip=1, localization_weight='1', pose_multiplier=0.2, learning_rate=1e-3,
+                     weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=1, std=0.08)
+    g = np.random.Generator(np.random.PCG64(4))
+    B, S, t = 2, 4, cfg.token_image_size
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, t, t)))
+    _, cams = synthetic_scene_batch(B, S, 8, 1)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    tr = MIGTTrainer(MIGT(cfg).load_state_dict(sd).to(dev), warmup_steps=4)
+    tr.dropout_seed, tr.step_count = 42, 3
+    metrics = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    g1 = tr.flat_g.clone()
+    grads, ref_metrics = to.gradients_with_dropout(sd, cfg, poses, tokens, 3, 0.1, tr.step_seed(3))
+    assert abs(float(metrics['loss']) - ref_metrics['loss']) < 1e-4 * max(1.0, abs(ref_metrics['loss']))
+    for name in tr.names:
+        e = _err(tr.g(name), grads[name].reshape(tr.slices[name][2]))
+        assert e < 2e-3, (name, e)
+    tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    # same (seed, step) -> same masks: identical up to the float-atomic order of the embedding-row scatter (vf_embed_bwd_f32)
+    assert ((tr.flat_g - g1).abs().max() / g1.abs().max()).item() < 1e-6
+    tr.step_count = 4
+    m4 = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert float(m4['loss']) != float(metrics['loss'])
+    # and the no-dropout loss differs from both (dropout really is on)
+    _, ref0 = to.gradients(sd, cfg, poses, tokens, step=3)
+    assert abs(ref0['loss'] - ref_metrics['loss']) > 1e-4

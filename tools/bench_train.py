@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=10)
     ap.add_argument('--seq', type=int, default=10)
+    ap.add_argument('--dropout', type=float, default=0.0, help='the reference default is 0.1 (counter-based masks at all four sites)')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='bf16: dense GEMMs of the forward and backward pass on bf16 MFMA (fp32 master weights, fp32 attention / '
                          'normalisation / losses / optimizer), like the reference\'s --fp16')
@@ -35,7 +36,7 @@ def main():
     rank, local, world = sharding.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    cfg = MIGTConfig(sequence_size=args.seq, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.0,
+    cfg = MIGTConfig(sequence_size=args.seq, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=args.dropout,
                      learning_rate=1e-4, weight_decay=0.05, total_steps=40000, batch_size=80)
     model = MIGT(cfg, precision=args.precision).load_state_dict(make_migt_weights(cfg, seed=0)).to(dev)
     tr = MIGTTrainer(model)
@@ -59,7 +60,7 @@ def main():
         tf = 3 * 0.37 * B * world
         print(json.dumps({'metric': 'MIGT training step (fwd+bwd+AdamW), CO3D-10cat config', 'ms_per_step': round(dt * 1e3, 1),
                           'samples_per_s': round(B * world / dt, 2), 'n_gpus': world, 'scenes_per_gpu': B,
-                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': args.precision,
+                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': args.precision, 'dropout': args.dropout,
                           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
     if world > 1:
         torch.distributed.destroy_process_group()

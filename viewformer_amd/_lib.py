@@ -55,10 +55,11 @@ EXPORTS = {
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                            c_float, c_int, c_int, P]),
+                                            c_float, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
+    'vf_dropout_add_f32': (c_int, [P, P, P, c_int64, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_attn_bwd_prep_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_float, c_int, P]),
+                                c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
     'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
                                                              const float* __restrict__ v, const float* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ Dv,
                                                              float* __restrict__ dq, int T, int L, int ldq, int ldk, int ldv,
-                                                             int lddo, int lddq, float scale, int twin) {
+                                                             int lddo, int lddq, float scale, int twin, uint32_t drop_thresh,
+                                                             float drop_scale, uint32_t drop_seed, uint32_t drop_site) {
     __shared__ __attribute__((aligned(16))) float Ks[TT * LD];
     __shared__ __attribute__((aligned(16))) float Vs[TT * LD];
     __shared__ __attribute__((aligned(16))) float Kt[DH * LD];
@@ -162,7 +163,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
                     if (key >= T) sc = -INFINITY;
                 }
                 const float p = __builtin_amdgcn_exp2f((sc - lse_q) * LOG2E);
-                st[r] = p * (dp[r] - D_q) * scale;                         // dS^T (d/dS of the scaled score)
+                float dpr = dp[r];
+                if (drop_thresh) {                                         // d(dropped P)/dP = mask * scale
+                    const int key = kt * TT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const uint64_t e = (((uint64_t)b * H + h) * T + qrow) * (uint64_t)T + key;
+                    dpr = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh ? dpr * drop_scale : 0.f;
+                }
+                st[r] = p * (dpr - D_q) * scale;                           // dS^T (d/dS of the scaled score)
             }
             // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]
 #pragma unroll
@@ -199,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
                                                               const float* __restrict__ lse, const float* __restrict__ Dv,
                                                               float* __restrict__ dk, float* __restrict__ dv, int T, int L,
                                                               int ldq, int ldk, int ldv, int lddo, int lddk, int lddv,
-                                                              float scale, int twin) {
+                                                              float scale, int twin, uint32_t drop_thresh, float drop_scale,
+                                                              uint32_t drop_seed, uint32_t drop_site) {
     extern __shared__ __attribute__((aligned(16))) float smem_a[];
     float* Qs = smem_a;                 // [TT][LD]   queries of the tile, row-major
     float* Os = Qs + TT * LD;           // [TT][LD]   dO rows
@@ -308,8 +316,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
                     if (!kvalid) sc = -INFINITY;
                 }
                 const float p = __builtin_amdgcn_exp2f((sc - Ls[ql]) * LOG2E);
-                st[r] = p;
-                dp[r] = p * (dp[r] - Ds[ql]) * scale;                      // dS
+                float pd = p, dpr = dp[r];
+                if (drop_thresh) {
+                    const uint64_t e = (((uint64_t)b * H + h) * T + (qt * TT + ql)) * (uint64_t)T + krow;
+                    const bool keep = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh;
+                    pd = keep ? p * drop_scale : 0.f;                      // the forward multiplied V by the dropped P
+                    dpr = keep ? dpr * drop_scale : 0.f;
+                }
+                st[r] = pd;
+                dp[r] = p * (dpr - Ds[ql]) * scale;                        // dS
             }
             // dV^T[d][key] += dO^T[d][query] . P[query][key];  dK^T[d][key] += Q^T[d][query] . dS[query][key]
 #pragma unroll
@@ -360,15 +375,19 @@ int vf_attn_bwd_prep_f32(const float* dout, const float* out, float* D, int B, i
 
 int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* D,
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq,
-                    int lddk, int lddv, float scale, int twin_view, void* stream) {
+                    int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
+                    uint32_t drop_site, void* stream) {
     if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     const int w = H * DH;
     if (ldq < w || ldk < w || ldv < w || lddo < w || lddq < w || lddk < w || lddv < w) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return VF_ERR_BAD_ARG;
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
+    const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
+    const float dscale = 1.0f / (1.0f - drop_rate);
     dim3 grid((unsigned)((T + OT - 1) / OT), (unsigned)H, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, q, k, v, dout, lse, D, dq, T, L, ldq, ldk, ldv, lddo, lddq,
-                       scale, twin_view);
+                       scale, twin_view, thresh, dscale, drop_seed, drop_site);
     int st = vf_last_status();
     if (st) return st;
     const size_t smem = (size_t)(2 * TT * LD + 2 * DH * LD + 2 * TT) * sizeof(float);
@@ -380,7 +399,7 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), smem, s, q, k, v, dout, lse, D, dk, dv, T, L, ldq, ldk, ldv, lddo,
-                       lddk, lddv, scale, twin_view);
+                       lddk, lddv, scale, twin_view, thresh, dscale, drop_seed, drop_site);
     return vf_last_status();
 }
 

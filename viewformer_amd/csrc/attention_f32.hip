@@ -29,7 +29,9 @@ constexpr int VT_LD = 68;    // V is parked TRANSPOSED ([feature][key]) so a lan
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int skip_masked, int twin, float* __restrict__ lse) {
+                                                                  float scale, int skip_masked, int twin, float* __restrict__ lse,
+                                                                  uint32_t drop_thresh, float drop_scale, uint32_t drop_seed,
+                                                                  uint32_t drop_site) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vt[DH * VT_LD];
 
@@ -196,9 +198,14 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f((st[t2][r] - m_new) * LOG2E);
+                float p = __builtin_amdgcn_exp2f((st[t2][r] - m_new) * LOG2E);
+                psum += p;                                   // the softmax normaliser is over the undropped weights
+                if (drop_thresh) {                           // attn_dropout (branching_attention.py:15-17): applied to softmax(w)
+                    const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const uint64_t e = (((uint64_t)b * gridDim.y + h) * T + qrow) * (uint64_t)T + key;
+                    p = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh ? p * drop_scale : 0.f;
+                }
                 st[t2][r] = p;
-                psum += p;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -255,19 +262,21 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr);
+                       ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr, 0u, 1.0f, 0u, 0u);
     return vf_last_status();
 }
 
 int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int T,
                                 int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
-                                void* stream) {
+                                float drop_rate, uint32_t drop_seed, uint32_t drop_site, void* stream) {
     if (!q || !k || !v || !out || !lse || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
+    const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view, lse);
+                       ldv, ldo, scale, skip_masked, twin_view, lse, thresh, 1.0f / (1.0f - drop_rate), drop_seed, drop_site);
     return vf_last_status();
 }
 

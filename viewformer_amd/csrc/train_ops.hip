@@ -307,6 +307,15 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// ------------------------------------------------------------------ dropout: out = x * keep / (1 - rate) [+ res]
+__global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                   long long n, uint32_t thresh, float scale, uint32_t seed, uint32_t site) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = vf_dropout_hash(seed, site, (uint64_t)i) >= thresh ? x[i] * scale : 0.f;
+        out[i] = res ? v + res[i] : v;
+    }
+}
+
 // ------------------------------------------------------------------ axpy-style helpers
 __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a[i] += b[i];
@@ -463,6 +472,16 @@ int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream) {
     if (!a || !b || n < 0) return VF_ERR_BAD_ARG;
     if (n == 0) return VF_OK;
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n);
+    return vf_last_status();
+}
+
+int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
+                       void* stream) {
+    if (!x || !out || n < 0 || !(rate >= 0.f && rate < 1.f)) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    const uint32_t thresh = (uint32_t)((double)rate * 4294967296.0);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, res, out, (long long)n,
+                       thresh, 1.0f / (1.0f - rate), seed, site);
     return vf_last_status();
 }
 

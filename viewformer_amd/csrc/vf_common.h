@@ -54,6 +54,23 @@ __device__ __forceinline__ float vf_wave_max(float v) {
     return v;
 }
 
+// Counter-based dropout mask (training step): keep element `idx` of dropout site `site` iff hash >= thresh, where
+// thresh = floor(rate * 2^32).  A pure function of (seed, site, idx): the forward and backward passes recompute the same mask
+// and nothing is stored; oracle/train_oracle.py restates it in numpy for the tests.
+__host__ __device__ __forceinline__ uint32_t vf_dropout_hash(uint32_t seed, uint32_t site, uint64_t idx) {
+    uint32_t h = seed ^ (site * 0x9E3779B9u);
+    h ^= (uint32_t)idx;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h += (uint32_t)(idx >> 32) * 0xC2B2AE35u + 0x27D4EB2Fu;
+    h ^= h >> 16;
+    h *= 0x165667B1u;
+    h ^= h >> 15;
+    h *= 0xD3A2646Cu;
+    h ^= h >> 16;
+    return h;
+}
+
 // shared host helper (defined in igemm_f32.hip): pack [taps][K][N] into the fragment-major B layout
 int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long long sk, long long sn, long long st,
                    int BN, int batch, long long src_bstride, hipStream_t stream);

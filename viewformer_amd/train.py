@@ -15,8 +15,12 @@ are the HBM-bound kernels of csrc/train_ops.hip.  Parameters, gradients and Adam
 buffers so that a layer's gradients are one contiguous RCCL all-reduce issued as soon as that layer's backward
 is done (overlapping the remaining backward).
 
-Limits of this first version (raise NotImplementedError otherwise): dropout must be 0, label_smoothing 0,
-random_pose_multiplier 1, no dynamic pose-loss weighting.
+Dropout (config.dropout, default 0.1 in the reference: migt.py:72,216,403 and attn_dropout branching_attention.py:15-17) uses a
+counter-based mask — keep = hash(seed, site, element index) >= rate * 2^32 (csrc/vf_common.h) — that the backward pass recomputes;
+``dropout_seed`` and the step counter give the per-step seed.  The masks cannot coincide with TensorFlow's RNG stream; the tests
+check the kernels against autograd with the SAME masks restated in numpy (oracle/train_oracle.py).
+
+Limits (raise NotImplementedError otherwise): label_smoothing 0, random_pose_multiplier 1, no dynamic pose-loss weighting.
 """
 import math
 import re
@@ -52,12 +56,29 @@ def learning_rate(step, init_lr, total_steps, warmup_steps):
     return init_lr * 0.5 * (1.0 + math.cos(math.pi * t / decay_steps))
 
 
+# dropout sites (the `site` word of the counter-based mask): one per Dropout layer instance of the reference
+SITE_EMBED = 1
+
+
+def site_attn(i):
+    return 16 + 4 * i
+
+
+def site_resid(i):
+    return 17 + 4 * i
+
+
+def site_mlp(i):
+    return 18 + 4 * i
+
+
 class MIGTTrainer:
     def __init__(self, model: MIGT, warmup_steps: int = 2000, beta1: float = 0.9, beta2: float = 0.999,
                  eps: float = 1e-8, process_group=None):
         cfg = model.config
-        if cfg.dropout != 0:
-            raise NotImplementedError('dropout > 0 is not built yet: set dropout=0.0 in MIGTConfig')
+        if not 0.0 <= cfg.dropout < 1.0:
+            raise ValueError('dropout must be in [0, 1)')
+        self.dropout_seed = 0
         if cfg.label_smoothing != 0 or cfg.random_pose_multiplier != 1 or cfg.use_dynamic_pose_loss:
             raise NotImplementedError('label smoothing / random pose multiplier / dynamic pose loss are not built')
         if model._sd_host is None or model.device is None:
@@ -198,18 +219,24 @@ class MIGTTrainer:
 
     attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
 
-    def _attn_bwd(self, qkv, datt, B, Tn, L, spec, att=None, lse=None):
+    def step_seed(self, step):
+        """per-step dropout seed (uint32) from ``dropout_seed`` and the step counter"""
+        return (int(self.dropout_seed) * 0x9E3779B1 + int(step) * 0x85EBCA77 + 0x1234567) & 0xFFFFFFFF
+
+    def _attn_bwd(self, qkv, datt, B, Tn, L, spec, att=None, lse=None, drop=(0.0, 0, 0)):
         """dQKV from dA (branching_attention.py:82-126 semantics).  'flash': one pair of kernels per layer re-materialises the
         probabilities tile by tile from the saved log-sum-exp and skips masked tiles; 'dense': per head with batched GEMMs."""
         c = self.cfg
         d, H = c.d_model, c.n_head
         M = B * Tn
         dqkv = torch.empty((M, 3 * d), dtype=torch.float32, device=qkv.device)
+        if drop[0] and not (self.attention_backward == 'flash' and att is not None and lse is not None):
+            raise NotImplementedError("attention dropout needs attention_backward='flash'")
         if self.attention_backward == 'flash' and att is not None and lse is not None:
             # thirds are (V, Q, K) (migt.py:207-213): gradients land in the same thirds of dqkv
             T.attn_bwd(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse,
                        dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d], B, H, Tn, L,
-                       3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+                       3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec, drop=drop)
             return dqkv
         S = torch.empty((B, Tn, Tn), dtype=torch.float32, device=qkv.device)
         dP = torch.empty_like(S)
@@ -274,18 +301,31 @@ class MIGTTrainer:
         ids32 = torch.cat(ids_streams, 1).reshape(M).to(torch.int32).contiguous()
         add = torch.cat(add_streams, 1).contiguous().view(B * V, d)
         h = ops.embed_sum(ids32, m._wte, m._wpe, add, B * V, L, d, nE + 2)
+        rate = float(c.dropout)
+        seed = self.step_seed(self.step_count)
+        if rate:
+            T.dropout_add(h, rate, seed, SITE_EMBED, out=h)                          # self.drop, migt.py:403
         saved = []
         for i in range(c.n_layer):
             p = f'h.{i}'
             n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d)
             qkv = self._linear(n1, p + '.attn.c_attn', M)
             att = torch.empty((M, d), dtype=torch.float32, device=dev)
-            lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S)
-            h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
+            lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
+                                 drop=(rate, seed, site_attn(i)))
+            if rate:                                                                 # resid_dropout, migt.py:216
+                y = self._linear(att, p + '.attn.c_proj', M)
+                h_mid = T.dropout_add(y, rate, seed, site_resid(i), res=h, out=y)
+            else:
+                h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
             n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d)
             u = self._linear(n2, p + '.mlp.c_fc', M)
             f = T.gelu(u)
-            h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
+            if rate:                                                                 # MLP dropout, migt.py:72
+                y = self._linear(f, p + '.mlp.c_proj', M)
+                h_out = T.dropout_add(y, rate, seed, site_mlp(i), res=h_mid, out=y)
+            else:
+                h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
             saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
             h = h_out
         hf = ops.layernorm(h, *m._ln['ln_f'], M, d).view(B, NS, S, L, d)
@@ -347,12 +387,12 @@ class MIGTTrainer:
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
-            df = self._linear_bwd(p + '.mlp.c_proj', f, dh, M)
+            df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
             du = T.gelu_bwd(u, df)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
             dh_mid = T.add_(self._ln_bwd(p + '.ln_2', dn2, h_mid, M), dh)
-            datt = self._linear_bwd(p + '.attn.c_proj', att, dh_mid, M)
-            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse)
+            datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M)
+            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
             dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
             saved[i] = None
@@ -360,6 +400,8 @@ class MIGTTrainer:
                 a, b = self.layer_ranges[i]
                 handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
+        if rate:
+            T.dropout_add(dh, rate, seed, SITE_EMBED, out=dh)
         dadd = T.embed_bwd(dh, ids32, gwte, self.g('wpe.embeddings'), B * V, L, d, nE + 2).view(B, V, d)
         dpe = (dadd[:, :S] + dadd[:, S:2 * S]).contiguous().view(B * S, d)
         if use_loc:

@@ -117,20 +117,32 @@ def clip_by_norm_(x, clip, scratch1):
     return x
 
 
-def attn_fwd_lse(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1):
-    """forward attention that also returns the per-query log-sum-exp [B,H,T] the flash backward needs"""
+def attn_fwd_lse(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1, drop=(0.0, 0, 0)):
+    """forward attention that also returns the per-query log-sum-exp [B,H,T] the flash backward needs;
+    ``drop`` = (rate, seed, site) applies attn_dropout to softmax(w) with the counter-based mask of vf_common.h"""
     lib = _lib.load()
     lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(lib.vf_attn_blockcausal_lse_f32(_p(q), _p(k), _p(v), _p(out), _p(lse), B, H, T, L, ldq, ldk, ldv, ldo, scale, 1,
-                                          mask_spec, _stream()), 'vf_attn_blockcausal_lse_f32')
+                                          mask_spec, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]), _stream()),
+          'vf_attn_blockcausal_lse_f32')
     return lse
 
 
 def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0,
-             mask_spec=-1):
+             mask_spec=-1, drop=(0.0, 0, 0)):
     """dQ, dK, dV of the block-causal / streams attention (written in place; the tensors may be column views)"""
     lib = _lib.load()
     D = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(lib.vf_attn_bwd_prep_f32(_p(dout), _p(out), _p(D), B, H, T, lddo, ldo, _stream()), 'vf_attn_bwd_prep_f32')
     check(lib.vf_attn_bwd_f32(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), B, H, T, L, ldq, ldk, ldv,
-                              lddo, lddq, lddk, lddv, scale, mask_spec, _stream()), 'vf_attn_bwd_f32')
+                              lddo, lddq, lddk, lddv, scale, mask_spec, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]),
+                              _stream()), 'vf_attn_bwd_f32')
+
+
+def dropout_add(x, rate, seed, site, res=None, out=None):
+    """out = keep ? x / (1 - rate) : 0 [+ res] with the counter-based mask (seed, site, flat index); in place when out is x"""
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vf_dropout_add_f32(_p(_f32(x)), _p(_f32(res)) if res is not None else None, _p(out), x.numel(), float(rate),
+                                         int(seed) & 0xFFFFFFFF, int(site), _stream()), 'vf_dropout_add_f32')
+    return out
