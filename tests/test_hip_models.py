@@ -246,3 +246,32 @@ def test_load_model_from_a_reference_written_directory(dev, tiny_vq):
     assert np.array_equal(codes.cpu().numpy(), g['codes'])
     dec = m.decode_code(torch.from_numpy(g['codes']).to(dev)).permute(0, 3, 1, 2)
     assert _maxerr(dec, g['decoded']) < 2e-5
+
+
+def test_full_size_pipeline_properties(dev, full_vq):
+    """BASELINE configs[1] shapes (full VQGAN + 12-layer MIGT, 7 views): size-independent properties instead of the (too slow)
+    oracle — run-to-run determinism, scene independence of every output (a scene alone == the same scene inside a batch, bit for
+    bit), and context tokens identical across the fp32 and mixed arms"""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    vcfg, vsd, _ = full_vq
+    mcfg = MIGTConfig(sequence_size=7, localization_weight='1', pose_multiplier=0.2)
+    msd = make_migt_weights(mcfg, seed=0)
+    frames, cams = synthetic_scene_batch(5, 7, 128, seed=11)
+    outs = {}
+    for arm in ('f32', 'bf16'):
+        vq_m = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm).load_state_dict(vsd).to(dev)
+        tr_m = MIGT(mcfg, precision=arm).load_state_dict(msd).to(dev)
+        a = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True)
+        b = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True)
+        for key in ('codes', 'generated_codes', 'generated_images', 'generated_cameras'):
+            assert torch.equal(a[key], b[key]), (arm, key)                                   # deterministic
+        one = generate_batch_predictions(tr_m, vq_m, frames[3:4], cams[3:4], return_codes=True)
+        for key in ('codes', 'generated_codes', 'generated_images', 'generated_cameras'):
+            assert torch.equal(one[key][0], a[key][3]), (arm, key)                           # scene independence
+        outs[arm] = a
+    assert torch.equal(outs['f32']['codes'], outs['bf16']['codes'])                          # the encoder is fp32 in both arms
+    assert outs['f32']['generated_images'].dtype == torch.uint8
