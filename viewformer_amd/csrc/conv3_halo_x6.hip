@@ -252,6 +252,162 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
     vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
+// ---- 16x16-pixel tile form (stride 1, H % 16 == 0, W % 16 == 0); opt-in (-DVF_X6_BIG=1), see the A/B note at the dispatch -------
+// One workgroup per CU (4 waves, one per SIMD, up to 512 registers each): a wave owns 8 rows x 16 px x 64 output channels
+// = 8 accumulator tiles, so every weight fragment it loads feeds 4 MFMAs per product instead of 2 (half the L1 traffic per
+// MFMA), the halo overhead drops from 1.41 to 1.27 patch pixels per output pixel, and a (tap, k-step) stage is 48 MFMAs =
+// 1536 matrix-pipe cycles — long enough that one wave per SIMD with the loads pinned one / two stages ahead keeps the pipe fed
+// on its own.  Same LDS layout, weight packing, epilogue and GroupNorm partial slots as the 8x16 kernel above.
+constexpr int BTH = 16;
+constexpr int B_PH = BTH + 2, B_PW = TW + 2, B_NPIX = B_PH * B_PW;          // 18 x 18 = 324
+constexpr int B_SLOTS = (B_NPIX * 8 + 255) / 256;                           // 11
+constexpr int B_BUF = (B_NPIX + 1) * P_LDB;
+
+template <bool PRO, bool SWISH>
+__global__ __launch_bounds__(256, 1) void conv3_halo_x6_big_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][B_BUF]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / BTH;
+    int bid = blockIdx.x;
+    const int nblk = bid % nb; bid /= nb;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int img = bid / tilesY;
+    const int y0 = ty * BTH, x0 = tx * TW;
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / CK;
+
+    const int c4 = tid & 7;
+    int s_off[B_SLOTS], s_lds[B_SLOTS];
+    bool s_ok[B_SLOTS];
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int pixc = pix < B_NPIX ? pix : B_NPIX;
+        const int pr = pixc / B_PW, pc = pixc - pr * B_PW;
+        const int sy = y0 - 1 + pr, sx = x0 - 1 + pc;
+        const bool ok = pix < B_NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
+        s_ok[q] = ok;
+        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_lds[q] = pixc * P_LDB + c4 * 8;
+    }
+    f32x4 preg[B_SLOTS];
+    f32x4 pmean, pscale, pbeta;
+    auto patch_load = [&](int chunk) {
+        const float* xc = X + chunk * CK;
+#pragma unroll
+        for (int q = 0; q < B_SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+        if (PRO) {
+            pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
+        }
+    };
+    auto patch_store_slot = [&](int buf, int q) {
+        unsigned char* dst = smem_h + buf * B_BUF + s_lds[q];
+        bf16x4 oh, om, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = preg[q][e];
+            if (PRO) {
+                t = (t - pmean[e]) * pscale[e] + pbeta[e];
+                if (SWISH) t = vf_swish_1ulp(t);
+            }
+            __bf16 h, m, l;
+            split3(s_ok[q] ? t : 0.f, h, m, l);
+            oh[e] = h; om[e] = m; ol[e] = l;
+        }
+        *reinterpret_cast<bf16x4*>(dst) = oh;
+        *reinterpret_cast<bf16x4*>(dst + 64) = om;
+        *reinterpret_cast<bf16x4*>(dst + 128) = ol;
+    };
+
+    const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
+    int a_base[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a_base[mi] = ((wave_m * 8 + mi * 2 + trow) * B_PW + tpx) * P_LDB + half * 16;
+
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    bf16x8 bring[3][3][2];
+    bf16x8 aring[2][4][3];
+    const int last_g = nchunks * 18 - 1;
+    auto b_load = [&](bf16x8 (&dst)[3][2], int g) {
+        g = min(g, last_g);
+        const unsigned char* src = Wb + (size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES + b_lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const bf16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+    };
+    auto a_load = [&](bf16x8 (&dst)[4][3], const unsigned char* patch, int s) {
+        const int tap = s >> 1, ks = s & 1;
+        const int off = ((tap / 3) * B_PW + tap % 3) * P_LDB + ks * 32;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[mi][pl] = *reinterpret_cast<const bf16x8*>(patch + a_base[mi] + off + pl * 64);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    patch_load(0);
+    b_load(bring[0], 0);
+    b_load(bring[1], 1);
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) patch_store_slot(0, q);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned char* patch = smem_h + (chunk & 1) * B_BUF;
+        patch_load(min(chunk + 1, nchunks - 1));
+        a_load(aring[0], patch, 0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            b_load(bring[(s + 2) % 3], chunk * 18 + s + 2);
+#ifndef VF_X6_BIG_AMID
+#define VF_X6_BIG_AMID 1      // the next stage's LDS fragments are issued before product t = AMID (one wave per SIMD: nothing else hides
+#endif                        // their latency; left to the scheduler they sink to the end of the stage)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if (t == VF_X6_BIG_AMID) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi][PA[t]], bring[s % 3][PB[t]][j], acc[mi][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s >= 1 && s <= B_SLOTS) patch_store_slot((chunk + 1) & 1, s - 1);
+        }
+        __syncthreads();
+    }
+    // the wave's 8 rows are exactly one 8x16 tile of the epilogue's (and the GroupNorm slots') geometry: rows 0-3 then 4-7
+    const int ty8 = ty * 2 + wave_m;
+    const f32x16 (&lo)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[0]);
+    const f32x16 (&hi)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[2]);
+    vf_halo_epilogue<false>(p, lo, img, img, ty8 * TH, x0, (ty8 * tilesX + tx) * 2, nblk, 0, wave_n, half, l31);
+    vf_halo_epilogue<false>(p, hi, img, img, ty8 * TH, x0, (ty8 * tilesX + tx) * 2, nblk, 1, wave_n, half, l31);
+}
+
 // ---- stride-2 form: Downsample = pad (right, bottom) by one, 3x3 stride 2 (vqgan_th.py:45-49) ------------------------
 // One 8x16 OUTPUT tile needs a 17x33 input patch; it is staged 16 channels at a time (112-byte pixel stride) in ONE LDS
 // buffer (62 KB -> two workgroups per CU, which cover each other's staging), stored by column parity
@@ -474,6 +630,27 @@ int vf_conv3_halo_x6(const vf_igemm_args* args, void* stream) {
     if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
     if (int st = vf_halo_gn_check(a)) return st;
     hipStream_t s = (hipStream_t)stream;
+#ifndef VF_X6_BIG
+#define VF_X6_BIG 0      // A/B result (profiles/r1_x6_feed_probe.txt): 216-225 TF, the same as the 8x16 kernel -> kept opt-in
+#endif
+    if (VF_X6_BIG && a.mode == VF_MODE_CONV3_S1 && !pair && a.Hout % BTH == 0) {
+        const long long blocks = (long long)(a.M / (a.Hout * a.Wout)) * (a.Hout / BTH) * (a.Wout / TW) * (a.Cout / BN);
+        const size_t smem = (size_t)2 * B_BUF;
+        static bool attr_set = false;
+        if (!attr_set) {
+            for (const void* f : {reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<false, false>),
+                                  reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<true, false>),
+                                  reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<true, true>)}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return (int)e;
+            }
+            attr_set = true;
+        }
+        if (!a.pro_mean) hipLaunchKernelGGL((conv3_halo_x6_big_kernel<false, false>), dim3((unsigned)blocks), dim3(256), smem, s, a);
+        else if (a.pro_swish) hipLaunchKernelGGL((conv3_halo_x6_big_kernel<true, true>), dim3((unsigned)blocks), dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((conv3_halo_x6_big_kernel<true, false>), dim3((unsigned)blocks), dim3(256), smem, s, a);
+        return vf_last_status();
+    }
     if (pair) return dispatch_pro<false, true>(a, s);
     return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);
 }
