@@ -104,7 +104,27 @@ def convin(n_img=224, H=128, C=128):
     print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
-ALL = dict(convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
+def clockprobe(n_img=56, C=128, H=128):
+    """needs a -DVF_X6_CLOCKPROBE build (tools/variants.sh): shader clock during the x6 conv from one workgroup's
+    s_memtime / s_memrealtime (100 MHz) stamps, delivered through the gn_part pointer"""
+    x = torch.randn(n_img * H * H, C, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.03
+    wp = ops.pack_conv3_x6(w)
+    out = torch.empty_like(x)
+    part = ops.new_gn_part(n_img, H, H, dev)
+    g = torch.ones(C, device=dev)
+    m, s = ops.groupnorm_stats(x, g, n_img, H * H, C)
+    M = n_img * H * H
+    fn = lambda: ops.igemm(x, wp, M, C, C, out, res=x, mode=ops.MODE_CONV3_S1, pro=(m, s, torch.zeros(C, device=dev)), pro_swish=True,
+                           Hin=H, Win=H, Hout=H, Wout=H, x6=True, gn_part=part)
+    ms = timeit(fn)
+    torch.cuda.synchronize()
+    d = part.view(-1)[:4].view(torch.int64).cpu().tolist()
+    print(f'x6 conv {ms:.3f} ms; one workgroup: {d[0]} shader cycles in {d[1] / 100.0:.1f} us -> sclk ~ {d[0] / (d[1] / 100.0) / 1e3:.2f} GHz')
+
+
+ALL = dict(clockprobe=clockprobe,
+           convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
+#ifdef VF_X6_CLOCKPROBE      // developer build: shader-clock / 100 MHz wall-clock stamps of one mid-grid workgroup into p.bias[0..3] (as raw bits)
+    const long long cp_c0 = __builtin_readcyclecounter(), cp_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int nb = p.Cout / BN;
     const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
@@ -250,6 +253,13 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x6_kernel(vf_igemm_args p) 
     }
 
     vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+#ifdef VF_X6_CLOCKPROBE
+    if (blockIdx.x == gridDim.x / 2 && tid == 0 && p.gn_part) {
+        long long* dbg = reinterpret_cast<long long*>(p.gn_part);
+        dbg[0] = __builtin_readcyclecounter() - cp_c0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - cp_w0;
+    }
+#endif
 }
 
 // ---- 16x16-pixel tile form (stride 1, H % 16 == 0, W % 16 == 0); opt-in (-DVF_X6_BIG=1), see the A/B note at the dispatch -------
