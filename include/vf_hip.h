@@ -280,9 +280,10 @@ int vf_gelu_bwd_f32(const float* u, const float* df, float* du, int64_t n, void*
  * dS = P*(dP - sum dP*P)*scale (zero where masked) in place on dp */
 int vf_softmax_mask_f32(float* s, int64_t batch, int T, int L, int mask_spec, float scale, void* stream);
 int vf_softmax_mask_bwd_f32(const float* p, float* dp, int64_t batch, int T, int L, int mask_spec, float scale, void* stream);
-/* tf.nn.sparse_softmax_cross_entropy_with_logits (migt.py:423): loss[r], dlogits[r][:] = (softmax - onehot)*row_weight[r] */
+/* tf.nn.sparse_softmax_cross_entropy_with_logits (migt.py:423) and its label-smoothed form (:99-104, y = onehot(1-eps) + eps/V):
+ * loss[r], dlogits[r][:] = (softmax - y)*row_weight[r] */
 int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* row_weight, float* loss, float* dlogits,
-                      int64_t rows, int V, void* stream);
+                      int64_t rows, int V, float label_smoothing, void* stream);
 /* pose MSE of QuaternionPoseRepresentation.call (migt.py:165-177): raw [rows][7], gt [rows/L][7] */
 int vf_pose_mse_f32(const float* raw, const float* gt, const float* row_weight, float* pos_loss, float* ori_loss, float* draw,
                     int64_t rows, int L, float position_multiplier, void* stream);

@@ -31,7 +31,8 @@ def losses(sd, cfg, poses, tokens, step=0, dtype=torch.float64):
     ids = tokens.reshape(B, S, -1).long()
     skip = cfg.n_loss_skip
     logits = out['logits'].reshape(B, S, ids.shape[-1], -1)
-    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1), reduction='none').reshape(B, S, -1)   # :423
+    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1), reduction='none',
+                         label_smoothing=float(cfg.label_smoothing)).reshape(B, S, -1)      # :420-423 (smoothed form :99-104)
     ce = ce[:, skip:].mean((1, 2))                                                      # :424-426
     loss = ce * cfg.image_generation_weight                                             # :428
     metrics = dict(ce_loss=ce.mean())

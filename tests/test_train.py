@@ -152,14 +152,15 @@ def test_backward_kernels_against_autograd(dev):
     assert _err(zc, z.double() * 3.0 / max(z.double().norm().item(), 3.0)) < 1e-6
 
 
-def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32'):
+def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothing=0.0):
     from viewformer_amd.config import MIGTConfig
     from viewformer_amd.migt import MIGT
     from viewformer_amd.train import MIGTTrainer
     from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
     from oracle import migt_oracle as mg
     cfg = MIGTConfig(**TINY_MIGT, dropout=0.0, n_loss_skip=1, localization_weight='cosine(0,2,10)' if loc else '0',
-                     pose_multiplier=0.2, learning_rate=1e-3, weight_decay=0.05, total_steps=50, gradient_clip_val=clip)
+                     pose_multiplier=0.2, learning_rate=1e-3, weight_decay=0.05, total_steps=50, gradient_clip_val=clip,
+                     label_smoothing=label_smoothing)
     sd = make_migt_weights(cfg, seed=seed, std=0.08)
     g = np.random.Generator(np.random.PCG64(seed + 3))
     t = cfg.token_image_size
@@ -234,7 +235,7 @@ def test_per_tensor_gradient_clipping(dev):
         from viewformer_amd.migt import MIGT
         from viewformer_amd.train import MIGTTrainer
         from viewformer_amd.weights import make_migt_weights
-        c2 = MIGTConfig(**TINY_MIGT, label_smoothing=0.1)      # unsupported options are refused, never ignored
+        c2 = MIGTConfig(**TINY_MIGT, random_pose_multiplier=2.0)      # unsupported options are refused, never ignored
         MIGTTrainer(MIGT(c2).load_state_dict(make_migt_weights(c2)).to(dev))
 
 
@@ -442,3 +443,17 @@ def test_train_step_with_dropout_matches_autograd_with_the_same_masks(dev):
     # and the no-dropout loss differs from both (dropout really is on)
     _, ref0 = to.gradients(sd, cfg, poses, tokens, step=3)
     assert abs(ref0['loss'] - ref_metrics['loss']) > 1e-4
+
+
+@pytest.mark.gpu
+def test_label_smoothing_matches_autograd(dev):
+    from oracle import train_oracle as to
+    cfg, sd, tokens, poses, tr = _setup(True, dev, label_smoothing=0.1)
+    tr.step_count = 3
+    metrics = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    grads, ref_metrics = to.gradients(sd, cfg, poses, tokens, step=3)
+    _, plain = to.gradients(sd, cfg.__class__(**{**cfg.__dict__, 'label_smoothing': 0.0}) if hasattr(cfg, '__dict__') else cfg, poses, tokens, step=3)
+    assert abs(float(metrics['ce_loss']) - ref_metrics['ce_loss']) < 1e-4
+    assert abs(ref_metrics['ce_loss'] - plain['ce_loss']) > 1e-3                 # smoothing really changes the loss
+    for name in tr.names:
+        assert _err(tr.g(name), grads[name].reshape(tr.slices[name][2])) < 2e-3, name

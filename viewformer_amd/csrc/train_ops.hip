@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256) void softmax_mask_bwd_kernel(const float* __re
 
 // ------------------------------------------------------------------ softmax cross-entropy (one wave per row)
 // loss[r] = lse - logit[target]; dlogits = (softmax - onehot) * w[r]   (sparse_softmax_cross_entropy_with_logits, migt.py:423)
+// label smoothing eps (migt.py:99-104): y = onehot (1 - eps) + eps / V  ->  loss = lse - (1 - eps) x[t] - (eps / V) sum_c x[c]
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int* __restrict__ target,
                                                  const float* __restrict__ w, float* __restrict__ loss, float* __restrict__ dl,
-                                                 long long rows, int V) {
+                                                 long long rows, int V, float eps) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -221,15 +222,17 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     float mx = -INFINITY;
     for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
     mx = vf_wave_max(mx);
-    float s = 0.f;
-    for (int c = lane; c < V; c += 64) s += expf(x[c] - mx);
+    float s = 0.f, sx = 0.f;
+    for (int c = lane; c < V; c += 64) { s += expf(x[c] - mx); sx += x[c]; }
     s = vf_wave_sum(s);
     const int t = target[row];
     const float lse = mx + logf(s);
-    if (lane == 0) loss[row] = lse - x[t];
+    const float uni = eps / (float)V;
+    if (eps != 0.f) sx = vf_wave_sum(sx);
+    if (lane == 0) loss[row] = eps != 0.f ? lse - (1.f - eps) * x[t] - uni * sx : lse - x[t];
     const float wr = w[row];
     float* d = dl + row * V;
-    for (int c = lane; c < V; c += 64) d[c] = (expf(x[c] - mx) / s - (c == t ? 1.f : 0.f)) * wr;
+    for (int c = lane; c < V; c += 64) d[c] = (expf(x[c] - mx) / s - ((c == t ? 1.f - eps : 0.f) + uni)) * wr;
 }
 
 // ------------------------------------------------------------------ pose MSE (migt.py:165-177): per token
@@ -428,10 +431,11 @@ int vf_softmax_mask_bwd_f32(const float* p, float* dp, int64_t batch, int T, int
 }
 
 int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* row_weight, float* loss, float* dlogits,
-                      int64_t rows, int V, void* stream) {
+                      int64_t rows, int V, float label_smoothing, void* stream) {
     if (!logits || !target || !row_weight || !loss || !dlogits || rows <= 0 || V <= 0) return VF_ERR_BAD_ARG;
+    if (!(label_smoothing >= 0.f && label_smoothing < 1.f)) return VF_ERR_BAD_ARG;
     hipLaunchKernelGGL(ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, row_weight,
-                       loss, dlogits, (long long)rows, V);
+                       loss, dlogits, (long long)rows, V, label_smoothing);
     return vf_last_status();
 }
 

@@ -20,7 +20,7 @@ counter-based mask — keep = hash(seed, site, element index) >= rate * 2^32 (cs
 ``dropout_seed`` and the step counter give the per-step seed.  The masks cannot coincide with TensorFlow's RNG stream; the tests
 check the kernels against autograd with the SAME masks restated in numpy (oracle/train_oracle.py).
 
-Limits (raise NotImplementedError otherwise): label_smoothing 0, random_pose_multiplier 1, no dynamic pose-loss weighting.
+Limits (raise NotImplementedError otherwise): random_pose_multiplier 1, no dynamic pose-loss weighting.
 """
 import math
 import re
@@ -79,8 +79,8 @@ class MIGTTrainer:
         if not 0.0 <= cfg.dropout < 1.0:
             raise ValueError('dropout must be in [0, 1)')
         self.dropout_seed = 0
-        if cfg.label_smoothing != 0 or cfg.random_pose_multiplier != 1 or cfg.use_dynamic_pose_loss:
-            raise NotImplementedError('label smoothing / random pose multiplier / dynamic pose loss are not built')
+        if cfg.random_pose_multiplier != 1 or cfg.use_dynamic_pose_loss:
+            raise NotImplementedError('random pose multiplier / dynamic pose loss are not built')
         if model._sd_host is None or model.device is None:
             raise RuntimeError('load_state_dict() and .to("cuda") the model first')
         self.model, self.cfg, self.dev = model, cfg, model.device
@@ -338,7 +338,7 @@ class MIGTTrainer:
         ops.igemm(hmask, m._lm_head, M1, d, nE, logits)
         tgt = tok.reshape(M1).to(torch.int32).contiguous()
         w_ce = (view_ok * (c.image_generation_weight / denom)).contiguous()
-        ce_rows, dlogits = T.softmax_ce(logits, tgt, w_ce, M1, nE)
+        ce_rows, dlogits = T.softmax_ce(logits, tgt, w_ce, M1, nE, c.label_smoothing)        # :420-423
         ce_b = ce_rows.view(B, S, L)[:, skip:].mean((1, 2))
         loss_b = ce_b * c.image_generation_weight
         metrics = dict(ce_loss=ce_b.mean())

@@ -72,11 +72,11 @@ def softmax_mask_bwd_(p, dp, batch, T, L, mask_spec, scale=1.0):
     return dp
 
 
-def softmax_ce(logits, target_i32, row_weight, rows, V):
+def softmax_ce(logits, target_i32, row_weight, rows, V, label_smoothing=0.0):
     loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
     dl = torch.empty((rows, V), dtype=torch.float32, device=logits.device)
     check(_lib.load().vf_softmax_ce_f32(_p(_f32(logits)), _p(_chk(target_i32, torch.int32)), _p(_f32(row_weight)), _p(loss), _p(dl),
-                                        rows, V, _stream()), 'vf_softmax_ce_f32')
+                                        rows, V, float(label_smoothing), _stream()), 'vf_softmax_ce_f32')
     return loss, dl
 
 
