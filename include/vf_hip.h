@@ -235,6 +235,18 @@ int vf_gemm_x6(const vf_igemm_args* args /* host */, void* stream);
 int vf_sum_slabs_f32(const float* slabs, int nslabs, int64_t stride, int64_t n, float* dst, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Training branch of the codebook quantizer: the EMA codebook update of QuantizeEMA.forward (utils_th.py:46-64).
+ * accumulate: counts[k] = #rows with idx == k (:47), embed_sum[d][k] = sum of those rows of z (:48) — rows added in index order,
+ * no atomics (bit-reproducible).  The caller all-reduces counts / embed_sum over replicas (:50-52), then
+ * update: EMA buffers (:55-56), bias correction corr = 1 - decay^counter (:24-30), Laplace smoothing (:59-62),
+ * embeddings = ema_dw / cluster_size (:63-64).  E, embed_sum, dw_hidden are [D][Kc] like the reference's buffers.
+ * ------------------------------------------------------------------------------------- */
+int vf_vq_ema_accumulate_f32(const float* z, const int64_t* idx, int64_t M, int D, int Kc, float* counts, float* embed_sum,
+                             void* stream);
+int vf_vq_ema_update_f32(const float* counts, const float* embed_sum, float* cluster_size_hidden, float* dw_hidden,
+                         float* embeddings, int D, int Kc, float decay, float eps, float corr, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.

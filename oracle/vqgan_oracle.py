@@ -161,6 +161,35 @@ def quantize(sd, z_nchw, dtype=torch.float32):
     return q, diff, ind
 
 
+def quantize_train_step(state, z_nchw, decay=0.99, eps=1e-5, all_reduce=None, dtype=torch.float32):
+    """QuantizeEMA.forward TRAINING branch, utils_th.py:32-68.  ``state`` = dict(embeddings [D,K], ema_cluster_size_hidden [K],
+    ema_dw_hidden [D,K], counter int) is updated in place exactly as the reference's buffers are: the lookup and the returned
+    quantize/diff use the embeddings BEFORE the update (:41-44), then the per-code counts and sums (:47-48) are optionally
+    all-reduced over replicas (:50-52), folded into the EMA buffers (:55-57) and turned into the new, bias-corrected and
+    Laplace-smoothed embeddings (:59-64).  ``all_reduce(t)`` sums a tensor over replicas in place (None = single replica)."""
+    emb = state['embeddings'].to(dtype)
+    q, diff, ind = quantize({'quantize.embeddings': emb}, z_nchw, dtype)
+    K = emb.shape[1]
+    x = z_nchw.to(dtype).permute(0, 2, 3, 1)
+    flatten = x.reshape(-1, x.size(-1))
+    onehot = F.one_hot(ind.reshape(-1), K).to(dtype)
+    counts = onehot.sum(0)                                              # :47
+    embed_sum = flatten.transpose(0, 1) @ onehot                        # :48
+    if all_reduce is not None:                                          # :50-52
+        all_reduce(counts)
+        all_reduce(embed_sum)
+    cs, dw = state['ema_cluster_size_hidden'].to(dtype), state['ema_dw_hidden'].to(dtype)
+    cs = cs + (counts - cs) * (1 - decay)                               # :55  (Tensor.add_(other, alpha))
+    dw = dw + (embed_sum - dw) * (1 - decay)                            # :56
+    counter = int(state['counter']) + 1                                 # :57
+    corr = 1.0 - torch.pow(torch.tensor(decay, dtype=dtype), counter)   # bias correction of the properties :24-30
+    ema_cs, ema_dw = cs / corr, dw / corr
+    n = ema_cs.sum()                                                    # :59
+    cluster = (ema_cs + eps) / (n + K * eps) * n                        # :60-62
+    state.update(embeddings=ema_dw / cluster.unsqueeze(0), ema_cluster_size_hidden=cs, ema_dw_hidden=dw, counter=counter)   # :63-64
+    return q, diff, ind
+
+
 def encode_z(sd, cfg, x, dtype=torch.float32):
     """encoder + quant_conv (vqgan_th.py:380-381): the vectors fed to the lookup."""
     return conv(sd, 'quant_conv', encoder(sd, cfg, x, dtype), dtype)

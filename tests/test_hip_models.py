@@ -275,3 +275,54 @@ def test_full_size_pipeline_properties(dev, full_vq):
         outs[arm] = a
     assert torch.equal(outs['f32']['codes'], outs['bf16']['codes'])                          # the encoder is fp32 in both arms
     assert outs['f32']['generated_images'].dtype == torch.uint8
+
+
+def test_quantizer_ema_training_matches_reference_golden(dev):
+    """QuantizeEMA.forward training branch on the GPU (vq_train.QuantizeEMATrainer) vs three steps recorded from the reference"""
+    import os
+    from viewformer_amd.vq_train import QuantizeEMATrainer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vq_ema.npz'))
+    tr = QuantizeEMATrainer(torch.from_numpy(g['E0']).to(dev), decay=float(g['decay']), eps=float(g['eps']))
+    for step in range(3):
+        q, diff, ind = tr(torch.from_numpy(g[f'z{step}']).to(dev))
+        assert np.array_equal(ind.cpu().numpy(), g[f'ind{step}'])
+        assert abs(float(diff) - float(g[f'diff{step}'])) < 1e-6
+        assert np.allclose(q.cpu().numpy(), g[f'quant{step}'], atol=1e-6)
+        sd = tr.state_dict()
+        assert int(sd['quantize.counter']) == int(g[f'counter{step + 1}'])
+        assert np.allclose(sd['quantize.ema_cluster_size_hidden'].cpu().numpy(), g[f'cs{step + 1}'], rtol=1e-6, atol=1e-7)
+        assert np.allclose(sd['quantize.ema_dw_hidden'].cpu().numpy(), g[f'dw{step + 1}'], rtol=1e-5, atol=1e-6)
+        assert np.allclose(sd['quantize.embeddings'].cpu().numpy(), g[f'E{step + 1}'], rtol=2e-5, atol=1e-6)
+    tr.training = False                                       # eval: lookup only, the codebook stays put
+    E = tr.embeddings.clone()
+    tr(torch.from_numpy(g['z0']).to(dev))
+    assert torch.equal(E, tr.embeddings)
+
+
+def test_quantizer_ema_accumulate_is_deterministic_and_additive_over_replicas(dev):
+    """full-size codebook (256 x 1024): counts / sums of a batch == the sum over its two halves (what the all-reduce of
+    utils_th.py:50-52 relies on), bit-reproducible run to run, and equal to the one-hot matmul of the reference"""
+    from viewformer_amd import _lib, ops
+    from viewformer_amd.ops import _p, _stream
+    lib = _lib.load()
+    D, Kc, M = 256, 1024, 14336
+    g = np.random.Generator(np.random.PCG64(9))
+    z = torch.from_numpy((g.standard_normal((M, D)) * 0.3).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(g.integers(0, 300, size=M)).to(dev)          # skewed: many empty codes, some heavy ones
+
+    def acc(zz, ii):
+        c = torch.full((Kc,), float('nan'), device=dev)
+        s = torch.full((D, Kc), float('nan'), device=dev)
+        _lib.check(lib.vf_vq_ema_accumulate_f32(_p(zz), _p(ii), zz.shape[0], D, Kc, _p(c), _p(s), _stream()), 'acc')
+        return c, s
+    c, s = acc(z, idx)
+    c2, s2 = acc(z, idx)
+    assert torch.equal(c, c2) and torch.equal(s, s2)
+    onehot = torch.nn.functional.one_hot(idx, Kc).double()
+    assert torch.equal(c.double(), onehot.sum(0))
+    ref = z.double().t() @ onehot
+    assert ((s.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    ca, sa = acc(z[:M // 2].contiguous(), idx[:M // 2].contiguous())
+    cb, sb = acc(z[M // 2:].contiguous(), idx[M // 2:].contiguous())
+    assert torch.equal(ca + cb, c)
+    assert ((sa + sb - s).abs().max() / s.abs().max()).item() < 1e-6

@@ -76,3 +76,23 @@ def test_pre_post_process_semantics():
     assert torch.equal(back, u8)                             # 255.5 scale + truncation round-trips every level
     y = vq.postprocess_u8(torch.tensor([-3.0, -1.0, 0.0, 0.999, 1.0, 7.0]).reshape(1, 1, 1, 6).repeat(1, 3, 1, 1))
     assert y[0, 0, :, 0].tolist() == [0, 0, 127, 255, 255, 255]
+
+
+def test_quantizer_ema_training_branch_matches_reference_golden():
+    """QuantizeEMA.forward with self.training (utils_th.py:46-64): three consecutive steps recorded from the reference"""
+    import os
+    import numpy as np
+    import torch
+    from oracle import vqgan_oracle as vq
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vq_ema.npz'))
+    D, K = g['E0'].shape
+    state = dict(embeddings=torch.from_numpy(g['E0']), ema_cluster_size_hidden=torch.zeros(K), ema_dw_hidden=torch.zeros(D, K), counter=0)
+    for step in range(3):
+        q, diff, ind = vq.quantize_train_step(state, torch.from_numpy(g[f'z{step}']), float(g['decay']), float(g['eps']))
+        assert np.array_equal(ind.numpy(), g[f'ind{step}'])
+        assert abs(float(diff) - float(g[f'diff{step}'])) < 1e-6
+        assert np.allclose(q.numpy(), g[f'quant{step}'], atol=1e-6)
+        assert state['counter'] == int(g[f'counter{step + 1}'])
+        assert np.allclose(state['ema_cluster_size_hidden'].numpy(), g[f'cs{step + 1}'], rtol=1e-6, atol=1e-7)
+        assert np.allclose(state['ema_dw_hidden'].numpy(), g[f'dw{step + 1}'], rtol=1e-5, atol=1e-6)
+        assert np.allclose(state['embeddings'].numpy(), g[f'E{step + 1}'], rtol=2e-5, atol=1e-6)

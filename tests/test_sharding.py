@@ -49,3 +49,40 @@ def test_world2_gloo_shards_cover_all_scenes(tmp_path):
     res = torch.load(out)
     assert res['t'] == 1.5 and res['total'] == 7.0
     assert torch.equal(res['all'], torch.arange(7) * 3 + 1)
+
+
+def _ema_worker(rank, world, port, out):
+    """two replicas, each with half of the batch: the quantizer's two all-reduces (utils_th.py:50-52) make both hold the state a
+    single replica would reach on the whole batch"""
+    import numpy as np
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import vqgan_oracle as vq
+    from viewformer_amd import sharding
+    sharding.init_from_env('gloo')
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vq_ema.npz'))
+    D, K = g['E0'].shape
+    state = dict(embeddings=torch.from_numpy(g['E0']), ema_cluster_size_hidden=torch.zeros(K), ema_dw_hidden=torch.zeros(D, K), counter=0)
+    z = torch.from_numpy(np.concatenate([g['z0'], g['z1']], 0))          # 6 images: 3 per replica
+    mine = z[rank * 3:(rank + 1) * 3]
+    vq.quantize_train_step(state, mine, float(g['decay']), float(g['eps']), all_reduce=lambda t: dist.all_reduce(t))
+    torch.save(state, out + f'.{rank}')
+    dist.destroy_process_group()
+
+
+def test_world2_quantizer_ema_allreduce_protocol(tmp_path):
+    import numpy as np
+    from oracle import vqgan_oracle as vq
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'ema')
+    mp.spawn(_ema_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + '.0'), torch.load(out + '.1')
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vq_ema.npz'))
+    D, K = g['E0'].shape
+    one = dict(embeddings=torch.from_numpy(g['E0']), ema_cluster_size_hidden=torch.zeros(K), ema_dw_hidden=torch.zeros(D, K), counter=0)
+    vq.quantize_train_step(one, torch.from_numpy(np.concatenate([g['z0'], g['z1']], 0)), float(g['decay']), float(g['eps']))
+    for key in ('embeddings', 'ema_cluster_size_hidden', 'ema_dw_hidden'):
+        assert torch.equal(a[key], b[key])                                # replicas agree bit for bit
+        assert torch.allclose(a[key], one[key], rtol=1e-5, atol=1e-7)     # and equal the single-replica update on the whole batch

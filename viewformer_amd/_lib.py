@@ -47,6 +47,8 @@ EXPORTS = {
     'vf_vq_pack_codebook_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_colsumsq_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_vq_argmin_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),
+    'vf_vq_ema_accumulate_f32': (c_int, [P, P, c_int64, c_int, c_int, P, P, P]),
+    'vf_vq_ema_update_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, P]),
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, P]),
