@@ -247,6 +247,27 @@ int vf_vq_ema_update_f32(const float* counts, const float* embed_sum, float* clu
                          float* embeddings, int D, int Kc, float decay, float eps, float corr, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Backward-pass helpers of the codebook (VQGAN) training step (vqgan_th.py:349-368,427-429).  The contractions of that backward
+ * pass are launches of the forward conv / GEMM entry points on re-packed operands; these are the remaining HBM-bound pieces.
+ * ------------------------------------------------------------------------------------- */
+/* dst[c][p] = src[img][y*stride+oy][x*stride+ox][c] (0 outside), p = (img,y,x) over Hout x Wout: the tap-shifted channel-major
+ * activation that makes conv dW one GEMM per tap */
+int vf_gather_transpose_f32(const float* src, float* dst, int n_img, int Hin, int Win, int C, int Hout, int Wout, int stride, int oy,
+                            int ox, int64_t ld_dst, void* stream);
+/* nearest-x2 upsample backward (Upsample.forward vqgan_th.py:29-32): dx = 2x2 block sums of du [n][2H][2W][C] */
+int vf_upsample2_bwd_f32(const float* du, float* dx, int n_img, int H, int W, int C, void* stream);
+/* GroupNorm(+swish) backward (Normalize / nonlinearity vqgan_th.py:11-17): dx (+=), chan_sums [n_img][C][2] = {dgamma, dbeta} parts */
+size_t vf_groupnorm_bwd_workspace_bytes(int n_img, int HW, int C, int groups);
+int vf_groupnorm_bwd_f32(const float* x, const float* da, const float* mean_c, const float* scale_c, const float* gamma,
+                         const float* beta, float* dx, float* chan_sums, int n_img, int HW, int C, int groups, int swish,
+                         int accumulate, void* ws, void* stream);
+/* row softmax backward (AttnBlock vqgan_th.py:132-134): dp <- scale * p * (dp - sum p dp) in place */
+int vf_softmax_rows_bwd_f32(const float* p, float* dp, int64_t rows, int n, float scale, void* stream);
+/* L1 reconstruction loss (vqgan_th.py:355,361): partial sums of |y - x| (vf_l1_loss_partials(n) of them) and dy = sign(y-x)*w */
+int vf_l1_loss_partials(int64_t n);
+int vf_l1_loss_f32(const float* x, const float* y, float* dy, float* part, int64_t n, float grad_weight, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.

@@ -96,3 +96,64 @@ def test_quantizer_ema_training_branch_matches_reference_golden():
         assert np.allclose(state['ema_cluster_size_hidden'].numpy(), g[f'cs{step + 1}'], rtol=1e-6, atol=1e-7)
         assert np.allclose(state['ema_dw_hidden'].numpy(), g[f'dw{step + 1}'], rtol=1e-5, atol=1e-6)
         assert np.allclose(state['embeddings'].numpy(), g[f'E{step + 1}'], rtol=2e-5, atol=1e-6)
+
+
+def _summary(t):
+    f = np.asarray(t, dtype=np.float64).reshape(-1)
+    n = f.size
+    return np.array([np.linalg.norm(f), f.sum(), f[0], f[n // 2], f[n - 1]])
+
+
+def test_vqgan_training_step_oracle_matches_reference_golden():
+    """loss terms, the gradient of every parameter, the EMA codebook after the forward and two Adam steps vs the reference"""
+    import os
+    from oracle import vqgan_oracle as vq
+    from oracle import vqgan_train_oracle as vt
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.weights import make_vqgan_weights
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vqgan_train_tiny.npz'))
+    cfg = VQGANConfig(ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], image_size=32, z_channels=32, embed_dim=32,
+                      n_embed=64, perceptual_weight=0.0, codebook_weight=1.0, learning_rate=1e-3)
+    sd = make_vqgan_weights(cfg, seed=int(g['seed']), codebook_scale=float(g['codebook_scale']))
+    x = vq.preprocess_u8(torch.from_numpy(g['frames']))
+    names = [str(n) for n in g['param_names']]
+    params = {k: np.asarray(sd[k], dtype=np.float64) for k in names}
+    bufs = {k: np.asarray(sd[k]) for k in vt.BUFFERS}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    state = dict(embeddings=torch.from_numpy(np.asarray(bufs['quantize.embeddings'], dtype=np.float32)),
+                 ema_cluster_size_hidden=torch.zeros(64), ema_dw_hidden=torch.zeros(32, 64), counter=0)
+    for step in (1, 2):
+        cur = dict(params)
+        cur.update({k: np.asarray(val) for k, val in bufs.items()})
+        cur['quantize.embeddings'] = state['embeddings'].numpy()
+        grads, metrics, extra = vt.gradients(cur, cfg, x)
+        if step == 1:
+            assert abs(metrics['loss'] - float(g['loss'])) < 2e-6
+            assert abs(metrics['rec_loss'] - float(g['rec_loss'])) < 2e-6 and abs(metrics['quant_loss'] - float(g['quant_loss'])) < 1e-6
+            for i, n in enumerate(names):
+                got, want = _summary(grads[n].numpy()), g['grad_summary'][i]
+                assert np.allclose(got, want, rtol=2e-3, atol=2e-7), (n, got, want)
+            for key in g.files:
+                if key.startswith('grad:'):
+                    assert np.allclose(grads[key[5:]].numpy(), g[key], rtol=2e-3, atol=2e-7), key
+        # the forward in training mode moves the codebook (utils_th.py:46-64) ...
+        vq.quantize_train_step(state, extra['z'].detach().float(), 0.99, 1e-5)
+        if step == 1:
+            assert np.allclose(state['embeddings'].numpy(), g['E_after_fwd'], rtol=1e-4, atol=1e-6)
+            assert np.allclose(state['ema_cluster_size_hidden'].numpy(), g['cs_after_fwd'], rtol=1e-5, atol=1e-7)
+        # ... then Adam moves everything else
+        vt.adam_step(params, {k: grads[k].numpy() for k in names}, m, v2, step, float(g['lr']))
+        want = g[f'param_summary_step{step}']
+        for i, n in enumerate(names):
+            if g['grad_summary'][i][0] < 1e-6:
+                # a bias in front of a per-channel GroupNorm (32 channels, 32 groups) has a mathematically zero gradient: Adam turns
+                # the rounding noise into +-lr steps whose signs no two implementations share — bound the drift instead
+                lim = 1.01 * float(g['lr']) * step
+                assert np.all(np.abs(params[n] - np.asarray(sd[n], dtype=np.float64)) <= lim), (step, n)
+                continue
+            # (the first Adam steps are sign-like: elements whose gradient is rounding noise move by +-lr with implementation-
+            # dependent sign, so the SUM is not comparable; the norm and the sampled elements are)
+            got = _summary(params[n])
+            assert np.allclose(got[[0, 2, 3, 4]], want[i][[0, 2, 3, 4]], rtol=1e-4, atol=2.1 * float(g['lr']) * step), (step, n)
+            assert abs(got[0] - want[i][0]) < 1e-4 * want[i][0] + 1e-6, (step, n)

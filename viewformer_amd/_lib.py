@@ -47,6 +47,13 @@ EXPORTS = {
     'vf_vq_pack_codebook_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_colsumsq_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_vq_argmin_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),
+    'vf_gather_transpose_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, P]),
+    'vf_upsample2_bwd_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_groupnorm_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'vf_groupnorm_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'vf_softmax_rows_bwd_f32': (c_int, [P, P, c_int64, c_int, c_float, P]),
+    'vf_l1_loss_partials': (c_int, [c_int64]),
+    'vf_l1_loss_f32': (c_int, [P, P, P, P, c_int64, c_float, P]),
     'vf_vq_ema_accumulate_f32': (c_int, [P, P, c_int64, c_int, c_int, P, P, P]),
     'vf_vq_ema_update_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, P]),
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),

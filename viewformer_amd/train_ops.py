@@ -146,3 +146,50 @@ def dropout_add(x, rate, seed, site, res=None, out=None):
     check(_lib.load().vf_dropout_add_f32(_p(_f32(x)), _p(_f32(res)) if res is not None else None, _p(out), x.numel(), float(rate),
                                          int(seed) & 0xFFFFFFFF, int(site), _stream()), 'vf_dropout_add_f32')
     return out
+
+
+# ------------------------------------------------------------------ VQGAN backward helpers (csrc/vqgan_bwd.hip)
+def gather_transpose(src, n_img, Hin, Win, C, Hout, Wout, stride=1, oy=0, ox=0):
+    """[C][n_img*Hout*Wout]: channel-major, tap-shifted view of an NHWC activation (zero outside the image)"""
+    P = n_img * Hout * Wout
+    dst = torch.empty((C, P), dtype=torch.float32, device=src.device)
+    check(_lib.load().vf_gather_transpose_f32(_p(_f32(src)), _p(dst), n_img, Hin, Win, C, Hout, Wout, stride, oy, ox, P, _stream()),
+          'vf_gather_transpose_f32')
+    return dst
+
+
+def upsample2_bwd(du, n_img, H, W, C):
+    dx = torch.empty((n_img * H * W, C), dtype=torch.float32, device=du.device)
+    check(_lib.load().vf_upsample2_bwd_f32(_p(_f32(du)), _p(dx), n_img, H, W, C, _stream()), 'vf_upsample2_bwd_f32')
+    return dx
+
+
+def groupnorm_bwd(x, da, mean_c, scale_c, gamma, beta, n_img, HW, C, swish, groups=32):
+    """-> (dx, dgamma [C], dbeta [C]) of a = swish?(GroupNorm(x))"""
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    chan = torch.empty((n_img, C, 2), dtype=torch.float32, device=x.device)
+    ws = _ws(int(lib.vf_groupnorm_bwd_workspace_bytes(n_img, HW, C, groups)), x.device, 'gnbwd')
+    check(lib.vf_groupnorm_bwd_f32(_p(_f32(x)), _p(_f32(da)), _p(mean_c), _p(scale_c), _p(_f32(gamma)), _p(_f32(beta)), _p(dx),
+                                   _p(chan), n_img, HW, C, groups, 1 if swish else 0, 0, _p(ws), _stream()), 'vf_groupnorm_bwd_f32')
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    colsum(chan.view(n_img, 2 * C), sums, n_img, 2 * C)
+    sums = sums.view(C, 2)
+    return dx, sums[:, 0].contiguous(), sums[:, 1].contiguous()
+
+
+def softmax_rows_bwd_(p, dp, rows, n, scale):
+    check(_lib.load().vf_softmax_rows_bwd_f32(_p(_f32(p)), _p(_f32(dp)), rows, n, float(scale), _stream()), 'vf_softmax_rows_bwd_f32')
+    return dp
+
+
+def l1_loss(x, y, grad_weight):
+    """-> (sum |y - x| as a 0-d tensor, dy = sign(y - x) * grad_weight)"""
+    lib = _lib.load()
+    n = x.numel()
+    dy = torch.empty_like(y)
+    part = torch.empty(int(lib.vf_l1_loss_partials(n)), dtype=torch.float32, device=x.device)
+    check(lib.vf_l1_loss_f32(_p(_f32(x)), _p(_f32(y)), _p(dy), _p(part), n, float(grad_weight), _stream()), 'vf_l1_loss_f32')
+    total = torch.empty(1, dtype=torch.float32, device=x.device)
+    colsum(part.view(-1, 1), total, part.numel(), 1)
+    return total[0], dy
