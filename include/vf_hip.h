@@ -330,6 +330,8 @@ int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* 
 int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_decay, float lr_adam, float beta1,
                  float beta2, float eps, void* stream);
 int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream);
+/* out = a*x + b*y (y may be NULL: out = a*x); out may alias x or y */
+int vf_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);
 /* tf.clip_by_norm per tensor (migt.py:486-487): x *= clip / max(||x||, clip); scratch1 = one float */
 int vf_clip_by_norm_f32(float* x, int64_t n, float clip, float* scratch1, void* stream);
 

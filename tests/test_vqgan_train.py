@@ -1,0 +1,147 @@
+"""Codebook (VQGAN) training step on the GPU vs the oracle restatement and the reference-recorded golden.
+
+The oracle (oracle/vqgan_train_oracle.py, fp64 autograd) is pinned to the reference by tests/test_oracle_vqgan.py; here the HIP
+training step (viewformer_amd/vqgan_train.py) is compared with both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'vqgan_train_tiny.npz')
+
+
+def _summary(t):
+    f = np.asarray(t, dtype=np.float64).reshape(-1)
+    n = f.size
+    return np.array([np.linalg.norm(f), f.sum(), f[0], f[n // 2], f[n - 1]])
+
+
+def _tiny():
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.weights import make_vqgan_weights
+    g = np.load(GOLD)
+    cfg = VQGANConfig(ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], image_size=32, z_channels=32, embed_dim=32,
+                      n_embed=64, perceptual_weight=0.0, codebook_weight=1.0, learning_rate=1e-3)
+    sd = make_vqgan_weights(cfg, seed=int(g['seed']), codebook_scale=float(g['codebook_scale']))
+    return g, cfg, sd
+
+
+def _trainer(cfg, sd, **kw):
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.vqgan_train import VQGANTrainer
+    model = VQGAN(cfg, device='cuda')
+    model.load_state_dict(sd)
+    return VQGANTrainer(model, **kw)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def test_training_step_matches_reference_golden_and_oracle():
+    """loss terms, all 154 gradients, the EMA codebook after the forward, and two Adam steps"""
+    from oracle import vqgan_oracle as vq
+    from oracle import vqgan_train_oracle as vt
+    g, cfg, sd = _tiny()
+    x = vq.preprocess_u8(torch.from_numpy(g['frames']))                      # NCHW float32 in [-1, 1]
+    names = [str(n) for n in g['param_names']]
+    tr = _trainer(cfg, sd)
+    assert sorted(tr.names) == sorted(names)
+    m = tr.train_step(x, apply_update=False)
+    torch.cuda.synchronize()
+    assert abs(float(m['total_loss']) - float(g['loss'])) < 5e-6
+    assert abs(float(m['rec_loss']) - float(g['rec_loss'])) < 5e-6
+    assert abs(float(m['quant_loss']) - float(g['quant_loss'])) < 2e-6
+    # ---- every gradient against the fp64 oracle (elementwise) and the reference's recorded summaries
+    grads, metrics, extra = vt.gradients({k: np.asarray(v) for k, v in sd.items()}, cfg, x)
+    assert torch.equal(tr.last_indices.cpu().view(-1), extra['ind'].view(-1))
+    worst, bad = 0.0, []
+    for i, n in enumerate(names):
+        got = tr.g(n).cpu().numpy()
+        want = grads[n].numpy()
+        gn = float(g['grad_summary'][i][0])
+        if gn < 1e-6:                                                         # mathematically zero (bias before a per-channel norm)
+            if not np.abs(got).max() < 1e-6:
+                bad.append((n, 'nonzero', float(np.abs(got).max())))
+            continue
+        r = _rel(got, want)
+        worst = max(worst, r)
+        s = _summary(got)
+        if not (r < 2e-4 and np.allclose(s[[0, 2, 3, 4]], g['grad_summary'][i][[0, 2, 3, 4]], rtol=2e-3, atol=1e-6)):
+            bad.append((n, r, float(np.linalg.norm(got)), float(np.linalg.norm(want))))
+    assert not bad, '\n'.join(map(str, bad))
+    for key in g.files:
+        if key.startswith('grad:'):
+            assert np.allclose(tr.g(key[5:]).cpu().numpy(), g[key], rtol=2e-3, atol=1e-6), key
+    print('worst relative gradient error vs fp64 oracle', worst)
+    # ---- the forward moved the codebook
+    qs = tr.quantizer.state_dict()
+    assert np.allclose(qs['quantize.embeddings'].cpu().numpy(), g['E_after_fwd'], rtol=1e-4, atol=1e-6)
+    assert np.allclose(qs['quantize.ema_cluster_size_hidden'].cpu().numpy(), g['cs_after_fwd'], rtol=1e-5, atol=1e-7)
+    # ---- two optimizer steps
+    tr.apply_gradients()
+    lr = float(g['lr'])
+    for step in (1, 2):
+        if step == 2:
+            m2 = tr.train_step(x)
+            assert abs(float(m2['total_loss']) - float(g['loss_step2'])) < 1e-4                # the loss of the second forward
+        want = g[f'param_summary_step{step}']
+        for i, n in enumerate(names):
+            p = tr.p(n).cpu().numpy().astype(np.float64)
+            if g['grad_summary'][i][0] < 1e-6:
+                assert np.all(np.abs(p - np.asarray(sd[n], np.float64)) <= 1.01 * lr * step), (step, n)
+                continue
+            got = _summary(p)
+            assert np.allclose(got[[0, 2, 3, 4]], want[i][[0, 2, 3, 4]], rtol=1e-4, atol=2.1 * lr * step), (step, n)
+            assert abs(got[0] - want[i][0]) < 1e-4 * want[i][0] + 1e-6, (step, n)
+
+
+def test_training_reduces_the_loss_and_syncs_back():
+    """a few steps on one batch drive the reconstruction loss down; sync_model() makes the inference model use the trained weights"""
+    from oracle import vqgan_oracle as vq
+    g, cfg, sd = _tiny()
+    x = vq.preprocess_u8(torch.from_numpy(g['frames']))
+    tr = _trainer(cfg, sd)
+    first = float(tr.train_step(x)['total_loss'])
+    for _ in range(15):
+        last = float(tr.train_step(x)['total_loss'])
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
+    model = tr.sync_model()
+    codes = model.encode_codes(x.cuda())
+    assert codes.shape == (x.shape[0], 16, 16)
+
+
+@pytest.mark.parametrize('cfgkw,n', [
+    (dict(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], image_size=32, z_channels=64, embed_dim=64, n_embed=128), 4),
+    (dict(ch=128, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[16], image_size=64, z_channels=128, embed_dim=64, n_embed=128), 2),
+])
+def test_gradients_match_oracle_on_wide_configs(cfgkw, n):
+    """channel counts that route the 3x3 convolutions to the split-bf16 halo kernels (Cout % 128 == 0) and all three conv modes"""
+    from oracle import vqgan_train_oracle as vt
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.weights import make_vqgan_weights
+    cfg = VQGANConfig(perceptual_weight=0.0, codebook_weight=0.7, learning_rate=1e-3, **cfgkw)
+    sd = make_vqgan_weights(cfg, seed=11, codebook_scale=1.0)
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(n, 3, cfg.image_size, cfg.image_size)).astype(np.float32))
+    tr = _trainer(cfg, sd)
+    m = tr.train_step(x, apply_update=False)
+    grads, metrics, extra = vt.gradients({k: np.asarray(v) for k, v in sd.items()}, cfg, x)
+    assert abs(float(m['total_loss']) - metrics['loss']) < 1e-5 * max(1.0, abs(metrics['loss']))
+    same = (tr.last_indices.cpu().view(-1) == extra['ind'].view(-1)).float().mean().item()
+    assert same == 1.0, same
+    gmax = max(float(v.norm()) for v in grads.values())
+    bad = []
+    for name in tr.names:
+        want = grads[name].numpy()
+        got = tr.g(name).cpu().numpy()
+        if np.linalg.norm(want) < 1e-7 * gmax:
+            if not np.linalg.norm(got) < 1e-5 * gmax:
+                bad.append((name, 'nonzero', float(np.linalg.norm(got))))
+        elif not _rel(got, want) < 3e-4:
+            bad.append((name, _rel(got, want), float(np.linalg.norm(got)), float(np.linalg.norm(want))))
+    assert not bad, '\n'.join(map(str, bad))

@@ -323,6 +323,11 @@ __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __r
 __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a[i] += b[i];
 }
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y, float* __restrict__ out,
+                             long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
 __global__ void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
     float s = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i] * x[i];
@@ -486,6 +491,13 @@ int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, 
     const uint32_t thresh = (uint32_t)((double)rate * 4294967296.0);
     hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, res, out, (long long)n,
                        thresh, 1.0f / (1.0f - rate), seed, site);
+    return vf_last_status();
+}
+
+int vf_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream) {
+    if (!x || !out || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, a, x, b, y, out, (long long)n);
     return vf_last_status();
 }
 

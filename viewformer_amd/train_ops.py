@@ -112,6 +112,15 @@ def add_(a, b):
     return a
 
 
+def axpby(a, x, b=0.0, y=None, out=None):
+    """out = a*x + b*y"""
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vf_axpby_f32(float(a), _p(_f32(x)), float(b), _p(_f32(y)) if y is not None else None, _p(out), x.numel(),
+                                   _stream()), 'vf_axpby_f32')
+    return out
+
+
 def clip_by_norm_(x, clip, scratch1):
     check(_lib.load().vf_clip_by_norm_f32(_p(_f32(x)), x.numel(), clip, _p(scratch1), _stream()), 'vf_clip_by_norm_f32')
     return x
