@@ -268,6 +268,30 @@ int vf_l1_loss_partials(int64_t n);
 int vf_l1_loss_f32(const float* x, const float* y, float* dy, float* part, int64_t n, float grad_weight, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Perceptual loss of the codebook training step: lpips.LPIPS(net='vgg') as called at vqgan_th.py:337,402-404 (and, forward only,
+ * the LPIPSMetric of the evaluators, evaluate_transformer.py:34).  The `lpips` package (v0.1.x) is a third-party dependency that is
+ * not part of the reference tree; its published algorithm: ScalingLayer (x - shift) / scale, VGG-16 features tapped after
+ * relu1_2 / 2_2 / 3_3 / 4_3 / 5_3, per-pixel channel normalisation x / (|x| + 1e-10), squared difference, non-negative 1x1 "lin"
+ * weights, spatial mean, sum over the five taps.  The VGG convolutions are vf_igemm_f32 / vf_conv3_halo_x6 launches; these are
+ * the remaining HBM-bound pieces (NHWC, fp32).
+ * ------------------------------------------------------------------------------------- */
+/* ScalingLayer: y = (x - shift[c]) / scale[c] on [npix][3]; backward = 1: y = x / scale[c] (shift3 / scale3 are HOST arrays) */
+int vf_lpips_scaling_f32(const float* x, float* y, int64_t npix, const float* shift3, const float* scale3, int backward, void* stream);
+/* in-place ReLU, and its backward dy <- dy * (y > 0) with y the ReLU OUTPUT; n % 4 == 0 */
+int vf_relu_f32(float* x, int64_t n, void* stream);
+int vf_relu_bwd_f32(float* dy, const float* y, int64_t n, void* stream);
+/* 2x2 stride-2 max-pool, x [n][2Hout][2Wout][C] -> y [n][Hout][Wout][C] (C % 4 == 0); backward routes dy to the first maximum of
+ * each window in row-major order (torch.nn.MaxPool2d) and writes every element of dx */
+int vf_maxpool2_f32(const float* x, float* y, int n_img, int Hout, int Wout, int C, void* stream);
+int vf_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int n_img, int Hout, int Wout, int C, void* stream);
+/* LPIPS head of one tap: part[blk * n_img + img] = partial sums over pixels of sum_c w[c] (f0n - f1n)^2 (vf_lpips_head_blocks(HW)
+ * blocks per image); backward: df1 (+)= gscale * d/df1 of the per-pixel value (f0, w are constants) */
+int vf_lpips_head_blocks(int HW);
+int vf_lpips_head_f32(const float* f0, const float* f1, const float* w, float* part, int n_img, int HW, int C, void* stream);
+int vf_lpips_head_bwd_f32(const float* f0, const float* f1, const float* w, float* df1, int64_t npix, int C, float gscale,
+                          int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training step of the transformer (MIGT.train_step, viewformer/models/migt.py:464-505).
  * The dense contractions of the backward pass are vf_igemm_f32 calls (dX = dY.W^T with the weight
  * packed transposed, dW = X^T.dY via vf_transpose_f32); these are the remaining pieces.

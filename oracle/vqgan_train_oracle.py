@@ -14,9 +14,10 @@ from . import vqgan_oracle as vq
 BUFFERS = ('quantize.embeddings', 'quantize.ema_cluster_size_hidden', 'quantize.ema_dw_hidden', 'quantize.counter')
 
 
-def losses(sd, cfg, x, dtype=torch.float64):
+def losses(sd, cfg, x, dtype=torch.float64, lpips_sd=None):
     """-> (loss, dict(rec_loss, quant_loss, z, ind)); x NCHW in [-1, 1]; the codebook used is sd['quantize.embeddings'] (the lookup
-    happens BEFORE the EMA update, utils_th.py:36-44)"""
+    happens BEFORE the EMA update, utils_th.py:36-44).  ``lpips_sd``: frozen LPIPS-VGG weights, required when perceptual_weight > 0
+    (vqgan_th.py:402-404; restated in lpips_oracle.py — that part of the graph is parity-unpinned)"""
     x = x.to(dtype)
     z = vq.encode_z(sd, cfg, x, dtype)                                    # encoder + quant_conv, vqgan_th.py:380-381
     with torch.no_grad():
@@ -25,19 +26,25 @@ def losses(sd, cfg, x, dtype=torch.float64):
     diff = (qe - z).pow(2).mean()                                          # utils_th.py:66  (quantize.detach() - input)
     quant = z + (qe - z).detach()                                          # :67 straight-through
     dec = vq.decoder(sd, cfg, vq.conv(sd, 'post_quant_conv', quant, dtype), dtype)      # vqgan_th.py:385-388 (vq.decode is no_grad)
-    rec = (x - dec).abs().mean()                                           # :355,361
-    loss = rec + cfg.codebook_weight * diff                                # :362
-    return loss, dict(rec_loss=rec, quant_loss=diff, z=z, ind=ind)
+    rec = (x - dec).abs()                                                  # :401
+    p_loss = torch.zeros(1, dtype=dtype)
+    if cfg.perceptual_weight > 0:                                          # :402-404
+        from . import lpips_oracle
+        p_loss = lpips_oracle.distance(lpips_sd, x, dec, dtype).view(-1, 1, 1, 1)
+        rec = rec + cfg.perceptual_weight * p_loss
+    rec = rec.mean()                                                       # :407
+    loss = rec + cfg.codebook_weight * diff                                # :408
+    return loss, dict(rec_loss=rec, quant_loss=diff, p_loss=p_loss.mean(), z=z, ind=ind)
 
 
 def trainable(sd):
     return [k for k in sd if k not in BUFFERS]
 
 
-def gradients(sd_np, cfg, x):
+def gradients(sd_np, cfg, x, lpips_sd=None):
     """fp64 autograd gradients w.r.t. every trainable tensor -> (grads, metrics)"""
     sd = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=(k not in BUFFERS)) for k, v in sd_np.items()}
-    loss, m = losses(sd, cfg, torch.as_tensor(x))
+    loss, m = losses(sd, cfg, torch.as_tensor(x), lpips_sd=lpips_sd)
     loss.backward()
     grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in trainable(sd)}
     return grads, dict(loss=float(loss.detach()), rec_loss=float(m['rec_loss'].detach()), quant_loss=float(m['quant_loss'].detach())), m

@@ -54,6 +54,14 @@ EXPORTS = {
     'vf_softmax_rows_bwd_f32': (c_int, [P, P, c_int64, c_int, c_float, P]),
     'vf_l1_loss_partials': (c_int, [c_int64]),
     'vf_l1_loss_f32': (c_int, [P, P, P, P, c_int64, c_float, P]),
+    'vf_lpips_scaling_f32': (c_int, [P, P, c_int64, P, P, c_int, P]),
+    'vf_relu_f32': (c_int, [P, c_int64, P]),
+    'vf_relu_bwd_f32': (c_int, [P, P, c_int64, P]),
+    'vf_maxpool2_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_maxpool2_bwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_lpips_head_blocks': (c_int, [c_int]),
+    'vf_lpips_head_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'vf_lpips_head_bwd_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     'vf_vq_ema_accumulate_f32': (c_int, [P, P, c_int64, c_int, c_int, P, P, P]),
     'vf_vq_ema_update_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, P]),
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),

@@ -158,10 +158,10 @@ def dropout_add(x, rate, seed, site, res=None, out=None):
 
 
 # ------------------------------------------------------------------ VQGAN backward helpers (csrc/vqgan_bwd.hip)
-def gather_transpose(src, n_img, Hin, Win, C, Hout, Wout, stride=1, oy=0, ox=0):
+def gather_transpose(src, n_img, Hin, Win, C, Hout, Wout, stride=1, oy=0, ox=0, out=None):
     """[C][n_img*Hout*Wout]: channel-major, tap-shifted view of an NHWC activation (zero outside the image)"""
     P = n_img * Hout * Wout
-    dst = torch.empty((C, P), dtype=torch.float32, device=src.device)
+    dst = torch.empty((C, P), dtype=torch.float32, device=src.device) if out is None else _f32(out)
     check(_lib.load().vf_gather_transpose_f32(_p(_f32(src)), _p(dst), n_img, Hin, Win, C, Hout, Wout, stride, oy, ox, P, _stream()),
           'vf_gather_transpose_f32')
     return dst
@@ -202,3 +202,54 @@ def l1_loss(x, y, grad_weight):
     total = torch.empty(1, dtype=torch.float32, device=x.device)
     colsum(part.view(-1, 1), total, part.numel(), 1)
     return total[0], dy
+
+
+# ------------------------------------------------------------------ perceptual loss pieces (csrc/lpips.hip)
+def lpips_scaling(x, shift3, scale3, backward=False):
+    """ScalingLayer of lpips on NHWC [.., 3] rows: (x - shift) / scale; backward: x / scale"""
+    import ctypes
+    y = torch.empty_like(x)
+    sh = (ctypes.c_float * 3)(*[float(v) for v in shift3])
+    sc = (ctypes.c_float * 3)(*[float(v) for v in scale3])
+    check(_lib.load().vf_lpips_scaling_f32(_p(_f32(x)), _p(y), x.numel() // 3, sh, sc, 1 if backward else 0, _stream()),
+          'vf_lpips_scaling_f32')
+    return y
+
+
+def relu_(x):
+    check(_lib.load().vf_relu_f32(_p(_f32(x)), x.numel(), _stream()), 'vf_relu_f32')
+    return x
+
+
+def relu_bwd_(dy, y):
+    check(_lib.load().vf_relu_bwd_f32(_p(_f32(dy)), _p(_f32(y)), dy.numel(), _stream()), 'vf_relu_bwd_f32')
+    return dy
+
+
+def maxpool2(x, n_img, Hout, Wout, C):
+    y = torch.empty((n_img * Hout * Wout, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_maxpool2_f32(_p(_f32(x)), _p(y), n_img, Hout, Wout, C, _stream()), 'vf_maxpool2_f32')
+    return y
+
+
+def maxpool2_bwd(x, dy, n_img, Hout, Wout, C):
+    dx = torch.empty((n_img * Hout * Wout * 4, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_maxpool2_bwd_f32(_p(_f32(x)), _p(_f32(dy)), _p(dx), n_img, Hout, Wout, C, _stream()), 'vf_maxpool2_bwd_f32')
+    return dx
+
+
+def lpips_head(f0, f1, w, n_img, HW, C):
+    """-> per-image sums over pixels of sum_c w_c (f0n - f1n)^2, [n_img]"""
+    lib = _lib.load()
+    nb = int(lib.vf_lpips_head_blocks(HW))
+    part = torch.empty((nb, n_img), dtype=torch.float32, device=f0.device)
+    check(lib.vf_lpips_head_f32(_p(_f32(f0)), _p(_f32(f1)), _p(_f32(w)), _p(part), n_img, HW, C, _stream()), 'vf_lpips_head_f32')
+    sums = torch.empty(n_img, dtype=torch.float32, device=f0.device)
+    colsum(part, sums, nb, n_img)
+    return sums
+
+
+def lpips_head_bwd(f0, f1, w, df1, npix, C, gscale, accumulate):
+    check(_lib.load().vf_lpips_head_bwd_f32(_p(_f32(f0)), _p(_f32(f1)), _p(_f32(w)), _p(_f32(df1)), npix, C, float(gscale),
+                                            1 if accumulate else 0, _stream()), 'vf_lpips_head_bwd_f32')
+    return df1

@@ -12,7 +12,9 @@ plus the HBM-bound helpers of csrc/vqgan_bwd.hip (GroupNorm+swish backward, soft
 flips, zero-insertion, concatenation) and issues the collectives.  First version: correct and deterministic, not tuned — the GroupNorm
 prologues are materialised instead of fused, packings are rebuilt every call.
 
-Limits: ``perceptual_weight`` must be 0 (LPIPS needs the VGG weights the reference downloads; refused otherwise).
+``perceptual_weight > 0`` (the reference default, 1.0) needs the LPIPS-VGG weights the reference downloads: pass them as
+``lpips_state_dict`` (lpips.load_lpips_weights / make_lpips_weights); without them the trainer refuses instead of silently dropping
+the term.
 """
 import math
 
@@ -30,10 +32,11 @@ _BUFFERS = ('quantize.embeddings', 'quantize.ema_cluster_size_hidden', 'quantize
 
 class VQGANTrainer:
     def __init__(self, model: VQGAN, lr: float = None, betas=(0.5, 0.9), eps: float = 1e-8, ema_decay: float = 0.99,
-                 process_group=None):
+                 process_group=None, lpips_state_dict=None):
         cfg = model.config
-        if cfg.perceptual_weight != 0:
-            raise NotImplementedError('perceptual (LPIPS) loss is not built: set perceptual_weight=0.0 in VQGANConfig')
+        if cfg.perceptual_weight > 0 and lpips_state_dict is None:
+            raise ValueError('perceptual_weight > 0 needs the LPIPS-VGG weights (lpips_state_dict=...; viewformer_amd.lpips.'
+                             'load_lpips_weights reads the upstream .pth files) — or set perceptual_weight=0.0 in VQGANConfig')
         if model._sd_host is None or model.device is None:
             raise RuntimeError('load_state_dict() and .to("cuda") the model first')
         self.model, self.cfg, self.dev = model, cfg, model.device
@@ -59,6 +62,10 @@ class VQGANTrainer:
                                             ema_dw_hidden=torch.from_numpy(np.ascontiguousarray(host['quantize.ema_dw_hidden'])).to(self.dev),
                                             counter=int(np.asarray(host['quantize.counter']).reshape(-1)[0]))
         self._enc_plan, self._dec_plan = model._enc_plan, model._dec_plan
+        self.lpips = None
+        if cfg.perceptual_weight > 0:
+            from .lpips import LPIPS
+            self.lpips = LPIPS(lpips_state_dict, self.dev)
 
     # ------------------------------------------------------------------ parameter / gradient views
     def p(self, name):
@@ -81,24 +88,32 @@ class VQGANTrainer:
 
     # ------------------------------------------------------------------ GEMM helpers
     @staticmethod
-    def _gemm(a, b_rows, M, K, N):
-        """[M x K] @ [K x N] (both row-major device tensors) -> [M x N], fp32-equivalent when the shape allows the x6 kernel"""
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    def _pack_b(b_rows, K, N):
+        """B operand [K x N] (row-major) packed once for any number of ``_gemm`` calls against it"""
         if K % 64 == 0:
+            return ('x6', ops.pack_dense_kn_x6(b_rows))
+        return ('f32', ops.pack(b_rows, K, N, 1, sk=N, sn=1, st=0))
+
+    @staticmethod
+    def _gemm(a, b, M, K, N):
+        """[M x K] @ [K x N] -> [M x N]; ``b`` is a row-major device tensor or a ``_pack_b`` result.  fp32-equivalent split-bf16
+        kernel (split-K when the output has few tiles and the reduction is long) when K % 64 == 0, the fp32 MFMA GEMM otherwise"""
+        kind, bp = b if isinstance(b, tuple) else VQGANTrainer._pack_b(b, K, N)
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if kind == 'x6':
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
-            splits = max(1, min(16, 768 // max(tiles, 1), K // 1024))
-            wp = ops.pack_dense_kn_x6(b_rows)
+            splits = max(1, min(256, 512 // max(tiles, 1), K // 512))
             if splits > 1 and (M * N) % 4 == 0:
-                ops.gemm_x6_splitk(a, wp, M, K, N, out, splits, accumulate=False)
+                ops.gemm_x6_splitk(a, bp, M, K, N, out, splits, accumulate=False)
             else:
-                ops.igemm(a, wp, M, K, N, out, x6=True)
+                ops.igemm(a, bp, M, K, N, out, x6=True)
             return out
         Kp = (K + 31) // 32 * 32
         if Kp != K:
             a2 = torch.zeros((M, Kp), dtype=torch.float32, device=a.device)
             a2[:, :K] = a
             a = a2
-        ops.igemm(a, ops.pack(b_rows, K, N, 1, sk=N, sn=1, st=0), M, Kp, N, out)
+        ops.igemm(a, bp, M, Kp, N, out)
         return out
 
     # ------------------------------------------------------------------ convolution forward / backward
@@ -148,12 +163,14 @@ class VQGANTrainer:
             xin, Hi, Wi, stride, off = x, H, W, 2, 0
         else:
             xin, Hi, Wi, stride, off = x, H, W, 1, -1
-        taps = []
+        # all nine taps as one GEMM: [9*cin][P] (tap-shifted, channel-major) x dY [P][cout]
+        xt = torch.empty((9, cin, P), dtype=torch.float32, device=dy.device)
         for ky in range(3):
             for kx in range(3):
-                xt = T.gather_transpose(xin, n, Hi, Wi, cin, Ho, Wo, stride, ky + off, kx + off)       # [cin][P]
-                taps.append(self._gemm(xt, dy, cin, P, cout))                             # [cin][cout]
-        dw = torch.stack(taps, 0).view(3, 3, cin, cout).permute(3, 2, 0, 1).contiguous()   # -> OIHW
+                T.gather_transpose(xin, n, Hi, Wi, cin, Ho, Wo, stride, ky + off, kx + off, out=xt[ky * 3 + kx])
+        dw = self._gemm(xt.view(9 * cin, P), dy, 9 * cin, P, cout)                        # [9*cin][cout]
+        del xt
+        dw = dw.view(3, 3, cin, cout).permute(3, 2, 0, 1).contiguous()                     # -> OIHW
         T.add_(gw, dw)
         if not need_dx:
             return None
@@ -319,12 +336,12 @@ class VQGANTrainer:
                 name, image, n, H, W, cout = c
                 P = n * H * W
                 T.colsum(dx, self.g(name + '.bias'), P, cout, accumulate=True)
-                taps = []
+                xt = torch.empty((9, 3, P), dtype=torch.float32, device=dx.device)
                 for ky in range(3):
                     for kx in range(3):
-                        xt = T.gather_transpose(image, n, H, W, 3, H, W, 1, ky - 1, kx - 1)      # [3][P]
-                        taps.append(self._gemm(xt, dx, 3, P, cout))
-                T.add_(self.g(name + '.weight'), torch.stack(taps, 0).view(3, 3, 3, cout).permute(3, 2, 0, 1).contiguous())
+                        T.gather_transpose(image, n, H, W, 3, H, W, 1, ky - 1, kx - 1, out=xt[ky * 3 + kx])
+                dw = self._gemm(xt.view(27, P), dx, 27, P, cout)                          # [27][cout]
+                T.add_(self.g(name + '.weight'), dw.view(3, 3, 3, cout).permute(3, 2, 0, 1).contiguous())
                 dx = None
         return dx
 
@@ -349,10 +366,16 @@ class VQGANTrainer:
         d0, kpq = self._conv_fw('post_quant_conv', qrows, n, eh, ew, mode=ops.MODE_GEMM)
         xrec, _, _, dec_tape = self._plan_fw(self._dec_plan, d0, n, eh, ew)
         self.last_indices = ind
-        # ---- loss (vqgan_th.py:354-368) --------------------------------------------------------------------
+        # ---- loss (vqgan_th.py:400-408): mean(|x - xrec| + pw * lpips[n]) + cw * commitment -----------------
         numel = img.numel()
         l1_sum, dxrec = T.l1_loss(img.view(-1), xrec.view(-1), 1.0 / numel)
         rec = l1_sum / numel
+        p_mean = torch.zeros((), dtype=torch.float32, device=dev)
+        if self.lpips is not None:
+            p, dperc = self.lpips.loss_and_grad(img, xrec.view(n, H, W, 3), cfg.perceptual_weight / n)
+            p_mean = p.mean()
+            rec = rec + cfg.perceptual_weight * p_mean
+            T.add_(dxrec, dperc.reshape(-1))
         loss = rec + cfg.codebook_weight * diff
         # ---- backward --------------------------------------------------------------------------------------
         dd0 = self._plan_bw(dec_tape, dxrec.view(n * H * W, cfg.out_ch))
@@ -367,7 +390,7 @@ class VQGANTrainer:
             T.axpby(1.0 / dist.get_world_size(self.group), self.flat_g, out=self.flat_g)
         if apply_update:
             self.apply_gradients()
-        return dict(total_loss=loss, rec_loss=rec, quant_loss=diff)
+        return dict(total_loss=loss, rec_loss=rec, quant_loss=diff, p_loss=p_mean)
 
     def apply_gradients(self):
         """torch.optim.Adam(lr, betas=(0.5, 0.9)), vqgan_th.py:427-429"""
