@@ -254,6 +254,14 @@ int vf_vq_ema_update_f32(const float* counts, const float* embed_sum, float* clu
  * activation that makes conv dW one GEMM per tap */
 int vf_gather_transpose_f32(const float* src, float* dst, int n_img, int Hin, int Win, int C, int Hout, int Wout, int stride, int oy,
                             int ox, int64_t ld_dst, void* stream);
+/* weight + bias gradient of a 3x3 convolution (torch.nn.Conv2d backward of vqgan_th.py's ResnetBlock / Downsample / Upsample convs) as
+ * ONE split-bf16 GEMM gathered straight from the NHWC input x [n][Hin][Win][Cin] (mode = VF_MODE_CONV3_*: the forward conv's mode):
+ *   slabs[s][(ky*3+kx)*Cin + ci][co] = partial sums over output pixels of x[tap-shifted][ci] * dY[p][co],  row 9*Cin = sum_p dY[p][co]
+ * dy_packed = vf_gemm_x6_pack of dY [P][Cout] (K = P); sum the `splits` slabs of vf_conv3_wgrad_x6_rows(Cin) * Cout floats with
+ * vf_sum_slabs_f32.  Needs Cin % 128 == 0, Hout / Wout powers of two, P % 64 == 0 (VF_ERR_UNSUPPORTED otherwise). */
+size_t vf_conv3_wgrad_x6_rows(int Cin);
+int vf_conv3_wgrad_x6(const float* x, const void* dy_packed, float* slabs, int n_img, int Hin, int Win, int Cin, int Hout, int Wout,
+                      int Cout, int mode, int splits, void* stream);
 /* nearest-x2 upsample backward (Upsample.forward vqgan_th.py:29-32): dx = 2x2 block sums of du [n][2H][2W][C] */
 int vf_upsample2_bwd_f32(const float* du, float* dx, int n_img, int H, int W, int C, void* stream);
 /* GroupNorm(+swish) backward (Normalize / nonlinearity vqgan_th.py:11-17): dx (+=), chan_sums [n_img][C][2] = {dgamma, dbeta} parts */

@@ -209,3 +209,32 @@ def test_training_step_with_perceptual_loss_matches_oracle():
         elif not _rel(got, want) < 3e-4:
             bad.append((name, _rel(got, want)))
     assert not bad, '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('mode,cin,cout,n,h,w', [(1, 128, 128, 2, 16, 16), (1, 256, 64, 1, 8, 32), (2, 128, 256, 2, 32, 32),
+                                                 (3, 128, 128, 3, 8, 8), (1, 128, 132, 4, 8, 8)])
+def test_conv3_wgrad_kernel_matches_autograd(mode, cin, cout, n, h, w):
+    """vf_conv3_wgrad_x6 (weight + bias gradient gathered straight from the NHWC input) vs torch autograd in fp64, the three conv
+    modes of the VQGAN (stride 1, pad-right/bottom stride 2, nearest-x2 upsample + stride 1); h, w = INPUT size"""
+    import torch.nn.functional as F
+    from viewformer_amd import train_ops as T
+    rng = np.random.default_rng(mode * 7 + cin)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    xd = x.double()
+    if mode == 1:
+        y = F.conv2d(xd, wt, b, padding=1)
+    elif mode == 2:
+        y = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wt, b, stride=2)                 # Downsample.forward vqgan_th.py:45-49
+    else:
+        y = F.conv2d(F.interpolate(xd, scale_factor=2.0, mode='nearest'), wt, b, padding=1)      # Upsample.forward :29-32
+    ho, wo = y.shape[2], y.shape[3]
+    dy = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32))
+    y.backward(dy.double())
+    assert T.conv3_wgrad_supported(cin, n, ho, wo)
+    got = T.conv3_wgrad(x.permute(0, 2, 3, 1).contiguous().cuda().view(-1, cin), dy.permute(0, 2, 3, 1).contiguous().cuda().view(-1, cout),
+                        n, h, w, cin, ho, wo, cout, mode).cpu().numpy()
+    want_w = wt.grad.permute(2, 3, 1, 0).reshape(9 * cin, cout).numpy()       # rows (ky, kx, ci)
+    assert _rel(got[:9 * cin], want_w) < 2e-6, _rel(got[:9 * cin], want_w)
+    assert _rel(got[9 * cin], b.grad.numpy()) < 2e-6

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Codebook (VQGAN) training-step timing at the reference's codebook config (README.md codebook training: 128x128 images,
-ch 128, ch_mult [1,1,2,2,4], 2 res blocks, attention at 8x8, global batch 352 = 44 per GPU on 8 GPUs; perceptual_weight 0 — see
-vqgan_train.py limits).
+ch 128, ch_mult [1,1,2,2,4], 2 res blocks, attention at 16x16, global batch 352 = 44 per GPU on 8 GPUs, L1 + LPIPS-VGG + commitment
+loss, Adam; random weights).
 
   python tools/bench_vqtrain.py [--steps K] [--batch 44]
   python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_vqtrain.py   # DP, RCCL all-reduce
@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=44)
+    ap.add_argument('--perceptual-weight', type=float, default=1.0, help='reference default 1.0 (LPIPS-VGG, random weights here)')
     args = ap.parse_args()
     from viewformer_amd import sharding
     from viewformer_amd.config import VQGANConfig
@@ -31,10 +32,11 @@ def main():
     rank, local, world = sharding.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    cfg = VQGANConfig(perceptual_weight=0.0)
+    cfg = VQGANConfig(perceptual_weight=args.perceptual_weight)
     model = VQGAN(cfg, device=dev)
     model.load_state_dict(make_vqgan_weights(cfg, seed=0))
-    tr = VQGANTrainer(model)
+    from viewformer_amd.lpips import make_lpips_weights
+    tr = VQGANTrainer(model, lpips_state_dict=make_lpips_weights(0) if args.perceptual_weight > 0 else None)
     g = np.random.Generator(np.random.PCG64(rank))
     x = torch.from_numpy(g.uniform(-1, 1, size=(args.batch, 3, cfg.image_size, cfg.image_size)).astype(np.float32)).to(dev)
     for _ in range(args.warmup):
@@ -49,7 +51,8 @@ def main():
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev) / args.steps
     if rank == 0:
         print(json.dumps(dict(metric='codebook_train_images_per_sec', value=args.batch * world / dt, ms_per_step=dt * 1e3, n_gpus=world,
-                              batch_per_gpu=args.batch, loss=float(met['total_loss']), rec_loss=float(met['rec_loss']),
+                              batch_per_gpu=args.batch, loss=float(met['total_loss']), rec_loss=float(met['rec_loss']), p_loss=float(met['p_loss']),
+                              perceptual_weight=args.perceptual_weight,
                               peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, dtype='f32 (split-bf16 x6)', data='synthetic')))
 
 

@@ -54,6 +54,8 @@ EXPORTS = {
     'vf_softmax_rows_bwd_f32': (c_int, [P, P, c_int64, c_int, c_float, P]),
     'vf_l1_loss_partials': (c_int, [c_int64]),
     'vf_l1_loss_f32': (c_int, [P, P, P, P, c_int64, c_float, P]),
+    'vf_conv3_wgrad_x6_rows': (c_size_t, [c_int]),
+    'vf_conv3_wgrad_x6': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_lpips_scaling_f32': (c_int, [P, P, c_int64, P, P, c_int, P]),
     'vf_relu_f32': (c_int, [P, c_int64, P]),
     'vf_relu_bwd_f32': (c_int, [P, P, c_int64, P]),

@@ -242,6 +242,178 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, lo
     }
 }
 
+// ---- weight gradient of a 3x3 convolution as ONE GEMM: dW[(tap, ci)][co] = sum_p X[p + tap][ci] * dY[p][co] --------------------
+// Same tile / pipeline as gemm_x6_kernel with K = pixels; the A operand is gathered straight from the NHWC activation: workgroup
+// row tile = 128 input channels of one tap, thread = (channel r, pixel quad): 4 dword loads along consecutive output pixels of one
+// channel (a wavefront reads 64 consecutive channels of a pixel = 256 contiguous bytes), so the values arrive k-contiguous and are
+// split and parked exactly like the dense kernel's float4 — no transposed copy of the activation in HBM (the first version's
+// vf_gather_transpose_f32 x 9 cost as much as all the GEMM work).  One extra row tile (tap 9) has a single row of ones: its output
+// row is the bias gradient sum_p dY[p][co].  Split-K slabs as in gemm_x6_kernel.
+struct wgrad_args {
+    const float* x;
+    const void* dyp;
+    float* out;
+    int n_img, Hin, Win, Cin, Hout, Wout, Cout, lw, lhw, nsplit, M;
+    long long P, stride_out;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(wgrad_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];   // [2][A_BYTES]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = (p.Cout + BN - 1) / BN;
+    const int nblk = blockIdx.x % nb;
+    const int mtile = blockIdx.x / nb;
+    const int tpt = p.Cin / BM;                      // row tiles per tap
+    const int tap = mtile / tpt, cblk = mtile % tpt; // tap == 9: the ones row (bias gradient)
+    const int ky = tap / 3, kx = tap % 3;
+    const bool ones_tile = tap >= 9;
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.dyp) + (size_t)nblk * CHUNK_BYTES;
+    const size_t chunk_stride = (size_t)nb * CHUNK_BYTES;
+    const int nsplit = p.nsplit;
+    const int total_chunks = (int)(p.P / CK);
+    const int per = ((total_chunks + nsplit - 1) / nsplit + 1) & ~1;
+    const int c0 = min((int)blockIdx.y * per, total_chunks);
+    const int nchunks = min(c0 + per, total_chunks);
+
+    const int r = tid & 127, kg = tid >> 7;
+    const float* __restrict__ xc = p.x + cblk * BM + r;
+    f32x4 areg[4];
+    auto a_fetch = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ones_tile) {
+                const float o = r == 0 ? 1.f : 0.f;
+                areg[q] = f32x4{o, o, o, o};
+                continue;
+            }
+            const int p0 = chunk * CK + 4 * (kg + 2 * q);                     // 4 consecutive output pixels of one row
+            const int x0 = p0 & (p.Wout - 1), y = (p0 >> p.lw) & (p.Hout - 1), img = p0 >> p.lhw;
+            int sy;
+            bool oky;
+            if (MODE == VF_MODE_CONV3_S1) { sy = y + ky - 1; oky = sy >= 0 && sy < p.Hin; }
+            else if (MODE == VF_MODE_CONV3_S2PAD) { sy = 2 * y + ky; oky = sy < p.Hin; }
+            else { const int uy = y + ky - 1; oky = uy >= 0 && uy < p.Hout; sy = uy >> 1; }
+            const long long rowbase = ((long long)img * p.Hin + (oky ? sy : 0)) * p.Win;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int sx;
+                bool okx;
+                if (MODE == VF_MODE_CONV3_S1) { sx = x0 + e + kx - 1; okx = sx >= 0 && sx < p.Win; }
+                else if (MODE == VF_MODE_CONV3_S2PAD) { sx = 2 * (x0 + e) + kx; okx = sx < p.Win; }
+                else { const int ux = x0 + e + kx - 1; okx = ux >= 0 && ux < p.Wout; sx = ux >> 1; }
+                const bool ok = oky && okx;
+                const float v = xc[(rowbase + (ok ? sx : 0)) * p.Cin];
+                areg[q][e] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto a_park = [&](int buf, int q) {
+        unsigned char* dst = smem_g + buf * A_BYTES + r * A_LDB + (kg + 2 * q) * 8;
+        bf16x4 oh, om, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(areg[q][e], h, m, l);
+            oh[e] = h; om[e] = m; ol[e] = l;
+        }
+        *reinterpret_cast<bf16x4*>(dst) = oh;
+        *reinterpret_cast<bf16x4*>(dst + 64) = om;
+        *reinterpret_cast<bf16x4*>(dst + 128) = ol;
+    };
+
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    bf16x8 bring[2][2][3][2];
+    auto b_load = [&](bf16x8 (&dst)[2][3][2], int chunk) {
+        chunk = min(chunk, nchunks - 1);
+        const unsigned char* src = Wb + (size_t)chunk * chunk_stride + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    dst[ks][pl][j] = *reinterpret_cast<const bf16x8*>(src + ks * KS_BYTES + pl * PLANE_BYTES + j * 32 * 16);
+    };
+    const int a_lane = (wave_m * 64 + l31) * A_LDB + half * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+
+    if (c0 < nchunks) {
+        a_fetch(c0);
+        b_load(bring[0], c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_park(0, q);
+    }
+    __syncthreads();
+
+    auto chunk_body = [&](int chunk, bf16x8 (&bcur)[2][3][2], bf16x8 (&bnext)[2][3][2]) {
+        const unsigned char* a_src = smem_g + ((chunk - c0) & 1) * A_BYTES + a_lane;
+        a_fetch(min(chunk + 1, nchunks - 1));
+        b_load(bnext, chunk + 1);
+        bf16x8 a[2][2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[ks][mi][pl] = *reinterpret_cast<const bf16x8*>(a_src + mi * 32 * A_LDB + pl * 64 + ks * 32);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi][PA[t]], bcur[ks][PB[t]][j], acc[mi][j], 0, 0, 0);
+            a_park((chunk - c0 + 1) & 1, ks * 2);
+            a_park((chunk - c0 + 1) & 1, ks * 2 + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    for (int chunk = c0; chunk < nchunks; chunk += 2) {
+        chunk_body(chunk, bring[0], bring[1]);
+        chunk_body(chunk + 1, bring[1], bring[0]);
+    }
+
+    float* __restrict__ Out = p.out + (size_t)blockIdx.y * p.stride_out;
+    const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);
+    const long long ldc = p.Cout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        const bool nok = n < p.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
+            float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + (nok ? n : 0);
+            const int rows_left = nok ? p.M - m0 : 0;
+            if (full) {
+                auto oo = [&](int rr) { return (long long)((rr & 3) + 8 * (rr >> 2)) * ldc; };
+                vf_store_tile<0, false>(acc[i][j], 0.f, o, nullptr, oo, oo);
+            } else {
+                vf_store_tile_ragged<0, false>(acc[i][j], 0.f, o, nullptr, ldc, ldc, rows_left);
+            }
+        }
+    }
+}
+
 template <bool PRO, bool SWISH>
 int launch(const vf_igemm_args& a, hipStream_t stream) {
     const size_t smem = (size_t)2 * A_BYTES;
@@ -277,6 +449,35 @@ int vf_sum_slabs_f32(const float* slabs, int nslabs, int64_t stride, int64_t n, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs,
                        (long long)stride, n4, dst, accumulate);
+    return vf_last_status();
+}
+
+size_t vf_conv3_wgrad_x6_rows(int Cin) { return Cin > 0 ? (size_t)9 * Cin + 1 : 0; }
+
+int vf_conv3_wgrad_x6(const float* x, const void* dy_packed, float* slabs, int n_img, int Hin, int Win, int Cin, int Hout, int Wout,
+                      int Cout, int mode, int splits, void* stream) {
+    if (!x || !dy_packed || !slabs || n_img <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 ||
+        splits < 1)
+        return VF_ERR_BAD_ARG;
+    if (mode == VF_MODE_CONV3_S1 && (Hout != Hin || Wout != Win)) return VF_ERR_BAD_ARG;
+    if (mode == VF_MODE_CONV3_S2PAD && (Hout != Hin / 2 || Wout != Win / 2)) return VF_ERR_BAD_ARG;
+    if (mode == VF_MODE_CONV3_UP2 && (Hout != Hin * 2 || Wout != Win * 2)) return VF_ERR_BAD_ARG;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const long long P = (long long)n_img * Hout * Wout;
+    if (Cin % BM || !pow2(Hout) || !pow2(Wout) || (Wout & 3) || P % 64 || P > 0x7fffffffLL) return VF_ERR_UNSUPPORTED;
+    wgrad_args a;
+    a.x = x; a.dyp = dy_packed; a.out = slabs;
+    a.n_img = n_img; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+    a.lw = __builtin_ctz((unsigned)Wout); a.lhw = a.lw + __builtin_ctz((unsigned)Hout);
+    a.nsplit = splits; a.M = 9 * Cin + 1; a.P = P; a.stride_out = (long long)a.M * Cout;
+    const int nb = (Cout + BN - 1) / BN, mt = 9 * (Cin / BM) + 1;
+    const size_t smem = (size_t)2 * A_BYTES;
+    const dim3 grid((unsigned)(mt * nb), (unsigned)splits);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == VF_MODE_CONV3_S1) hipLaunchKernelGGL(wgrad_x6_kernel<VF_MODE_CONV3_S1>, grid, dim3(256), smem, s, a);
+    else if (mode == VF_MODE_CONV3_S2PAD) hipLaunchKernelGGL(wgrad_x6_kernel<VF_MODE_CONV3_S2PAD>, grid, dim3(256), smem, s, a);
+    else if (mode == VF_MODE_CONV3_UP2) hipLaunchKernelGGL(wgrad_x6_kernel<VF_MODE_CONV3_UP2>, grid, dim3(256), smem, s, a);
+    else return VF_ERR_BAD_ARG;
     return vf_last_status();
 }
 

@@ -253,3 +253,31 @@ def lpips_head_bwd(f0, f1, w, df1, npix, C, gscale, accumulate):
     check(_lib.load().vf_lpips_head_bwd_f32(_p(_f32(f0)), _p(_f32(f1)), _p(_f32(w)), _p(_f32(df1)), npix, C, float(gscale),
                                             1 if accumulate else 0, _stream()), 'vf_lpips_head_bwd_f32')
     return df1
+
+
+def conv3_wgrad_supported(Cin, n_img, Hout, Wout):
+    pow2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
+    return Cin % 128 == 0 and pow2(Hout) and pow2(Wout) and Wout % 4 == 0 and (n_img * Hout * Wout) % 64 == 0
+
+
+def conv3_wgrad(x, dy, n_img, Hin, Win, Cin, Hout, Wout, Cout, mode):
+    """weight + bias gradient of a 3x3 convolution (forward mode ``mode``) -> [9*Cin + 1][Cout]: rows (ky*3+kx)*Cin + ci, last row
+    = bias gradient.  x: NHWC input rows of the forward conv, dy: [P][Cout]."""
+    from . import ops
+    lib = _lib.load()
+    P = n_img * Hout * Wout
+    rows = int(lib.vf_conv3_wgrad_x6_rows(Cin))
+    tiles = (9 * (Cin // 128) + 1) * ((Cout + 127) // 128)
+    splits = max(1, min(256, 512 // tiles, P // 512))
+    dyp = ops.pack_dense_kn_x6(dy)
+    slabs = torch.empty((splits, rows, Cout), dtype=torch.float32, device=x.device)
+    check(lib.vf_conv3_wgrad_x6(_p(_f32(x)), _p(dyp), _p(slabs), n_img, Hin, Win, Cin, Hout, Wout, Cout, mode, splits, _stream()),
+          'vf_conv3_wgrad_x6')
+    if splits == 1:
+        return slabs[0]
+    n = rows * Cout
+    if n % 4:
+        raise _lib.VfError('conv3_wgrad: (9*Cin+1)*Cout must be a multiple of 4 (vf_sum_slabs_f32 works in float4)')
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(lib.vf_sum_slabs_f32(_p(slabs), splits, n, n, _p(out), 0, _stream()), 'vf_sum_slabs_f32')
+    return out.view(rows, Cout)

@@ -147,15 +147,22 @@ class VQGANTrainer:
         w = self.p(name + '.weight')
         cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
         P = n * Ho * Wo
-        T.colsum(dy, self.g(name + '.bias'), P, cout, accumulate=True)
         gw = self.g(name + '.weight')
+        fused = k == 3 and cout % 4 == 0 and T.conv3_wgrad_supported(cin, n, Ho, Wo)
+        if not fused:
+            T.colsum(dy, self.g(name + '.bias'), P, cout, accumulate=True)
         if k == 1:
             xt = T.gather_transpose(x, 1, 1, P, cin, 1, P)                                 # [cin][P]
             T.add_(gw.view(cout, cin), self._gemm(xt, dy, cin, P, cout).t().contiguous())
             if not need_dx:
                 return None
             return self._gemm(dy, w.reshape(cout, cin).contiguous(), P, cout, cin)       # dX = dY . W
-        # ---- dW: one GEMM per tap on the tap-shifted, channel-major input
+        if fused:                                                                          # dW and db in one gathered GEMM
+            dw9 = T.conv3_wgrad(x, dy, n, H, W, cin, Ho, Wo, cout, mode)
+            T.add_(gw, dw9[:9 * cin].view(3, 3, cin, cout).permute(3, 2, 0, 1).contiguous())
+            T.add_(self.g(name + '.bias'), dw9[9 * cin].contiguous())
+            return self._conv_dx(w, dy, n, H, W, Ho, Wo, mode) if need_dx else None
+        # ---- dW, general shapes: the nine tap-shifted, channel-major copies of the input, one GEMM
         if mode == ops.MODE_CONV3_UP2:                                                     # the conv saw the nearest-x2 upsampled input
             xin = x.view(n, H, W, cin).repeat_interleave(2, 1).repeat_interleave(2, 2).contiguous()
             Hi, Wi, stride, off = Ho, Wo, 1, -1
@@ -172,9 +179,11 @@ class VQGANTrainer:
         del xt
         dw = dw.view(3, 3, cin, cout).permute(3, 2, 0, 1).contiguous()                     # -> OIHW
         T.add_(gw, dw)
-        if not need_dx:
-            return None
-        # ---- dX: the same convolution with the rotated, channel-transposed weight
+        return self._conv_dx(w, dy, n, H, W, Ho, Wo, mode) if need_dx else None
+
+    def _conv_dx(self, w, dy, n, H, W, Ho, Wo, mode):
+        """dX of a 3x3 convolution: the same convolution with the rotated, channel-transposed weight"""
+        cout, cin = w.shape[0], w.shape[1]
         wr = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                                # [cin][cout][3][3] as an OIHW weight
         if cout % 32:                                                                      # conv_out (3 channels): pad the reduction dim
             cp = (cout + 31) // 32 * 32
