@@ -349,9 +349,11 @@ int vf_softmax_mask_bwd_f32(const float* p, float* dp, int64_t batch, int T, int
  * loss[r], dlogits[r][:] = (softmax - y)*row_weight[r] */
 int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* row_weight, float* loss, float* dlogits,
                       int64_t rows, int V, float label_smoothing, void* stream);
-/* pose MSE of QuaternionPoseRepresentation.call (migt.py:165-177): raw [rows][7], gt [rows/L][7] */
-int vf_pose_mse_f32(const float* raw, const float* gt, const float* row_weight, float* pos_loss, float* ori_loss, float* draw,
-                    int64_t rows, int L, float position_multiplier, void* stream);
+/* pose MSE of QuaternionPoseRepresentation.call (migt.py:156-177): raw [rows][7], gt [rows/L][7]; xyz_div [rows] = the per-scene
+ * random pose multiplier the predicted position is divided by (:160-161; NULL = 1); the gradient of the position / orientation
+ * terms is weighted separately (w_pos, w_ori [rows]: DynamicLossWeightingCriterion :107-120 scales them differently) */
+int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const float* w_ori, const float* xyz_div, float* pos_loss,
+                    float* ori_loss, float* draw, int64_t rows, int L, float position_multiplier, void* stream);
 /* backward of vf_embed_sum_f32: dwte (atomic scatter), dwpe (atomic), dadd[bs][:] = sum_l dh */
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
                      int vocab, void* stream);

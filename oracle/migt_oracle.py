@@ -254,8 +254,9 @@ def pose_head(sd, cfg, hidden, dtype):
 
 
 def migt_forward(sd, cfg, input_ids, poses, localization_tokens=None, output_poses=None,
-                 dtype=torch.float32, compute_losses=False, grad=False):
-    """MIGT.call (training=False), migt.py:338-455.
+                 dtype=torch.float32, compute_losses=False, grad=False, pose_factors=None):
+    """MIGT.call (training=False), migt.py:338-455.  ``pose_factors`` [B]: the training-mode random pose multiplier (:350-354; ones
+    at inference) applied to the model-input positions (:141-144).
 
     input_ids [B,S,t,t] int, poses [B,Sp,7] float32.  Returns dict with
     ``logits`` [B,S,t,t,n_embeddings], ``hidden_states`` (list per stream,
@@ -275,7 +276,10 @@ def migt_forward(sd, cfg, input_ids, poses, localization_tokens=None, output_pos
 
         def pose_embed(p):
             # pose MLP runs in float32 in the reference (dtype='float32', migt.py:291)
-            e = mlp(sd, 'pose_embedding', pose_model_input(p.to(dtype), cfg.pose_multiplier), dtype)
+            pin = pose_model_input(p.to(dtype), cfg.pose_multiplier)
+            if pose_factors is not None:
+                pin = torch.cat([pin[..., :3] * pose_factors.to(dtype).view(-1, 1, 1), pin[..., 3:]], -1)
+            e = mlp(sd, 'pose_embedding', pin, dtype)
             return e.unsqueeze(-2)
 
         pose_emb = pose_embed(poses)                           # [B,Sp,1,d]

@@ -24,9 +24,17 @@ def schedule_value(s, t):
     return float(s)
 
 
-def losses(sd, cfg, poses, tokens, step=0, dtype=torch.float64):
-    """forward + losses of MIGT.train_step (migt.py:464-476) -> (scalar loss, metrics); autograd-enabled"""
-    out = mg.migt_forward(sd, cfg, tokens, poses, dtype=dtype, compute_losses=True, grad=True)
+def random_pose_factors(cfg, B, seed, site=2):
+    """rpm ** u_b with u_b = 2 * hash(seed, site, b) / 2^32 - 1: the build's counter-based stand-in for tf.random.uniform at
+    migt.py:351 (train.py SITE_POSE_MULT = 2)"""
+    u = dropout_hash(seed, site, np.arange(B, dtype=np.uint64)).astype(np.float64) / 2.0 ** 32 * 2.0 - 1.0
+    return torch.from_numpy((float(cfg.random_pose_multiplier) ** u).astype(np.float32))
+
+
+def losses(sd, cfg, poses, tokens, step=0, dtype=torch.float64, pose_factors=None):
+    """forward + losses of MIGT.train_step (migt.py:464-476) -> (scalar loss, metrics); autograd-enabled.  ``pose_factors`` [B]: the
+    per-scene random pose multiplier of this step (migt.py:350-354)"""
+    out = mg.migt_forward(sd, cfg, tokens, poses, dtype=dtype, compute_losses=True, grad=True, pose_factors=pose_factors)
     B, S = tokens.shape[:2]
     ids = tokens.reshape(B, S, -1).long()
     skip = cfg.n_loss_skip
@@ -39,21 +47,30 @@ def losses(sd, cfg, poses, tokens, step=0, dtype=torch.float64):
     if cfg.use_localization:                                                            # :430-448
         hidden = out['hidden_states'][-1]                                               # the LOC stream
         raw = mg.mlp(sd, 'pose_criterion.pose_classifier', hidden, dtype)               # :157
+        xyz = raw[..., :3]
+        if pose_factors is not None:
+            xyz = xyz / pose_factors.to(dtype).view(B, 1, 1, 1)                          # :160-161
         y = poses.to(dtype).unsqueeze(-2) * torch.tensor([cfg.pose_multiplier] * 3 + [1.0] * 4, dtype=dtype)   # :167
-        pos = ((y[..., :3] - raw[..., :3]) ** 2).mean(-1)[:, skip:].mean((1, 2))        # :170-175
+        pos = ((y[..., :3] - xyz) ** 2).mean(-1)[:, skip:].mean((1, 2))                 # :170-175
         ori = ((y[..., 3:] - raw[..., 3:]) ** 2).mean(-1)[:, skip:].mean((1, 2))
         w = schedule_value(cfg.localization_weight, step)                               # :446
-        loss = loss + (pos + ori) * w                                                   # :440,447
+        if cfg.use_dynamic_pose_loss:                                                   # DynamicLossWeightingCriterion :107-120
+            sw = sd['pose_loss_weighting_criterion.pos_ori_weights'].to(dtype)
+            pose_loss = (sw + torch.exp(-sw) * torch.stack([pos, ori], -1)).sum()       # reduce_SUM over batch and both terms
+            metrics['pose_loss'] = pose_loss
+        else:
+            pose_loss = pos + ori                                                       # :284
+        loss = loss + pose_loss * w                                                     # :440,447
         metrics.update(pose_pos_loss=pos.mean(), pose_ori_loss=ori.mean(), localization_weight=w)
     total = loss.mean()                                                                 # :476 reduce_mean
     metrics['loss'] = total
     return total, metrics
 
 
-def gradients(sd_np, cfg, poses, tokens, step=0):
+def gradients(sd_np, cfg, poses, tokens, step=0, pose_factors=None):
     """fp64 autograd gradients of the restated loss w.r.t. every variable"""
     sd = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd_np.items()}
-    total, metrics = losses(sd, cfg, torch.as_tensor(poses), torch.as_tensor(tokens), step)
+    total, metrics = losses(sd, cfg, torch.as_tensor(poses), torch.as_tensor(tokens), step, pose_factors=pose_factors)
     total.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
     return grads, {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in metrics.items()}

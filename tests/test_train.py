@@ -152,7 +152,7 @@ def test_backward_kernels_against_autograd(dev):
     assert _err(zc, z.double() * 3.0 / max(z.double().norm().item(), 3.0)) < 1e-6
 
 
-def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothing=0.0):
+def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothing=0.0, **extra):
     from viewformer_amd.config import MIGTConfig
     from viewformer_amd.migt import MIGT
     from viewformer_amd.train import MIGTTrainer
@@ -160,7 +160,7 @@ def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothin
     from oracle import migt_oracle as mg
     cfg = MIGTConfig(**TINY_MIGT, dropout=0.0, n_loss_skip=1, localization_weight='cosine(0,2,10)' if loc else '0',
                      pose_multiplier=0.2, learning_rate=1e-3, weight_decay=0.05, total_steps=50, gradient_clip_val=clip,
-                     label_smoothing=label_smoothing)
+                     label_smoothing=label_smoothing, **extra)
     sd = make_migt_weights(cfg, seed=seed, std=0.08)
     g = np.random.Generator(np.random.PCG64(seed + 3))
     t = cfg.token_image_size
@@ -230,13 +230,36 @@ def test_per_tensor_gradient_clipping(dev):
     tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     for name in tr.names:
         assert float(tr.g(name).norm()) <= 1e-3 * (1 + 1e-4), name
-    with pytest.raises(NotImplementedError):
-        from viewformer_amd.config import MIGTConfig
-        from viewformer_amd.migt import MIGT
-        from viewformer_amd.train import MIGTTrainer
-        from viewformer_amd.weights import make_migt_weights
-        c2 = MIGTConfig(**TINY_MIGT, random_pose_multiplier=2.0)      # unsupported options are refused, never ignored
-        MIGTTrainer(MIGT(c2).load_state_dict(make_migt_weights(c2)).to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opts', [dict(random_pose_multiplier=3.0), dict(use_dynamic_pose_loss=True),
+                                  dict(random_pose_multiplier=1.7, use_dynamic_pose_loss=True)])
+def test_random_pose_multiplier_and_dynamic_pose_loss(dev, opts):
+    """migt.py:350-354,160-161 (per-scene position scale in, divided out of the prediction) and :107-120 (learned log-variance
+    weighting, summed over the batch): loss and every gradient vs fp64 autograd with the same per-scene factors"""
+    from oracle import train_oracle as to
+    cfg, sd, tokens, poses, tr = _setup(True, dev, B=3, **opts)
+    tr.step_count = 4
+    tr.dropout_seed = 11
+    if cfg.use_dynamic_pose_loss:
+        assert 'pose_loss_weighting_criterion.pos_ori_weights' in tr.names
+    metrics = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    f = to.random_pose_factors(cfg, 3, tr.step_seed(4)) if cfg.random_pose_multiplier != 1 else None
+    if f is not None:
+        assert float(f.min()) >= 1 / cfg.random_pose_multiplier - 1e-6 and float(f.max()) <= cfg.random_pose_multiplier + 1e-6
+        assert float((f - 1).abs().max()) > 1e-2
+    grads, ref = to.gradients(sd, cfg, poses, tokens, step=4, pose_factors=f)
+    assert abs(float(metrics['loss']) - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
+    assert abs(float(metrics['pose_pos_loss']) - ref['pose_pos_loss']) < 1e-4 * max(1.0, ref['pose_pos_loss'])
+    for name in tr.names:
+        e = _err(tr.g(name), grads[name].reshape(tr.slices[name][2]))
+        assert e < 2e-3, (name, e)
+    # the optimizer moves the weighting pair too (it is an ordinary decayed variable, models/utils.py:424)
+    if cfg.use_dynamic_pose_loss:
+        before = tr.p('pose_loss_weighting_criterion.pos_ori_weights').clone()
+        tr.apply_gradients()
+        assert float((tr.p('pose_loss_weighting_criterion.pos_ori_weights') - before).abs().max()) > 0
 
 
 @pytest.mark.gpu

@@ -265,7 +265,7 @@ def keras_to_state_dict(bundle: Dict[str, np.ndarray]) -> "OrderedDict[str, np.n
         if '.OPTIMIZER_SLOT' in k or k.split('/')[0] in _IGNORED_PREFIXES:
             continue
         parts = k.split('/')
-        while parts and parts[0] not in ('h', 'wte', 'wpe', 'ln_f', 'pose_embedding', 'pose_criterion') \
+        while parts and parts[0] not in ('h', 'wte', 'wpe', 'ln_f', 'pose_embedding', 'pose_criterion', 'pose_loss_weighting_criterion') \
                 and not parts[0].startswith('h.'):
             parts = parts[1:]                                           # leading model / name scopes
         if not parts:

@@ -235,22 +235,24 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     for (int c = lane; c < V; c += 64) d[c] = (expf(x[c] - mx) / s - ((c == t ? 1.f - eps : 0.f) + uni)) * wr;
 }
 
-// ------------------------------------------------------------------ pose MSE (migt.py:165-177): per token
-// y = gt * [pm,pm,pm,1,1,1,1]; pos = mean_3 (y - raw)^2 ; ori = mean_4 (y - raw)^2 ; d raw = 2 (raw - y)/k * w[row]
-__global__ void pose_loss_kernel(const float* __restrict__ raw, const float* __restrict__ gt, const float* __restrict__ w,
-                                 float* __restrict__ pos, float* __restrict__ ori, float* __restrict__ draw, long long rows,
-                                 int L, float pm) {
+// ------------------------------------------------------------------ pose MSE (migt.py:156-177): per token
+// xyz = raw[0:3] / div[row] (the per-scene random pose multiplier, :160-161; div == nullptr: 1);  y = gt * [pm,pm,pm,1,1,1,1];
+// pos = mean_3 (y - xyz)^2 ; ori = mean_4 (y - raw[3:7])^2 ; d raw = 2 (. - y)/k * {w_pos, w_ori}[row] (/ div for xyz)
+__global__ void pose_loss_kernel(const float* __restrict__ raw, const float* __restrict__ gt, const float* __restrict__ wp,
+                                 const float* __restrict__ wo, const float* __restrict__ div, float* __restrict__ pos,
+                                 float* __restrict__ ori, float* __restrict__ draw, long long rows, int L, float pm) {
     const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float* g = gt + (r / L) * 7;
     const float* x = raw + r * 7;
     float* d = draw + r * 7;
-    const float wr = w[r];
+    const float wpr = wp[r], wor = wo[r];
+    const float dv = div ? div[r] : 1.f;
     float p = 0.f, o = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const float e = x[i] - g[i] * pm; p += e * e; d[i] = 2.f * e / 3.f * wr; }
+    for (int i = 0; i < 3; ++i) { const float e = x[i] / dv - g[i] * pm; p += e * e; d[i] = 2.f * e / 3.f * wpr / dv; }
 #pragma unroll
-    for (int i = 3; i < 7; ++i) { const float e = x[i] - g[i]; o += e * e; d[i] = 2.f * e / 4.f * wr; }
+    for (int i = 3; i < 7; ++i) { const float e = x[i] - g[i]; o += e * e; d[i] = 2.f * e / 4.f * wor; }
     pos[r] = p / 3.f;
     ori[r] = o / 4.f;
 }
@@ -444,11 +446,11 @@ int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* r
     return vf_last_status();
 }
 
-int vf_pose_mse_f32(const float* raw, const float* gt, const float* row_weight, float* pos_loss, float* ori_loss, float* draw,
-                    int64_t rows, int L, float position_multiplier, void* stream) {
-    if (!raw || !gt || !row_weight || !pos_loss || !ori_loss || !draw || rows <= 0 || L <= 0) return VF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pose_loss_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, gt,
-                       row_weight, pos_loss, ori_loss, draw, (long long)rows, L, position_multiplier);
+int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const float* w_ori, const float* xyz_div, float* pos_loss,
+                    float* ori_loss, float* draw, int64_t rows, int L, float position_multiplier, void* stream) {
+    if (!raw || !gt || !w_pos || !w_ori || !pos_loss || !ori_loss || !draw || rows <= 0 || L <= 0) return VF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_loss_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, gt, w_pos,
+                       w_ori, xyz_div, pos_loss, ori_loss, draw, (long long)rows, L, position_multiplier);
     return vf_last_status();
 }
 

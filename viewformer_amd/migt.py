@@ -76,6 +76,8 @@ class MIGT:
             keys += [d + '.weight', d + '.bias']
         for l in lns:
             keys += [l + '.gamma', l + '.beta']
+        if c.use_dynamic_pose_loss and self.use_localization:
+            keys.append('pose_loss_weighting_criterion.pos_ori_weights')      # DynamicLossWeightingCriterion, migt.py:107-113 (training only)
         return keys
 
     def load_state_dict(self, state_dict, strict: bool = True):

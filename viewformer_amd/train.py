@@ -20,7 +20,11 @@ counter-based mask — keep = hash(seed, site, element index) >= rate * 2^32 (cs
 ``dropout_seed`` and the step counter give the per-step seed.  The masks cannot coincide with TensorFlow's RNG stream; the tests
 check the kernels against autograd with the SAME masks restated in numpy (oracle/train_oracle.py).
 
-Limits (raise NotImplementedError otherwise): random_pose_multiplier 1, no dynamic pose-loss weighting.
+``random_pose_multiplier`` (migt.py:350-354,160-161): each scene's positions are scaled by rpm ** u, u ~ U(-1, 1), on the way in
+and the predicted position is divided by the same factor before the loss; u comes from the same counter hash as the dropout masks
+(site SITE_POSE_MULT, element = scene index), restated in oracle/train_oracle.py.  ``use_dynamic_pose_loss`` (:107-120,279-284,440):
+the learned log-variance pair ``pose_loss_weighting_criterion.pos_ori_weights`` — note the reference SUMS this term over the local
+batch (reduce_sum, :117) while every other term is a batch mean; restated as is.
 """
 import math
 import re
@@ -58,6 +62,8 @@ def learning_rate(step, init_lr, total_steps, warmup_steps):
 
 # dropout sites (the `site` word of the counter-based mask): one per Dropout layer instance of the reference
 SITE_EMBED = 1
+SITE_POSE_MULT = 2                      # per-scene random pose multiplier (host-side draw)
+DYN_KEY = 'pose_loss_weighting_criterion.pos_ori_weights'
 
 
 def site_attn(i):
@@ -79,8 +85,10 @@ class MIGTTrainer:
         if not 0.0 <= cfg.dropout < 1.0:
             raise ValueError('dropout must be in [0, 1)')
         self.dropout_seed = 0
-        if cfg.random_pose_multiplier != 1 or cfg.use_dynamic_pose_loss:
-            raise NotImplementedError('random pose multiplier / dynamic pose loss are not built')
+        if not cfg.random_pose_multiplier > 0:
+            raise ValueError('random_pose_multiplier must be positive')
+        if cfg.use_dynamic_pose_loss and DYN_KEY not in (model._sd_host or {}):
+            raise RuntimeError(f'Missing keys: {DYN_KEY} (use_dynamic_pose_loss)')
         if model._sd_host is None or model.device is None:
             raise RuntimeError('load_state_dict() and .to("cuda") the model first')
         self.model, self.cfg, self.dev = model, cfg, model.device
@@ -99,6 +107,8 @@ class MIGTTrainer:
                   'pose_criterion.pose_classifier.c_proj'):
             head += [n + '.weight', n + '.bias']
         head += ['ln_f.gamma', 'ln_f.beta']
+        if c.use_dynamic_pose_loss and self.model.use_localization:
+            head.append(DYN_KEY)
         layers = []
         for i in range(c.n_layer):
             p = f'h.{i}'
@@ -219,6 +229,12 @@ class MIGTTrainer:
 
     attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
 
+    def random_pose_factors(self, B, seed):
+        """rpm ** u_b, u_b = 2 * hash(seed, SITE_POSE_MULT, b) / 2^32 - 1 (migt.py:351; counter-based like the dropout masks)"""
+        from ._hash import dropout_hash
+        u = dropout_hash(seed, SITE_POSE_MULT, np.arange(B, dtype=np.uint64)).astype(np.float64) / 2.0 ** 32 * 2.0 - 1.0
+        return torch.from_numpy((float(self.cfg.random_pose_multiplier) ** u).astype(np.float32))
+
     def step_seed(self, step):
         """per-step dropout seed (uint32) from ``dropout_seed`` and the step counter"""
         return (int(self.dropout_seed) * 0x9E3779B1 + int(step) * 0x85EBCA77 + 0x1234567) & 0xFFFFFFFF
@@ -287,7 +303,13 @@ class MIGTTrainer:
         self.flat_g.zero_()
 
         # ---- forward with saved activations --------------------------------------------------------------
-        pin = geometry.pose_model_input(poses, c.pose_multiplier).reshape(B * S, 7).contiguous()
+        seed = self.step_seed(self.step_count)
+        rmul = None
+        pin = geometry.pose_model_input(poses, c.pose_multiplier)
+        if c.random_pose_multiplier != 1:                                            # migt.py:350-354: rpm ** U(-1, 1) per scene
+            rmul = self.random_pose_factors(B, seed).to(dev)
+            pin = torch.cat([pin[..., :3] * rmul.view(B, 1, 1), pin[..., 3:]], -1)
+        pin = pin.reshape(B * S, 7).contiguous()
         fc = m._dense['pose_embedding.c_fc']
         u1 = ops.dense_small_k(pin, fc.w_raw, fc.bias, B * S, 7, fc.n, gelu=False)
         h1 = T.gelu(u1)
@@ -302,7 +324,6 @@ class MIGTTrainer:
         add = torch.cat(add_streams, 1).contiguous().view(B * V, d)
         h = ops.embed_sum(ids32, m._wte, m._wpe, add, B * V, L, d, nE + 2)
         rate = float(c.dropout)
-        seed = self.step_seed(self.step_count)
         if rate:
             T.dropout_add(h, rate, seed, SITE_EMBED, out=h)                          # self.drop, migt.py:403
         saved = []
@@ -350,13 +371,31 @@ class MIGTTrainer:
             up = self._linear(hloc, 'pose_criterion.pose_classifier.c_fc', M1)
             p1 = T.gelu(up)
             raw = self._linear(p1, 'pose_criterion.pose_classifier.c_proj', M1)
-            w_pose = (view_ok * (loc_w / denom)).contiguous()
-            pos_r, ori_r, draw = T.pose_mse(raw, poses.reshape(B * S, 7).contiguous(), w_pose, M1, L, c.pose_multiplier)
+            dyn = c.use_dynamic_pose_loss
+            if dyn:                                                                  # DynamicLossWeightingCriterion, migt.py:107-120
+                sw = self.p(DYN_KEY)
+                e_pos, e_ori = float(torch.exp(-sw[0])), float(torch.exp(-sw[1]))
+                rows_per_scene = float((S - skip) * L)
+                w_pos = (view_ok * (loc_w * e_pos / rows_per_scene)).contiguous()    # reduce_SUM over the batch (:117): no 1/B
+                w_ori = (view_ok * (loc_w * e_ori / rows_per_scene)).contiguous()
+            else:
+                w_pos = w_ori = (view_ok * (loc_w / denom)).contiguous()
+            div = None if rmul is None else rmul.view(B, 1).expand(B, S * L).reshape(M1).contiguous()
+            pos_r, ori_r, draw = T.pose_mse(raw, poses.reshape(B * S, 7).contiguous(), w_pos, M1, L, c.pose_multiplier, w_ori=w_ori,
+                                            xyz_div=div)
             pos_b = pos_r.view(B, S, L)[:, skip:].mean((1, 2))
             ori_b = ori_r.view(B, S, L)[:, skip:].mean((1, 2))
-            loss_b = loss_b + (pos_b + ori_b) * loc_w
-            metrics.update(pose_pos_loss=pos_b.mean(), pose_ori_loss=ori_b.mean(), pose_loss=(pos_b + ori_b).mean(),
-                           localization_weight=loc_w)
+            if dyn:
+                pose_loss = (sw[0] + e_pos * pos_b + sw[1] + e_ori * ori_b).sum()    # a scalar, broadcast onto every scene (:440,447)
+                loss_b = loss_b + pose_loss * loc_w
+                gs = self.g(DYN_KEY)
+                gs[0] = loc_w * (B - e_pos * pos_b.sum())
+                gs[1] = loc_w * (B - e_ori * ori_b.sum())
+                metrics.update(dynamic_loss_weight_pos=sw[0].clone(), dynamic_loss_weight_ori=sw[1].clone(), pose_loss=pose_loss)
+            else:
+                loss_b = loss_b + (pos_b + ori_b) * loc_w
+                metrics['pose_loss'] = (pos_b + ori_b).mean()
+            metrics.update(pose_pos_loss=pos_b.mean(), pose_ori_loss=ori_b.mean(), localization_weight=loc_w)
         metrics['loss'] = loss_b.mean()                                              # reduce_mean, migt.py:476
 
         # ---- backward -------------------------------------------------------------------------------------

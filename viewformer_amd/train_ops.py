@@ -80,12 +80,16 @@ def softmax_ce(logits, target_i32, row_weight, rows, V, label_smoothing=0.0):
     return loss, dl
 
 
-def pose_mse(raw, gt, row_weight, rows, L, position_multiplier):
+def pose_mse(raw, gt, row_weight, rows, L, position_multiplier, w_ori=None, xyz_div=None):
+    """``row_weight`` weights the position term's gradient, ``w_ori`` (default: the same) the orientation term's; ``xyz_div`` [rows]:
+    per-row divisor of the predicted position (the random pose multiplier)"""
     dev = raw.device
     pos = torch.empty(rows, dtype=torch.float32, device=dev)
     ori = torch.empty(rows, dtype=torch.float32, device=dev)
     draw = torch.empty((rows, 7), dtype=torch.float32, device=dev)
-    check(_lib.load().vf_pose_mse_f32(_p(_f32(raw)), _p(_f32(gt)), _p(_f32(row_weight)), _p(pos), _p(ori), _p(draw), rows, L,
+    w_ori = row_weight if w_ori is None else w_ori
+    check(_lib.load().vf_pose_mse_f32(_p(_f32(raw)), _p(_f32(gt)), _p(_f32(row_weight)), _p(_f32(w_ori)),
+                                      _p(_f32(xyz_div)) if xyz_div is not None else None, _p(pos), _p(ori), _p(draw), rows, L,
                                       position_multiplier, _stream()), 'vf_pose_mse_f32')
     return pos, ori, draw
 
