@@ -194,6 +194,10 @@ int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx
 uint32_t vf_crc32c(const void* data, size_t n, uint32_t crc);
 /* clip[-1,1] -> /2+0.5 -> trunc(x*255.5) uint8  (evaluate_transformer.py:128-129, TF semantics) */
 int vf_postprocess_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+/* resize of the evaluators' pre-process (viewformer/data/_common.py:19-61 resize / resize_th): NHWC uint8 [n][Hin][Win][C] ->
+ * [n][Hout][Wout][C]; bilinear = 0: torch 'nearest' (the reference's choice when enlarging), 1: bilinear, align_corners = False
+ * (shrinking); through /255, clamp, *255 and a truncating cast exactly as the reference does (bit-identical uint8). */
+int vf_resize_u8(const uint8_t* src, uint8_t* dst, int n_img, int Hin, int Win, int Hout, int Wout, int C, int bilinear, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Reduced-precision arm (bf16 MFMA, fp32 activations in HBM, fp32 accumulate / epilogue) for the layers whose

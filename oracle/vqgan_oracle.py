@@ -213,6 +213,45 @@ def decode_code(sd, cfg, codes, dtype=torch.float32):
 
 
 # ---- image pre/post-processing used by the evaluators (TF semantics restated) ----------
+def resize_u8(images_u8_nhwc, image_size, method=None):
+    """``resize`` / ``resize_th`` (viewformer/data/_common.py:19-61) restated in numpy fp32: uint8 -> /255 -> torch interpolate
+    ('nearest' when enlarging, bilinear align_corners=False when shrinking) -> clamp -> *255 -> truncating uint8 cast.  The CPU
+    interpolation of torch evaluates fma(l0, a, l1*b) per axis (x, then y); emulated with an fp64 product-sum rounded once.
+    Pinned by tests/golden/resize.npz (recorded from the reference)."""
+    import numpy as np
+    img = np.asarray(images_u8_nhwc)
+    n, H, W, C = img.shape
+    if H == image_size:
+        return img
+    if method is None:
+        method = 'nearest' if image_size > H else 'bilinear'
+    f32 = np.float32
+    p = (img.astype(np.float32) / f32(255.0)).astype(np.float32)
+    if method == 'nearest':
+        def idx(inp):
+            scale = f32(inp) / f32(image_size)
+            return np.minimum(np.floor(np.arange(image_size, dtype=np.float32) * scale).astype(np.int64), inp - 1)
+        v = p[:, idx(H)][:, :, idx(W)]
+    else:
+        def axis(inp):
+            scale = f32(inp) / f32(image_size)
+            src = np.maximum(scale * (np.arange(image_size, dtype=np.float32) + f32(0.5)) - f32(0.5), f32(0))
+            i0 = src.astype(np.int64)
+            l1 = (src - i0.astype(np.float32)).astype(np.float32)
+            return i0, i0 + (i0 < inp - 1), (f32(1) - l1).astype(np.float32), l1
+
+        def fma(l0, a, l1, b):
+            t = (l1 * b).astype(np.float32)
+            return (l0.astype(np.float64) * a.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+        y0, y1, ly0, ly1 = axis(H)
+        x0, x1, lx0, lx1 = axis(W)
+        lx0, lx1 = lx0[None, None, :, None], lx1[None, None, :, None]
+        top = fma(lx0, p[:, y0][:, :, x0], lx1, p[:, y0][:, :, x1])
+        bot = fma(lx0, p[:, y1][:, :, x0], lx1, p[:, y1][:, :, x1])
+        v = fma(ly0[None, :, None, None], top, ly1[None, :, None, None], bot)
+    return (np.clip(v, 0, 1) * f32(255.0)).astype(np.float32).astype(np.uint8)
+
+
 def preprocess_u8(images_u8_nhwc):
     """evaluate_transformer.py:105-108: tf.image.convert_image_dtype(uint8->float32)
     multiplies by fp32(1/255) (tensorflow==2.4.1, third-party), then ``* 2 - 1``.

@@ -326,3 +326,37 @@ def test_quantizer_ema_accumulate_is_deterministic_and_additive_over_replicas(de
     cb, sb = acc(z[M // 2:].contiguous(), idx[M // 2:].contiguous())
     assert torch.equal(ca + cb, c)
     assert ((sa + sb - s).abs().max() / s.abs().max()).item() < 1e-6
+
+
+@pytest.mark.gpu
+def test_resize_u8_bit_identical_to_reference_golden_and_oracle():
+    """vf_resize_u8 (evaluators' pre-process resize, data/_common.py:19-61) vs the reference-recorded outputs, and vs the oracle on
+    more size pairs; empty batch"""
+    import os
+    from oracle import vqgan_oracle as vq
+    from viewformer_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resize.npz'))
+    for i in range(8):
+        dst, meth = (int(v) for v in g[f'meta{i}'])
+        method = None if meth < 0 else ['nearest', 'bilinear'][meth]
+        got = ops.resize_u8(torch.from_numpy(g[f'in{i}']).cuda(), dst, method).cpu().numpy()
+        assert np.array_equal(got, g[f'out{i}']), i
+    rng = np.random.default_rng(3)
+    for src, dst in [(129, 128), (131, 64), (512, 128), (100, 128), (17, 128), (255, 32)]:
+        img = rng.integers(0, 256, size=(2, src, src, 3), dtype=np.uint8)
+        got = ops.resize_u8(torch.from_numpy(img).cuda(), dst).cpu().numpy()
+        assert np.array_equal(got, vq.resize_u8(img, dst)), (src, dst)
+    assert ops.resize_u8(torch.zeros((0, 64, 64, 3), dtype=torch.uint8, device='cuda'), 128).shape == (0, 128, 128, 3)
+
+
+@pytest.mark.gpu
+def test_empty_batches_are_not_errors():
+    """the reference returns empty tensors for an empty batch (torch semantics); so does the HIP model"""
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_vqgan_weights
+    cfg = VQGANConfig(ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], image_size=32, z_channels=32, embed_dim=32, n_embed=64)
+    model = VQGAN(cfg, data_format='NCHW', device='cuda').load_state_dict(make_vqgan_weights(cfg, seed=3))
+    quant, diff, codes = model.encode(torch.zeros((0, 3, 32, 32), device='cuda'))
+    assert codes.shape == (0, 16, 16) and codes.dtype == torch.int64 and quant.shape == (0, 32, 16, 16)
+    assert model.decode_code(codes).shape == (0, 3, 32, 32)

@@ -79,7 +79,7 @@ def test_migt_training_graph_forward_matches_oracle(dev, loc):
         assert _maxerr(a, b) < 2e-4
     if loc:
         assert _maxerr(out['pose_prediction'], ref['pose_prediction']) < 2e-4
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='MIGTTrainer'):                  # the training graph lives in train.MIGTTrainer
         m(dict(input_ids=ids.to(dev), poses=cams.to(dev)), training=True)
 
 

@@ -157,3 +157,14 @@ def test_vqgan_training_step_oracle_matches_reference_golden():
             got = _summary(params[n])
             assert np.allclose(got[[0, 2, 3, 4]], want[i][[0, 2, 3, 4]], rtol=1e-4, atol=2.1 * float(g['lr']) * step), (step, n)
             assert abs(got[0] - want[i][0]) < 1e-4 * want[i][0] + 1e-6, (step, n)
+
+
+def test_resize_oracle_matches_reference_golden():
+    """data/_common.py:19-61 resize (nearest up / bilinear down, truncating uint8 cast): bit-identical to the reference's outputs"""
+    import os
+    from oracle import vqgan_oracle as vq
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resize.npz'))
+    for i in range(8):
+        dst, meth = (int(v) for v in g[f'meta{i}'])
+        got = vq.resize_u8(g[f'in{i}'], dst, None if meth < 0 else ['nearest', 'bilinear'][meth])
+        assert got.dtype == np.uint8 and np.array_equal(got, g[f'out{i}']), i

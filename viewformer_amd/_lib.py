@@ -85,6 +85,7 @@ EXPORTS = {
     'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),
     'vf_postprocess_u8': (c_int, [P, P, c_int64, P]),
+    'vf_resize_u8': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     # ---- bf16 arm (transformer dense layers, decoder convolutions)
     'vf_gemm_bf16_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_gemm_bf16_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, P]),

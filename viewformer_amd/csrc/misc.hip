@@ -213,6 +213,53 @@ inline unsigned grid_for(long long total, int per_block, unsigned cap = 16384) {
     return (unsigned)b;
 }
 
+// image resize of the evaluators' pre-process (data/_common.py:19-61): uint8 -> /255 -> nearest (enlarging) or bilinear,
+// align_corners = False (shrinking) -> clamp -> *255 -> truncate to uint8.  The reference's CPU interpolation evaluates
+// fma(l0, a, l1 * b) along x, then along y, in fp32; reproduced operation by operation so that the uint8 result (a truncation,
+// hence sensitive to the last bit) is identical (tests/golden/resize.npz).
+__device__ __forceinline__ void resize_axis(int dst, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
+    float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = __fsub_rn(src, (float)i0);
+    l0 = __fsub_rn(1.f, l1);
+}
+
+__global__ void resize_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long long total, int Hin, int Win,
+                                 int Hout, int Wout, int C, int bilinear) {
+    const float sy = __fdiv_rn((float)Hin, (float)Hout), sx = __fdiv_rn((float)Win, (float)Wout);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int x = (int)(t % Wout); t /= Wout;
+        const int y = (int)(t % Hout);
+        const long long img = t / Hout;
+        const uint8_t* b = src + img * Hin * Win * C + c;
+        float v;
+        if (!bilinear) {
+            int iy = (int)floorf(__fmul_rn((float)y, sy)), ix = (int)floorf(__fmul_rn((float)x, sx));
+            iy = iy < Hin - 1 ? iy : Hin - 1;
+            ix = ix < Win - 1 ? ix : Win - 1;
+            v = __fdiv_rn((float)b[((long long)iy * Win + ix) * C], 255.f);
+        } else {
+            int y0, y1, x0, x1;
+            float ly0, ly1, lx0, lx1;
+            resize_axis(y, Hin, sy, y0, y1, ly0, ly1);
+            resize_axis(x, Win, sx, x0, x1, lx0, lx1);
+            const float p00 = __fdiv_rn((float)b[((long long)y0 * Win + x0) * C], 255.f);
+            const float p01 = __fdiv_rn((float)b[((long long)y0 * Win + x1) * C], 255.f);
+            const float p10 = __fdiv_rn((float)b[((long long)y1 * Win + x0) * C], 255.f);
+            const float p11 = __fdiv_rn((float)b[((long long)y1 * Win + x1) * C], 255.f);
+            const float top = __fmaf_rn(lx0, p00, __fmul_rn(lx1, p01));
+            const float bot = __fmaf_rn(lx0, p10, __fmul_rn(lx1, p11));
+            v = __fmaf_rn(ly0, top, __fmul_rn(ly1, bot));
+        }
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[i] = (uint8_t)__fmul_rn(v, 255.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -264,6 +311,17 @@ int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream
     if (rows == 0) return VF_OK;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)rows, n, scale);
+    return vf_last_status();
+}
+
+int vf_resize_u8(const uint8_t* src, uint8_t* dst, int n_img, int Hin, int Win, int Hout, int Wout, int C, int bilinear,
+                 void* stream) {
+    if (n_img < 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0) return VF_ERR_BAD_ARG;
+    if (n_img == 0) return VF_OK;
+    if (!src || !dst) return VF_ERR_BAD_ARG;
+    const long long total = (long long)n_img * Hout * Wout * C;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, total, Hin, Win,
+                       Hout, Wout, C, bilinear);
     return vf_last_status();
 }
 

@@ -27,8 +27,11 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
 
     B, S = images.shape[:2]
     t = transformer_model.config.token_image_size
-    if images.shape[2] != codebook_model.config.image_size:
-        raise NotImplementedError('resize (data/_common.py:47-61) is not on the MI355X path; feed image_size frames')
+    if images.shape[2] != codebook_model.config.image_size:                 # resize_tf, evaluate_transformer.py:18-19,105
+        if images.dtype != torch.uint8:
+            raise TypeError('frames of another size than config.image_size must be uint8 (data/_common.py:19-45 resizes uint8)')
+        images = ops.resize_u8(images.reshape(B * S, *images.shape[2:]), codebook_model.config.image_size)
+        images = images.view(B, S, *images.shape[1:])
     # encode every view, target included, exactly as the reference does (:114-116)
     codes = codebook_model.encode(images.reshape(B * S, *images.shape[2:]))[-1]
     codes = codes.to(torch.int32).view(B, S, t, t)                      # :110,116

@@ -286,7 +286,8 @@ class MIGT:
     # ------------------------------------------------------------------ forward (single stream, inference)
     def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False):
         if training:
-            raise NotImplementedError('training (dropout, losses, backward) is not built yet (SURVEY.md §8 row a18)')
+            raise RuntimeError('the training graph (dropout, losses, backward, optimizer: MIGT.train_step migt.py:464-505) is '
+                               'viewformer_amd.train.MIGTTrainer(model).train_step(poses, tokens); __call__ is inference')
         if self._sd_host is None or self.device is None:
             raise RuntimeError('MIGT: load_state_dict() and .to("cuda") first')
         c, dev = self.config, self.device

@@ -370,3 +370,20 @@ def postprocess_u8(x):
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     check(_lib.load().vf_postprocess_u8(_p(x), _p(out), x.numel(), _stream()), 'vf_postprocess_u8')
     return out
+
+
+def resize_u8(images, image_size, method=None):
+    """``resize`` of viewformer/data/_common.py:47-61 on NHWC uint8 images [n,H,W,C]: identity when H == image_size, otherwise torch
+    'nearest' when enlarging / bilinear (align_corners=False) when shrinking unless ``method`` says otherwise; uint8 out"""
+    if method not in (None, 'nearest', 'bilinear'):
+        raise ValueError("method must be None, 'nearest' or 'bilinear'")
+    n, H, W, C = images.shape
+    if H == image_size:
+        return images
+    if method is None:
+        method = 'nearest' if image_size > H else 'bilinear'
+    src = _chk(images.contiguous(), torch.uint8, 'images')
+    out = torch.empty((n, image_size, image_size, C), dtype=torch.uint8, device=images.device)
+    check(_lib.load().vf_resize_u8(_p(src), _p(out), n, H, W, image_size, image_size, C, 1 if method == 'bilinear' else 0, _stream()),
+          'vf_resize_u8')
+    return out

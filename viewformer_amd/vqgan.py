@@ -298,6 +298,10 @@ class VQGAN:
         self._require_ready()
         x = self._to_nhwc(x.to(self.device))
         n = x.shape[0]
+        if n == 0:                                                        # an empty batch is not an error in the reference
+            t = x.shape[1] // self.config.stride
+            return _LazyEncodeResult(self, torch.empty((0, self.config.embed_dim), dtype=torch.float32, device=self.device),
+                                     torch.empty((0, t, t), dtype=torch.int64, device=self.device))
         zs, cs = [], []
         for a, b in self._chunks(n):
             z, c = self._encode_nhwc(x[a:b])
@@ -317,6 +321,10 @@ class VQGAN:
         cfg = self.config
         codes = code_b.to(self.device).to(torch.int64).contiguous()
         n, h, w = codes.shape
+        if n == 0:
+            s = self.config.stride
+            out = torch.empty((0, h * s, w * s, self.config.out_ch), dtype=torch.float32, device=self.device)
+            return out.permute(0, 3, 1, 2) if self.data_format == 'NCHW' else out
         outs = []
         for a, b in self._chunks(n):
             q = ops.codebook_gather(self._E, codes[a:b], cfg.embed_dim, cfg.n_embed)   # embed_code, utils_th.py:70-72
@@ -361,6 +369,11 @@ class _LazyEncodeResult(tuple):
         if self._qd is None:
             m, cfg = self._model, self._model.config
             n, h, w = self._codes.shape
+            if n == 0:
+                quant = torch.empty((0, h, w, cfg.embed_dim), dtype=torch.float32, device=self._codes.device)
+                self._qd = (quant.permute(0, 3, 1, 2) if m.data_format == 'NCHW' else quant,
+                            torch.full((), float('nan'), device=self._codes.device))       # mean over nothing, as torch gives
+                return self._qd
             q = ops.codebook_gather(m._E, self._codes, cfg.embed_dim, cfg.n_embed)
             z = self._z
             diff = (q - z).pow(2).mean()                 # utils_th.py:66  (reporting value, not on the hot path)
