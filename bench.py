@@ -33,7 +33,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (me
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x6'):
+X3H_PMC_KB = (None, None)          # (FETCH_SIZE, WRITE_SIZE) of the x3h conv's PMC pass, filled in once profiled
+
+
+def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h'):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -144,9 +147,11 @@ def main():
                          "bit-exact) with the transformer's dense layers and the decoder's convolutions on bf16 MFMA, fp32 "
                          "accumulate (logits / pixels within the tolerances stated in tests/test_hip_bf16.py); "
                          "f32: everything exact fp32 (full fp32 parity arm)")
-    ap.add_argument('--conv-arith', choices=['x6', 'f32'], default='x6',
-                    help="how the fp32 3x3 convolutions are evaluated: x6 = fp32-equivalent six-term split-bf16 products on the "
-                         "bf16 matrix pipe (same error vs fp64 as the f32 MFMA, tests/test_hip_x6.py); f32 = native f32 MFMA")
+    ap.add_argument('--conv-arith', choices=['x3h', 'x6', 'f32'], default='x3h',
+                    help="how the fp32 3x3 convolutions are evaluated: x3h = fp32-equivalent three-term split-fp16 products (low piece "
+                         "carried at 2^11, cross terms in their own accumulator; error vs fp64 <= the f32 MFMA for activations in "
+                         "fp16's range, tests/test_hip_x3h.py) for the stride-1 / upsample convs, x6 elsewhere; x6 = six-term "
+                         "split-bf16 products everywhere (no range condition, tests/test_hip_x6.py); f32 = native f32 MFMA")
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -205,9 +210,13 @@ def main():
                        'precision': ('fp32 everywhere' if args.precision == 'f32' else
                                      'mixed: fp32 encoder + codebook lookup (bit-exact tokens), bf16-MFMA transformer dense '
                                      'layers + decoder convs (fp32 accumulate; tolerances in tests/test_hip_bf16.py)'),
-                       'fp32_conv_arithmetic': ('x6: every fp32 product = 6 exact bf16 partial products (operands split h+m+l) '
-                                                'accumulated in fp32 on the bf16 MFMA pipe; error vs fp64 <= native f32 MFMA '
-                                                '(tests/test_hip_x6.py)' if args.conv_arith == 'x6' else 'native f32 MFMA'),
+                       'fp32_conv_arithmetic': {
+                           'x3h': 'x3h: every fp32 product = 3 exact fp16 partial products (operands split h + l*2^-11 with l carried at '
+                                  '2^11, cross terms in their own fp32 accumulator, power-of-two pre-scaled weights) on the fp16 MFMA '
+                                  'pipe; error vs fp64 <= native f32 MFMA (tests/test_hip_x3h.py); stride-2 and 1x1 convs: x6',
+                           'x6': 'x6: every fp32 product = 6 exact bf16 partial products (operands split h+m+l) accumulated in fp32 on '
+                                 'the bf16 MFMA pipe; error vs fp64 <= native f32 MFMA (tests/test_hip_x6.py)',
+                           'f32': 'native f32 MFMA'}[args.conv_arith],
                        'weights': 'random-init (deterministic generator), full-size VQGAN 67.9M + MIGT 88.4M',
                        'algorithmic_gflop_per_view': round(gf, 1),
                        'whole_path_tflops': round(value * gf / 1e3, 2)},
@@ -228,22 +237,25 @@ def main():
         d_ms = dom[0] / dom[2]                               # average launch duration (HIP events, launch stream)
         d_fl = dom[1] / dom[2]                               # algorithmic (fp32 conv) FLOP per launch
         ach = d_fl / (d_ms * 1e-3) / 1e12
-        x6 = args.conv_arith == 'x6'
+        x6 = args.conv_arith in ('x6', 'x3h')
+        nprod = {'x3h': 3, 'x6': 6, 'f32': 1}[args.conv_arith]
         # HBM bytes per launch from the PMC passes (profiles/r1_conv_x6_pmc.txt / r1_conv_halo_pmc.txt: 2*FETCH_SIZE +
         # WRITE_SIZE with the gfx950 unit correction), measured on a 56-image launch of this shape, scaled by pixels
-        fetch_kb, write_kb = (516830e3, 458750e3) if x6 else (497520e3, 458750e3)
-        is_dom_shape = dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
+        fetch_kb, write_kb = {'x3h': X3H_PMC_KB, 'x6': (516830e3, 458750e3), 'f32': (497520e3, 458750e3)}[args.conv_arith]
+        is_dom_shape = fetch_kb is not None and dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
         pmc_bytes_per_pixel = (2 * fetch_kb + write_kb) * 1.024 / (56 * 128 * 128) if is_dom_shape else None
         # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6
-        peak = BF16_MFMA_PEAK_TFLOPS / 6 if x6 else F32_MFMA_PEAK_TFLOPS
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if x6 else F32_MFMA_PEAK_TFLOPS      # dense f16 peak == dense bf16 peak (2.5 PF)
         line['roofline'] = {'bound': 'mfma',
-                            'kernel': ('conv3_halo_x6_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 6x v_mfma_f32_32x32x16_bf16 '
+                            'kernel': ('conv3_halo_x3h_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_32x32x16_f16 '
+                                       'per fp32 product)' if nprod == 3 else
+                                       'conv3_halo_x6_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 6x v_mfma_f32_32x32x16_bf16 '
                                        'per fp32 product)' if x6 else
                                        'conv3_halo_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, v_mfma_f32_32x32x2_f32)'),
                             'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                             'frac': round(ach / peak, 4),
-                            'peak_note': ('algorithmic fp32 TFLOP/s; peak = dense bf16 MFMA peak 2500 / 6 partial products. Executed '
-                                          f'bf16 rate {round(6 * ach, 1)} TFLOP/s; the native f32 MFMA peak is {F32_MFMA_PEAK_TFLOPS}'
+                            'peak_note': (f'algorithmic fp32 TFLOP/s; peak = dense 16-bit MFMA peak 2500 / {nprod} partial products. Executed '
+                                          f'16-bit rate {round(nprod * ach, 1)} TFLOP/s; the native f32 MFMA peak is {F32_MFMA_PEAK_TFLOPS}'
                                           if x6 else 'dense f32 MFMA peak'),
                             'traffic': (round(pmc_bytes_per_pixel * dom_key[1]) if pmc_bytes_per_pixel else None),
                             'traffic_unit': 'bytes/launch (PMC, scaled from the 56-image profile)',

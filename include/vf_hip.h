@@ -228,6 +228,13 @@ int vf_conv3_halo_gn_slots(int Hout, int Wout);
 size_t vf_conv3_x6_packed_elems(int Cin, int Cout);       /* number of bf16 elements (3 planes) */
 int vf_conv3_x6_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
 int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);
+/* the same 3x3 convolution (stride 1 / nearest-x2 upsample; same call sites) with HALF the matrix instructions: operands split
+ * into two fp16 pieces with the low piece carried at 2^11 times its value, 3 products, cross terms in their own accumulator, weights
+ * pre-scaled by a power of two at pack time (csrc/conv3_halo_x3h.hip).  fp32-equivalent for |x| in [~6e-5, 65504): the arithmetic
+ * of the inference encoder (GroupNorm-normalised / O(1) activations); x6 has no range condition and stays the training arithmetic. */
+size_t vf_conv3_x3h_packed_elems(int Cin, int Cout);      /* number of f16 elements (2 planes + the 1/S tail) */
+int vf_conv3_x3h_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
+int vf_conv3_halo_x3h(const vf_igemm_args* args /* host */, void* stream);
 /* dense / 1x1 sibling: VF_MODE_GEMM, Cin % 64 == 0, batch == 1, optional GroupNorm(+swish) prologue, bias / exact-erf GELU /
  * residual epilogue.  Replaces the same call sites as vf_igemm_f32's GEMM mode (Conv1D.call migt.py:89-96,
  * SharedEmbeddings._linear :51-56, the 1x1 convolutions of vqgan_th.py:72-76,99-118,332-333).

@@ -25,7 +25,7 @@ def _maxerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ VQGAN
-@pytest.mark.parametrize('arith', ['f32', 'x6'])
+@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h'])
 def test_vqgan_tiny_matches_reference_golden(dev, tiny_vq, arith):
     from oracle import vqgan_oracle as vq
     cfg, sd, g = tiny_vq
@@ -44,7 +44,7 @@ def test_vqgan_tiny_matches_reference_golden(dev, tiny_vq, arith):
     assert torch.equal(codes_u8, codes)
 
 
-@pytest.mark.parametrize('arith', ['f32', 'x6'])      # native f32 MFMA / fp32-equivalent split-bf16 convolutions
+@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h'])      # native f32 MFMA / fp32-equivalent split-bf16 / split-fp16 convolutions
 def test_vqgan_full_matches_reference_golden(dev, full_vq, arith):
     from viewformer_amd.weights import synthetic_scene_batch
     cfg, sd, g = full_vq

@@ -1,0 +1,111 @@
+"""GPU: the fp32-equivalent split-fp16 ("x3h") convolution — two fp16 pieces per operand with the low piece carried at 2^11,
+three products, cross terms in their own accumulator, power-of-two pre-scaled weights (csrc/conv3_halo_x3h.hip).  The claim under
+test: for activations inside fp16's range its error against fp64 is no larger than the native f32-MFMA kernel's (it is NOT a
+reduced-precision arm); outside that range it degrades as documented, which is why x6 stays the arithmetic of the backward pass."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _err(out, ref, mag):
+    e = (out.double().cpu() - ref).abs() / mag
+    return e.max().item(), e.pow(2).mean().sqrt().item()
+
+
+def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
+    from viewformer_amd import ops
+    n = n or (3 if H == 8 else 2)
+    x = _rand((n, cin, H, H), 11) * xscale + 0.2 * xscale
+    w, b = _rand((cout, cin, 3, 3), 12, wscale), _rand((cout,), 13) * wscale * xscale * 10
+    gamma, beta = _rand((cin,), 14) * 0.3 + 1, _rand((cin,), 15) * 0.2
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    prol, a = None, x.double()
+    if pro:
+        mean_c, scale_c = ops.groupnorm_stats(xn, gamma.to(dev), n, H * H, cin)
+        prol = (mean_c, scale_c, beta.to(dev))
+        mu = mean_c.double().cpu().view(n, cin, 1, 1)
+        sc = scale_c.double().cpu().view(n, cin, 1, 1)
+        a = (a - mu) * sc + beta.double().view(1, cin, 1, 1)
+        a = a * torch.sigmoid(a)
+    m, Ho = {'s1': (ops.MODE_CONV3_S1, H), 'up': (ops.MODE_CONV3_UP2, 2 * H)}[mode]
+    if mode == 'up':
+        a = F.interpolate(a, scale_factor=2.0, mode='nearest')
+    ref = F.conv2d(a, w.double(), None, padding=1)
+    mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1)
+    res = _rand((n * Ho * Ho, cout), 16) * wscale * xscale * 10
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + b.double() + res.double()
+    mag = mag.permute(0, 2, 3, 1).reshape(-1, cout) + b.double().abs() + res.double().abs()
+    kw = dict(bias=b.to(dev), res=res.to(dev), mode=m, pro=prol, pro_swish=True, Hin=H, Win=H, Hout=Ho, Wout=Ho)
+    assert ops.conv3_x3h_supported(m, cin, cout, Ho, Ho)
+    o3 = torch.empty((n * Ho * Ho, cout), device=dev)
+    ops.igemm(xn, ops.pack_conv3_x3h(w.to(dev)), n * Ho * Ho, cin, cout, o3, x3h=True, **kw)
+    o32 = torch.empty((n * Ho * Ho, cout), device=dev)
+    ops.igemm(xn, ops.pack_conv_oihw(w.to(dev)), n * Ho * Ho, cin, cout, o32, **kw)
+    return _err(o3, ref, mag), _err(o32, ref, mag)
+
+
+@pytest.mark.parametrize('mode,cin,cout,H,pro', [('s1', 128, 128, 16, True), ('s1', 64, 256, 32, False), ('up', 128, 128, 8, False),
+                                                  ('up', 32, 128, 16, True), ('s1', 128, 128, 64, True),
+                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True)])
+def test_conv3_halo_x3h_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
+    (mx3, rms3), (mx32, rms32) = _run(dev, mode, cin, cout, H, pro)
+    print(f'{mode} {cin}->{cout} @{H} pro={pro}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
+    assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
+
+
+@pytest.mark.parametrize('xscale,wscale', [(1e-2, 0.05), (300.0, 0.02), (1.0, 1e-4), (1.0, 30.0), (3e-3, 2.0)])
+def test_x3h_holds_over_the_magnitudes_of_the_inference_path(dev, xscale, wscale):
+    """un-normalised inputs (no prologue) from 1e-2 to a few hundred and any weight scale (absorbed by the pack-time power of two)"""
+    (mx3, rms3), (mx32, rms32) = _run(dev, 's1', 128, 128, 16, False, xscale=xscale, wscale=wscale)
+    print(f'x ~{xscale:g} w ~{wscale:g}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
+    assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
+
+
+def test_x3h_range_limit_is_what_the_header_says(dev):
+    """gradient-like magnitudes (1e-6) are below fp16's range: the error grows to ~1e-5 — the reason the backward pass keeps x6"""
+    (mx3, rms3), (mx32, rms32) = _run(dev, 's1', 128, 128, 16, False, xscale=1e-6)
+    print(f'x ~1e-6: x3h rms {rms3:.2e} | f32 MFMA rms {rms32:.2e}')
+    assert rms3 > 3 * rms32 and rms3 < 1e-3
+
+
+def test_x3h_fused_groupnorm_partials(dev):
+    from viewformer_amd import ops
+    for mode, cin, cout, H, n in [('s1', 64, 128, 16, 2), ('up', 32, 256, 8, 2), ('s1', 64, 512, 8, 3)]:
+        x = (_rand((n, H, H, cin), 31) * 1.3 + 0.1).to(dev)
+        w, b = _rand((cout, cin, 3, 3), 32, 0.08).to(dev), _rand((cout,), 33).to(dev)
+        gamma = (_rand((cout,), 34) * 0.3 + 1).to(dev)
+        m, Ho = (ops.MODE_CONV3_S1, H) if mode == 's1' else (ops.MODE_CONV3_UP2, 2 * H)
+        out = torch.empty((n * Ho * Ho, cout), device=dev)
+        part = ops.new_gn_part(n, Ho, Ho, dev)
+        part.fill_(float('nan'))
+        ops.igemm(x, ops.pack_conv3_x3h(w), n * Ho * Ho, cin, cout, out, bias=b, mode=m, Hin=H, Win=H, Hout=Ho, Wout=Ho, x3h=True,
+                  gn_part=part)
+        assert torch.isfinite(part).all()
+        mean_f, scale_f = ops.groupnorm_finalize(part, gamma, n, Ho * Ho, cout)
+        mean_s, scale_s = ops.groupnorm_stats(out, gamma, n, Ho * Ho, cout)
+        assert (mean_f - mean_s).abs().max().item() < 2e-6 * (1 + mean_s.abs().max().item())
+        assert ((scale_f - scale_s).abs() / scale_s.abs()).max().item() < 5e-6
+
+
+def test_x3h_refuses_stride_2(dev):
+    from viewformer_amd import ops
+    assert not ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 16, 16)
+    x = torch.zeros((2 * 32 * 32, 128), device=dev)
+    out = torch.empty((2 * 16 * 16, 128), device=dev)
+    with pytest.raises(ops._lib.VfError):
+        ops.igemm(x, ops.pack_conv3_x3h(torch.zeros((128, 128, 3, 3), device=dev)), 2 * 16 * 16, 128, 128, out,
+                  mode=ops.MODE_CONV3_S2PAD, Hin=32, Win=32, Hout=16, Wout=16, x3h=True)

@@ -41,10 +41,10 @@ def conv_s2(n_img=224, C=128, H=128, x6=True):
     print(f'conv3x3 s2{" x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
 
 
-def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False):
+def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
-    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv3_bf16(w) if bf16 else ops.pack_conv_oihw(w)
+    wp = ops.pack_conv3_x3h(w) if x3h else ops.pack_conv3_x6(w) if x6 else ops.pack_conv3_bf16(w) if bf16 else ops.pack_conv_oihw(w)
     b = torch.randn(C, device=dev)
     out = torch.empty_like(x)
     prol = None
@@ -54,9 +54,9 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False):
         prol = (m, s, torch.zeros(C, device=dev))
     M = n_img * H * H
     ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
-                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16))
+                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16, x3h=x3h))
     fl = 2.0 * M * C * C * 9
-    print(f'conv3x3{" x6" if x6 else " bf16" if bf16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
+    print(f'conv3x3{" x3h" if x3h else " x6" if x6 else " bf16" if bf16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 
 
 def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
@@ -135,7 +135,9 @@ ALL = dict(clockprobe=clockprobe,
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
-           convx6_512=lambda: conv(224, 512, 8, x6=True))
+           convx6_512=lambda: conv(224, 512, 8, x6=True),
+           convx3h=lambda: conv(x3h=True), convx3h_64=lambda: conv(56, 128, 64, x3h=True), convx3h_256=lambda: conv(56, 256, 32, x3h=True),
+           convx3h_512=lambda: conv(224, 512, 8, x3h=True), convx3h_nopro=lambda: conv(pro=False, x3h=True))
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

@@ -1,0 +1,357 @@
+// fp32-EQUIVALENT 3x3 convolution on the fp16 matrix pipe ("x3h": 3-term split-fp16 products with a scaled low part), gfx950.
+// Same halo-tile structure, pixel permutation, pipeline and epilogue as conv3_halo_x6.hip with HALF the matrix instructions:
+// every fp32 operand is split into two fp16 pieces with the low piece carried at 2^11 times its value,
+//     x = h + l' * 2^-11,   h = rne_f16(x),   l' = rne_f16((x - h) * 2^11)          (x - h is exact in fp32, the scaling is exact)
+// so that l' has h's magnitude and keeps all 11 bits (an unscaled low piece falls into fp16's subnormals for |x| < 0.125), and
+//     a * b  ~=  ah*bh  +  2^-11 * (al'*bh + ah*bl')                               (each f16 x f16 product is exact in fp32)
+// with the cross terms in their own fp32 accumulator (accx), combined once in the epilogue.  The dropped term al*bl is below 2^-22
+// of the product; the weights are pre-scaled at pack time by a power of two S so that max|w| lands in [2^13, 2^14) (their h and l'
+// pieces are then exact to 2^-22 for every weight within 2^-17 of the largest) and the result is divided by S in the epilogue.
+// Error vs fp64 relative to sum|a*b| (K = 1152, unit-scale activations): 4e-9 representation error, i.e. the fp32 accumulation
+// (3e-8, identical to the native f32 MFMA and to x6) dominates — tests/test_hip_x3h.py.
+// RANGE (why x6 stays the arithmetic of the training backward): activations must satisfy |x| < 65504 (fp16 overflow), and an
+// activation is carried to 2^-22 relative only while |x| >= ~6e-5 (below that h is subnormal and the absolute error floors at
+// ~1.5e-11); GroupNorm-normalised inputs and the VQGAN's residual stream are O(1e-2 .. 1e2), gradients are not.
+// Data path as in conv3_halo_x6.hip: fp32 activations in HBM, GroupNorm-apply(+swish) prologue in exact fp32, split ONCE per patch
+// element when the patch is parked in LDS as [pixel][plane h|l'][32 ch] f16 (144-byte pixel stride = 9 x 16 B: conflict-free
+// ds_read_b128 for every tap shift); two weight planes streamed L2 -> VGPR in a register ring (341 B per MFMA vs 256 for x6:
+// the kernel is bound by that stream, so the gain over x6 is ~1.5x, not 2x).
+// Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,197,249) with
+// GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
+#include "halo_common.h"
+
+#ifndef VF_X3H_BD
+#define VF_X3H_BD 2       // weight fragments are fetched this many stages ahead (register ring of BD + 1)
+#endif
+#ifndef VF_X3H_AD
+#define VF_X3H_AD 1       // LDS activation fragments are read this many stages ahead (0 or 1)
+#endif
+#ifndef VF_X3H_STORE
+#define VF_X3H_STORE 0
+#endif
+#ifndef VF_X3H_SB
+#define VF_X3H_SB 1       // sched_barrier(0) at every stage boundary (pins the prefetch distance)
+#endif
+#ifndef VF_X3H_PRECISE_SWISH
+#define VF_X3H_PRECISE_SWISH 0
+#endif
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 32;
+constexpr int P_LDB = 144;          // bytes per patch pixel in LDS: 2 planes x 64 B + 16 B pad
+constexpr int TH = 8, TW = 16;
+constexpr int BN = 128;
+constexpr int PLANE_BYTES = 2 * BN * 16;      // one (k-step, plane): [half(2)][n(128)][8 f16] = 4 KB
+constexpr int KS_BYTES = 2 * PLANE_BYTES;     // one k-step of 16 channels: 2 planes
+constexpr int TAP_BYTES = 2 * KS_BYTES;       // one (chunk, tap, n-block) weight tile: 16 KB
+constexpr int TAIL_BYTES = 16;                // behind the planes: float 1/S, uint32 max|w| bits (pack scratch)
+
+template <bool UP2, bool PAIR = false>
+struct Geo {
+    static constexpr int PH = UP2 ? (TH / 2 + 2) : (TH + 2);
+    static constexpr int PW = PAIR ? 20 : (UP2 ? (TW / 2 + 2) : (TW + 2));
+    static constexpr int NPIX = PH * PW;
+    static constexpr int SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int BUF = (NPIX + 1) * P_LDB;             // bytes, +1 dummy pixel
+};
+
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * 2048.f);
+}
+
+template <bool UP2, bool PRO, bool SWISH, bool PAIR = false>
+__global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p) {
+    using G = Geo<UP2, PAIR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][BUF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    int bid = blockIdx.x;
+    const int nblk = bid % nb; bid /= nb;
+    int tx = 0, ty = 0, img;
+    if (PAIR) { img = bid * 2; }
+    else { tx = bid % tilesX; bid /= tilesX; ty = bid % tilesY; img = bid / tilesY; }
+    const int n_img_total = p.M / (p.Hout * p.Wout);
+    const int img1 = PAIR ? min(img + 1, n_img_total - 1) : img;   // 2nd image of the pair (= the 1st when n_img is odd: same values rewritten)
+    const int pair_pix = (img1 - img) * p.Hin * p.Win;            // pixel offset of the 2nd image
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int sy0 = UP2 ? (y0 / 2 - 1) : (y0 - 1);
+    const int sx0 = UP2 ? (x0 / 2 - 1) : (x0 - 1);
+
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / CK;
+    const int last_stage = nchunks * 9 - 1;
+
+    const int c4 = tid & 7;
+    int s_off[G::SLOTS];
+    bool s_ok[G::SLOTS];
+    int s_sel[G::SLOTS];
+    int s_lds[G::SLOTS];
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int pixc = pix < G::NPIX ? pix : G::NPIX;
+        const int pr = pixc / G::PW, pc0 = pixc - pr * G::PW;
+        const int sel = PAIR ? (pc0 >= 10) : 0;
+        const int pc = pc0 - 10 * sel;
+        s_sel[q] = sel;
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
+        s_ok[q] = ok;
+        s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        s_lds[q] = pixc * P_LDB + c4 * 8;
+    }
+
+    f32x4 preg[G::SLOTS];
+    f32x4 pmean, pscale, pbeta, pmean1, pscale1;
+    auto patch_load = [&](int chunk) {
+        const float* xc = X + chunk * CK;
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+        if (PRO) {
+            pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
+            pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
+            if (PAIR) {
+                pmean1 = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+                pscale1 = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img1 * p.Cin + chunk * CK + c4 * 4);
+            }
+        }
+    };
+    auto patch_store_slot = [&](int buf, int q) {
+        unsigned char* dst = smem_h + buf * G::BUF + s_lds[q];
+        f16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = preg[q][e];
+            if (PRO) {
+                const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
+                const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
+                t = (t - mu) * sc + pbeta[e];
+                if (SWISH) t = VF_X3H_PRECISE_SWISH ? vf_swish(t) : vf_swish_1ulp(t);
+            }
+            _Float16 h, l;
+            split2(s_ok[q] ? t : 0.f, h, l);
+            oh[e] = h; ol[e] = l;
+        }
+        *reinterpret_cast<f16x4*>(dst) = oh;
+        *reinterpret_cast<f16x4*>(dst + 64) = ol;
+    };
+
+    const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
+    int a_base[2], a_r[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int a0 = wave_m * 4 + mi * 2 + trow;
+        a_r[mi] = a0;
+        const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
+        a_base[mi] = (a0 * G::PW + tcol) * P_LDB + half * 16;
+    }
+
+    // packed weights [chunk][tap][nblk][ks(2)][plane(2)][half(2)][n(128)][8 f16]; one pipeline stage = one (tap, ks)
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    // software pipeline over stages g = chunk*18 + tap*2 + ks: B two stages ahead in a 3-deep register ring (an L2 hit
+    // costs about one stage of MFMA time, so one-ahead left the matrix pipe waiting), A one stage ahead (2-deep)
+    constexpr int BD = VF_X3H_BD, RING = BD + 1, AD = VF_X3H_AD;
+    static_assert(18 % RING == 0 && (AD == 0 || AD == 1), "ring indices must repeat per chunk");
+    f16x8 bring[RING][2][2];
+    f16x8 aring[2][2][2];
+    const int last_g = nchunks * 18 - 1;
+    auto b_load = [&](f16x8 (&dst)[2][2], int g) {
+        g = min(g, last_g);
+        const unsigned char* src = Wb + (size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES + b_lane;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+    };
+    auto a_load = [&](f16x8 (&dst)[2][2], const unsigned char* patch, int s) {
+        const int tap = s >> 1, ks = s & 1;
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            int aoff;
+            if (UP2) {
+                const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
+                aoff = (pr * G::PW + pc) * P_LDB + half * 16;
+            } else {
+                aoff = a_base[mi] + (dy * G::PW + dx) * P_LDB;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(patch + aoff + pl * 64 + ks * 32);
+        }
+    };
+
+    f32x16 acc[2][2], accx[2][2];          // main products ah*bh; cross products (al*2^11)*bh + ah*(bl*2^11)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    patch_load(0);
+#pragma unroll
+    for (int g = 0; g < BD; ++g) b_load(bring[g], g);
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
+        patch_load(min(chunk + 1, nchunks - 1));
+        if (AD) a_load(aring[0], patch, 0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
+            if (AD == 0) a_load(aring[s & 1], patch, s);
+            else if (VF_X3H_SB != 3 && s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+            if (VF_X3H_SB == 2) __builtin_amdgcn_sched_barrier(0);      // loads are issued before this stage's MFMAs
+            // three partial products (plane 0 = h, 1 = l * 2^11): the two cross terms into accx, the main term into acc
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (VF_X3H_SB == 3 && t == 1) {                         // LDS fragments of the next stage issued mid-stage
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (t == 0) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][1], bring[s % RING][0][j], accx[mi][j], 0, 0, 0);
+                        else if (t == 1) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][0], bring[s % RING][1][j], accx[mi][j], 0, 0, 0);
+                        else acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][0], bring[s % RING][0][j], acc[mi][j], 0, 0, 0);
+                    }
+            }
+            // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
+            if (VF_X3H_SB == 1 || VF_X3H_SB == 3) __builtin_amdgcn_sched_barrier(0);
+            if ((s & 1) && (s >> 1) >= VF_X3H_STORE && (s >> 1) - VF_X3H_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X3H_STORE);
+            if (VF_X3H_SB == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // out = (acc + accx * 2^-11) / S with S the power-of-two weight scale stored behind the packed planes
+    const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nchunks * 9 * nb * TAP_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
+    vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+}
+
+
+// max |w| over the tensor as the bits of a non-negative float (monotone as unsigned)
+__global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    m = vf_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// OIHW fp32 -> two fragment-packed f16 planes of w * S, S = 2^(13 - floor(log2 max|w|)); thread 0 leaves 1/S in the tail
+__global__ void pack_conv_x3h_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks,
+                                     unsigned char* __restrict__ tail) {
+    const float amax = __uint_as_float(*reinterpret_cast<const unsigned*>(tail + 4));
+    const int ex = amax > 0.f ? ilogbf(amax) : 13;
+    const float S = ldexpf(1.f, 13 - ex);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(tail) = ldexpf(1.f, ex - 13);
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        long long t = idx >> 3;
+        const int nl = (int)(t % BN); t /= BN;
+        const int half = (int)(t & 1);
+        const int ks = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int nblk = (int)(t % nb); t /= nb;
+        const int tap = (int)(t % 9);
+        const int chunk = (int)(t / 9);
+        const int c = chunk * CK + ks * 16 + half * 8 + e;
+        const int n = nblk * BN + nl;
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * 9 + tap] * S;
+        _Float16 h, l;
+        split2(v, h, l);
+        const size_t base = ((((size_t)(chunk * 9 + tap) * nb + nblk) * 2 + ks) * 2) * (2 * BN * 8) + ((size_t)half * BN + nl) * 8 + e;
+        dst[base] = h;
+        dst[base + 2 * BN * 8] = l;
+    }
+}
+
+template <bool UP2, bool PRO, bool SWISH, bool PAIR>
+int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
+    using G = Geo<UP2, PAIR>;
+    const size_t smem = (size_t)2 * G::BUF;
+    const int n_img = a.M / (a.Hout * a.Wout);
+    const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)
+                                  : (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv3_halo_x3h_kernel<UP2, PRO, SWISH, PAIR>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
+    return vf_last_status();
+}
+
+template <bool UP2, bool PAIR>
+int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
+    if (!a.pro_mean) return launch_halo<UP2, false, false, PAIR>(a, s);
+    return a.pro_swish ? launch_halo<UP2, true, true, PAIR>(a, s) : launch_halo<UP2, true, false, PAIR>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vf_conv3_x3h_packed_elems(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)((Cin + CK - 1) / CK) * 9 * ((Cout + BN - 1) / BN) * CK * BN * 2 + TAIL_BYTES / 2;
+}
+
+int vf_conv3_x3h_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream) {
+    if (!w_oihw || !dst || Cin <= 0 || Cout <= 0) return VF_ERR_BAD_ARG;
+    const int nb = (Cout + BN - 1) / BN, nchunks = (Cin + CK - 1) / CK;
+    const long long total = (long long)nchunks * 9 * nb * CK * BN;
+    unsigned char* tail = reinterpret_cast<unsigned char*>(dst) + (size_t)total * 2 * sizeof(_Float16);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(tail, 0, TAIL_BYTES, s) != hipSuccess) return vf_last_status();
+    const long long nw = (long long)Cout * Cin * 9;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0, s, w_oihw, nw,
+                       reinterpret_cast<unsigned*>(tail + 4));
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_x3h_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, (_Float16*)dst, Cin, Cout, nb, nchunks, tail);
+    return vf_last_status();
+}
+
+int vf_conv3_halo_x3h(const vf_igemm_args* args, void* stream) {
+    if (!args) return VF_ERR_BAD_ARG;
+    const vf_igemm_args& a = *args;
+    if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
+    if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
+    const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
+    if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0))) return VF_ERR_UNSUPPORTED;
+    if (a.Hin <= 0 || a.Win <= 0 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_S1 && (a.Hout != a.Hin || a.Wout != a.Win)) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_UP2 && (a.Hout != a.Hin * 2 || a.Wout != a.Win * 2)) return VF_ERR_BAD_ARG;
+    if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+    if ((a.pro_mean || a.pro_scale || a.pro_beta) && !(a.pro_mean && a.pro_scale && a.pro_beta)) return VF_ERR_BAD_ARG;
+    if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+    if (int st = vf_halo_gn_check(a)) return st;
+    hipStream_t s = (hipStream_t)stream;
+    if (pair) return dispatch_pro<false, true>(a, s);
+    return (a.mode == VF_MODE_CONV3_UP2) ? dispatch_pro<true, false>(a, s) : dispatch_pro<false, false>(a, s);
+}
+
+}  // extern "C"

@@ -117,6 +117,22 @@ def pack_conv3_x6(w_oihw):
     return out
 
 
+def pack_conv3_x3h(w_oihw):
+    """OIHW fp32 3x3 weight -> two fragment-packed f16 planes of w * S (S a power of two, 1/S stored behind them) for
+    vf_conv3_halo_x3h"""
+    lib = _lib.load()
+    w = _f32(w_oihw).contiguous()
+    cout, cin = w.shape[:2]
+    out = torch.empty(int(lib.vf_conv3_x3h_packed_elems(cin, cout)), dtype=torch.float16, device=w.device)
+    check(lib.vf_conv3_x3h_pack(_p(w), _p(out), cin, cout, _stream()), 'vf_conv3_x3h_pack')
+    return out
+
+
+def conv3_x3h_supported(mode, Cin, Cout, Hout, Wout):
+    """shape rules of vf_conv3_halo_x3h (stride 1 and upsample only)"""
+    return mode in (MODE_CONV3_S1, MODE_CONV3_UP2) and conv3_x6_supported(mode, Cin, Cout, Hout, Wout)
+
+
 def pack_dense_kn_x6(w):
     """Conv1D weight [nx][nf] -> 3-plane split packing for vf_gemm_x6"""
     lib = _lib.load()
@@ -158,7 +174,8 @@ def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
 
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
-          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0):
+          lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
+          x3h=False):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
@@ -192,6 +209,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     for t in (x, out, bias, res):
         if t is not None:
             _f32(t)
+    if x3h:                                   # w_packed = pack_conv3_x3h: the 3-product split-fp16 kernel (3x3 s1 / up2 only)
+        _chk(w_packed, torch.float16, 'w_packed')
+        check(lib.vf_conv3_halo_x3h(ctypes.byref(a), _stream()), 'vf_conv3_halo_x3h')
+        return out
     if x6:
         _chk(w_packed, torch.bfloat16, 'w_packed')
         if mode == MODE_GEMM:

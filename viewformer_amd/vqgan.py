@@ -25,7 +25,7 @@ _IGNORED = re.compile(r'(perceptual_loss\..*)|(loss\..*)')     # vqgan_th.py:322
 
 
 class _Conv:
-    __slots__ = ('wp', 'wp16', 'wp6', 'bias', 'cin', 'cout', 'k', 'w_raw')
+    __slots__ = ('wp', 'wp16', 'wp6', 'wp3h', 'bias', 'cin', 'cout', 'k', 'w_raw')
 
 
 class VQGAN:
@@ -33,13 +33,15 @@ class VQGAN:
                  decoder_precision: str = 'f32', conv_arith: str = 'x6'):
         """``conv_arith`` picks how the fp32 3x3 convolutions are evaluated: 'f32' = native f32 MFMA, 'x6' = the
         fp32-EQUIVALENT six-term split-bf16 kernel (same error against fp64 as the f32 MFMA, ~1.6x faster; see
-        csrc/conv3_halo_x6.hip).  Both give bit-identical token indices on the reference's golden vectors.
+        csrc/conv3_halo_x6.hip), 'x3h' = x6 everywhere except the stride-1 / upsample 3x3 convolutions, which run the
+        three-term split-fp16 kernel (csrc/conv3_halo_x3h.hip: same error against fp64 for activations in fp16's range, half the
+        matrix instructions).  All give bit-identical token indices on the reference's golden vectors.
         ``decoder_precision='bf16'`` runs the DECODER's wide 3x3 convolutions and 1x1 projections on the bf16-MFMA
         arm (decoded pixels are tolerance-bounded in the north star); the encoder and the codebook lookup are always
         exact fp32 so token indices stay bit-exact."""
         self.config = config or VQGANConfig()
         assert data_format in ('NCHW', 'NHWC')
-        assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6')
+        assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6', 'x3h')
         self.decoder_precision = decoder_precision
         self.conv_arith = conv_arith
         self.data_format = data_format
@@ -128,9 +130,13 @@ class VQGAN:
             c.wp = ops.pack_conv_oihw(w) if c.cin % 32 == 0 else None
             c.wp16 = None
             c.wp6 = None
-            if self.conv_arith == 'x6' and c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
+            c.wp3h = None
+            split = self.conv_arith in ('x6', 'x3h')
+            if split and c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                 c.wp6 = ops.pack_conv3_x6(w)
-            elif self.conv_arith == 'x6' and c.k == 1 and c.cin % 64 == 0 and c.cout >= 64:
+                if self.conv_arith == 'x3h':
+                    c.wp3h = ops.pack_conv3_x3h(w)
+            elif split and c.k == 1 and c.cin % 64 == 0 and c.cout >= 64:
                 c.wp6 = ops.pack_dense_nk_x6(w.reshape(c.cout, c.cin))
             if self.decoder_precision == 'bf16' and (name.startswith('decoder.') or name == 'post_quant_conv'):
                 if c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
@@ -155,7 +161,7 @@ class VQGAN:
                 # fused q|k|v projection: one [C][3C] GEMM
                 w = torch.cat([dev_t(f'{name}.{p}.weight').reshape(c, c) for p in ('q', 'k', 'v')], 0)   # [3C][C] (out,in)
                 b = torch.cat([dev_t(f'{name}.{p}.bias') for p in ('q', 'k', 'v')], 0)
-                self._qkv[name] = (ops.pack_dense_nk_x6(w) if self.conv_arith == 'x6' and c % 64 == 0 else ops.pack_dense_nk(w), b)
+                self._qkv[name] = (ops.pack_dense_nk_x6(w) if self.conv_arith in ('x6', 'x3h') and c % 64 == 0 else ops.pack_dense_nk(w), b)
                 conv(name + '.proj_out')
             elif kind == 'norm_swish':
                 norm(name)
@@ -181,15 +187,16 @@ class VQGAN:
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
         bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
-        x6 = (not bf16 and c.wp6 is not None and ops.conv3_x6_supported(mode, c.cin, c.cout, Ho, Wo)
+        x3h = not bf16 and c.wp3h is not None and ops.conv3_x3h_supported(mode, c.cin, c.cout, Ho, Wo)
+        x6 = (not bf16 and not x3h and c.wp6 is not None and ops.conv3_x6_supported(mode, c.cin, c.cout, Ho, Wo)
               and not (mode == ops.MODE_CONV3_S2PAD and pro is not None))
         # the halo kernels also emit the GroupNorm partial statistics of what they store, so the consumer's norm
         # (_gn) only runs the tiny finalize instead of re-reading the activation
         part = None
-        if (bf16 or x6) and self.fuse_gn_stats and c.cout in (128, 256, 512, 1024):
+        if (bf16 or x6 or x3h) and self.fuse_gn_stats and c.cout in (128, 256, 512, 1024):
             part = ops.new_gn_part(n, Ho, Wo, x.device)
-        ops.igemm(x, c.wp16 if bf16 else c.wp6 if x6 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res, mode=mode,
-                  pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6, gn_part=part)
+        ops.igemm(x, c.wp16 if bf16 else c.wp3h if x3h else c.wp6 if x6 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res,
+                  mode=mode, pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6, x3h=x3h, gn_part=part)
         self._stats_of = (out, part) if part is not None else None
         return out, Ho, Wo
 
