@@ -33,7 +33,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (me
 HBM_PEAK_GBS = 8000.0
 
 
-X3H_PMC_KB = (None, None)          # (FETCH_SIZE, WRITE_SIZE) of the x3h conv's PMC pass, filled in once profiled
+X3H_PMC_KB = (532920e3, 501760e3)   # FETCH_SIZE, WRITE_SIZE of the x3h conv (profiles/r1_conv_x3h_pmc.txt), 56-image launch
 
 
 def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h'):

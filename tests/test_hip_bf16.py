@@ -37,7 +37,8 @@ def _rel(a, b):
     return ((a.detach().cpu().double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-@pytest.mark.parametrize('M,K,N', [(128, 64, 128), (300, 128, 64), (448, 768, 2304), (1000, 3072, 768), (70, 256, 1024)])
+@pytest.mark.parametrize('M,K,N', [(128, 64, 128), (300, 128, 64), (448, 768, 2304), (1000, 3072, 768), (70, 256, 1024),
+                                   (1024, 64, 128), (1500, 768, 200), (2048 + 37, 192, 768)])      # M >= 1024: the 256-row-tile kernel
 def test_gemm_bf16_layout_and_epilogue(dev, M, K, N):
     from viewformer_amd import ops
     x, w, b, r = _rand((M, K), 1), _rand((K, N), 2, 0.1), _rand((N,), 3), _rand((M, N), 4)

@@ -41,11 +41,16 @@ def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
         sc = scale_c.double().cpu().view(n, cin, 1, 1)
         a = (a - mu) * sc + beta.double().view(1, cin, 1, 1)
         a = a * torch.sigmoid(a)
-    m, Ho = {'s1': (ops.MODE_CONV3_S1, H), 'up': (ops.MODE_CONV3_UP2, 2 * H)}[mode]
+    m, Ho = {'s1': (ops.MODE_CONV3_S1, H), 'up': (ops.MODE_CONV3_UP2, 2 * H), 's2': (ops.MODE_CONV3_S2PAD, H // 2)}[mode]
     if mode == 'up':
         a = F.interpolate(a, scale_factor=2.0, mode='nearest')
-    ref = F.conv2d(a, w.double(), None, padding=1)
-    mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1)
+    if mode == 's2':                                      # Downsample: pad (right, bottom) + stride 2
+        ap = F.pad(a, (0, 1, 0, 1))
+        ref = F.conv2d(ap, w.double(), None, stride=2)
+        mag = F.conv2d(ap.abs(), w.double().abs(), None, stride=2)
+    else:
+        ref = F.conv2d(a, w.double(), None, padding=1)
+        mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1)
     res = _rand((n * Ho * Ho, cout), 16) * wscale * xscale * 10
     ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + b.double() + res.double()
     mag = mag.permute(0, 2, 3, 1).reshape(-1, cout) + b.double().abs() + res.double().abs()
@@ -60,7 +65,8 @@ def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
 
 @pytest.mark.parametrize('mode,cin,cout,H,pro', [('s1', 128, 128, 16, True), ('s1', 64, 256, 32, False), ('up', 128, 128, 8, False),
                                                   ('up', 32, 128, 16, True), ('s1', 128, 128, 64, True),
-                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True)])
+                                                  ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True),
+                                                  ('s2', 128, 128, 32, False), ('s2', 64, 256, 64, False), ('s2', 32, 128, 32, False)])
 def test_conv3_halo_x3h_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
     (mx3, rms3), (mx32, rms32) = _run(dev, mode, cin, cout, H, pro)
     print(f'{mode} {cin}->{cout} @{H} pro={pro}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
@@ -101,11 +107,11 @@ def test_x3h_fused_groupnorm_partials(dev):
         assert ((scale_f - scale_s).abs() / scale_s.abs()).max().item() < 5e-6
 
 
-def test_x3h_refuses_stride_2(dev):
+def test_x3h_refuses_unsupported_shapes(dev):
     from viewformer_amd import ops
-    assert not ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 16, 16)
-    x = torch.zeros((2 * 32 * 32, 128), device=dev)
-    out = torch.empty((2 * 16 * 16, 128), device=dev)
-    with pytest.raises(ops._lib.VfError):
-        ops.igemm(x, ops.pack_conv3_x3h(torch.zeros((128, 128, 3, 3), device=dev)), 2 * 16 * 16, 128, 128, out,
-                  mode=ops.MODE_CONV3_S2PAD, Hin=32, Win=32, Hout=16, Wout=16, x3h=True)
+    assert not ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 8, 8)       # 16x16 -> 8x8 stays on the generic kernel
+    x = torch.zeros((2 * 16 * 12, 64), device=dev)
+    out = torch.empty((2 * 16 * 12, 128), device=dev)
+    with pytest.raises(ops._lib.VfError):        # W % 16 != 0: refused, never rerouted
+        ops.igemm(x, ops.pack_conv3_x3h(torch.zeros((128, 64, 3, 3), device=dev)), 2 * 16 * 12, 64, 128, out, mode=ops.MODE_CONV3_S1,
+                  Hin=16, Win=12, Hout=16, Wout=12, x3h=True)

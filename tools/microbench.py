@@ -29,16 +29,17 @@ def timeit(fn, iters=8, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def conv_s2(n_img=224, C=128, H=128, x6=True):
+def conv_s2(n_img=224, C=128, H=128, x6=True, x3h=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
-    wp = ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
+    x6 = x6 and not x3h
+    wp = ops.pack_conv3_x3h(w) if x3h else ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
     b = torch.randn(C, device=dev)
     Ho = H // 2
     M = n_img * Ho * Ho
     out = torch.empty(M, C, device=dev)
-    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, mode=ops.MODE_CONV3_S2PAD, Hin=H, Win=H, Hout=Ho, Wout=Ho, x6=x6))
-    print(f'conv3x3 s2{" x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
+    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, mode=ops.MODE_CONV3_S2PAD, Hin=H, Win=H, Hout=Ho, Wout=Ho, x6=x6, x3h=x3h))
+    print(f'conv3x3 s2{" x3h" if x3h else " x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
 
 
 def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
@@ -127,10 +128,11 @@ ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True),
-           convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x6_256=lambda: conv_s2(224, 256, 32),
+           convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
-           gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
+           gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
+           gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),

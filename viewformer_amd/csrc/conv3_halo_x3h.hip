@@ -256,6 +256,149 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 }
 
 
+// ---- Downsample (pad right/bottom + 3x3 stride 2, vqgan_th.py:45-49), the x3h form of conv3_s2_x6_kernel ---------------------------
+// One 8x16 OUTPUT tile needs a 17x33 input patch; it is staged 16 channels at a time (112-byte pixel stride) in ONE LDS
+// buffer (44 KB), stored by column parity
+// ([row][even columns | odd columns]) so that the stride-2 reads of a tap are again 16 consecutive LDS pixels.
+// Weights: the same packing as the stride-1 kernel (a 16-channel chunk is one k-step of a packed 32-channel chunk).
+constexpr int S2_PH = 2 * TH + 1, S2_PW = 2 * TW + 1;        // 17 x 33
+constexpr int S2_NPIX = S2_PH * S2_PW;                       // 561
+constexpr int S2_LDB = 80;                                   // 2 planes x 32 B + 16 B pad = 5 x 16 B
+constexpr int S2_SLOTS = (S2_NPIX * 4 + 255) / 256;          // float4 staging slots per thread (9)
+constexpr int S2_BUF = (S2_NPIX + 1) * S2_LDB;
+
+__global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [S2_BUF]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    int bid = blockIdx.x;
+    const int nblk = bid % nb; bid /= nb;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int img = bid / tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / 16;
+
+    // staging slots: thread -> (patch pixel, float4 column of the 16-channel chunk)
+    const int c4 = tid & 3;
+    int s_off[S2_SLOTS], s_lds[S2_SLOTS];
+    bool s_ok[S2_SLOTS];
+#pragma unroll
+    for (int q = 0; q < S2_SLOTS; ++q) {
+        const int pix = (tid >> 2) + 64 * q;
+        const int pixc = pix < S2_NPIX ? pix : 0;
+        const int pr = pixc / S2_PW, pc = pixc - pr * S2_PW;
+        const int sy = 2 * y0 + pr, sx = 2 * x0 + pc;
+        const bool ok = pix < S2_NPIX && sy < p.Hin && sx < p.Win;            // right / bottom zero padding
+        s_ok[q] = ok;
+        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        const int slot = pix < S2_NPIX ? pr * S2_PW + (pc & 1) * (TW + 1) + (pc >> 1) : S2_NPIX;   // parity-major row
+        s_lds[q] = slot * S2_LDB + c4 * 8;
+    }
+    f32x4 preg[S2_SLOTS];
+    auto patch_load = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < S2_SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + chunk * 16 + s_off[q]);
+    };
+    auto patch_park = [&]() {
+#pragma unroll
+        for (int q = 0; q < S2_SLOTS; ++q) {
+            f16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 h, l;
+                split2(s_ok[q] ? preg[q][e] : 0.f, h, l);
+                oh[e] = h; ol[e] = l;
+            }
+            unsigned char* dst = smem_h + s_lds[q];
+            *reinterpret_cast<f16x4*>(dst) = oh;
+            *reinterpret_cast<f16x4*>(dst + 32) = ol;
+        }
+    };
+
+    const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
+    int a_base[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a_base[mi] = (2 * (wave_m * 4 + mi * 2 + trow) * S2_PW + tpx) * S2_LDB + half * 16;
+
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    const int last_g = nchunks * 9 - 1;
+    f16x8 bring[3][2][2];
+    f16x8 aring[2][2][2];
+    auto b_load = [&](f16x8 (&dst)[2][2], int g) {            // g = chunk16 * 9 + tap
+        g = min(g, last_g);
+        const int c = g / 9, tap = g - c * 9;
+        const unsigned char* src = Wb + (size_t)((c >> 1) * 9 + tap) * tap_stride + (c & 1) * KS_BYTES + b_lane;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+    };
+    auto a_load = [&](f16x8 (&dst)[2][2], int tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const int off = (dy * S2_PW + (dx & 1) * (TW + 1) + (dx >> 1)) * S2_LDB;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(smem_h + a_base[mi] + off + pl * 32);
+    };
+
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    patch_load(0);
+    b_load(bring[0], 0);
+    b_load(bring[1], 1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();                                        // every wave is done reading the previous chunk
+        patch_park();
+        patch_load(min(chunk + 1, nchunks - 1));
+        __syncthreads();
+        a_load(aring[0], 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            b_load(bring[(t + 2) % 3], chunk * 9 + t + 2);
+            if (t + 1 < 9) a_load(aring[(t + 1) & 1], t + 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][1], bring[t % 3][0][j], accx[mi][j], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % 3][1][j], accx[mi][j], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % 3][0][j], acc[mi][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)(p.Cin / CK) * 9 * nb * TAP_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
+    vf_halo_epilogue<false>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+}
+
+
 // max |w| over the tensor as the bits of a non-negative float (monotone as unsigned)
 __global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -339,6 +482,16 @@ int vf_conv3_halo_x3h(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
+    if (a.mode == VF_MODE_CONV3_S2PAD) {
+        if (a.Cout % BN != 0 || a.Cin % CK != 0 || a.Hout % TH != 0 || a.Wout % TW != 0 || a.pro_mean) return VF_ERR_UNSUPPORTED;
+        if (a.Hin != a.Hout * 2 || a.Win != a.Wout * 2 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
+        if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+        if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
+        if (int st = vf_halo_gn_check(a)) return st;
+        const long long blocks = (long long)(a.M / (a.Hout * a.Wout)) * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+        hipLaunchKernelGGL(conv3_s2_x3h_kernel, dim3((unsigned)blocks), dim3(256), (size_t)S2_BUF, (hipStream_t)stream, a);
+        return vf_last_status();
+    }
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
     const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
     if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0))) return VF_ERR_UNSUPPORTED;

@@ -279,6 +279,144 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     }
 }
 
+// 256x128 workgroup tile (wave tile 128 x 64 = 4x2 MFMA tiles, 128 accumulator registers): every B fragment streamed from L2 feeds
+// four MFMAs and every A fragment read from LDS feeds two, i.e. 0.75 operand fragments per MFMA instead of 1.0, and the fp32 A tile
+// (global float4 -> bf16 -> LDS) is amortised over twice the columns' worth of work per wave: 1.75 memory instructions per MFMA
+// instead of 3.0 for the 128x128 kernels above, which is what bounds them (they sit at 420-470 TFLOP/s with the matrix pipe < 25 %
+// busy).  K in stages of 32 (two k-steps, 16 MFMAs per wave per barrier), double-buffered LDS (2 x 20 KB), B one stage ahead in a
+// 2-deep register ring.  Needs K % 64 == 0 (even stage count) and takes the same bf16 packing.
+constexpr int WM = 256;
+constexpr int W_CK = 32;
+constexpr int W_LDB = 80;                   // bytes per A row in LDS (64 data + 16 pad: 5 x 16 B, conflict-free ds_read_b128)
+constexpr int W_ABYTES = WM * W_LDB;        // 20480
+
+template <int EPI, bool HAS_RES, bool FULL>
+__device__ __forceinline__ void w256_store(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int mtile, int nblk, int wave_m, int wave_n,
+                                           int half, int l31) {
+    const long long ldc = p.ldc, ldr = p.ldr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nblk * 128 + wave_n * 64 + j * 32 + l31;
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+        const int nn = nok ? n : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m0 = mtile * 256 + wave_m * 128 + i * 32 + 4 * half;
+            float* o = p.out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
+            const float* rs = HAS_RES ? p.res + (size_t)(m0 < p.M ? m0 : 0) * ldr + nn : nullptr;
+            if (FULL) {
+                auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
+                auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
+                vf_store_tile<EPI, HAS_RES>(acc[i][j], bias, o, rs, oo, ro);
+            } else {
+                vf_store_tile_ragged<EPI, HAS_RES>(acc[i][j], bias, o, rs, ldc, ldr, nok ? p.M - m0 : 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_w256_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                    // [2][W_ABYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = (p.Cout + BN - 1) / BN;
+    const int nblk = blockIdx.x % nb;
+    const int mtile = blockIdx.x / nb;
+    const float* __restrict__ X = p.x;
+    const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * B_BYTES;
+    const size_t chunk_stride = (size_t)nb * B_BYTES;          // one 64-deep packed chunk = two stages
+    const int nstages = p.Cin / W_CK;
+
+    const int a_c4 = tid & 7, a_r0 = tid >> 3;                 // float4 column of the 32-wide stage, rows a_r0 + 32 q
+    const float* arow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int m = mtile * WM + a_r0 + 32 * q;
+        m = m < p.M ? m : p.M - 1;
+        arow[q] = X + (size_t)m * p.lda + a_c4 * 4;
+    }
+    f32x4 areg[8];
+    auto a_fetch = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const f32x4*>(arow[q] + s * W_CK);
+    };
+    auto a_park = [&](int buf, int q) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[q][e];
+        *reinterpret_cast<bf16x4*>(As + buf * W_ABYTES + (a_r0 + 32 * q) * W_LDB + a_c4 * 8) = v;
+    };
+    const unsigned b_lane = (unsigned)((half * BN + wave_n * 64 + l31) * 16);
+    bf16x8 bring[2][2][2];             // [stage parity][ks][j]
+    auto b_load = [&](bf16x8 (&dst)[2][2], int s) {
+        s = min(s, nstages - 1);
+        const unsigned char* src = Wp + (size_t)(s >> 1) * chunk_stride + (unsigned)((s & 1) * 2 * (2 * BN * 16)) + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[ks][j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    a_fetch(0);
+    b_load(bring[0], 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a_park(0, q);
+    __syncthreads();
+
+    auto stage_body = [&](int s, bf16x8 (&bcur)[2][2], bf16x8 (&bnext)[2][2]) {
+        const unsigned char* a_src = As + (s & 1) * W_ABYTES + (wave_m * 128 + l31) * W_LDB + half * 16;
+        a_fetch(min(s + 1, nstages - 1));
+        b_load(bnext, s + 1);
+        bf16x8 a[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(a_src + i * 32 * W_LDB + ks * 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], bcur[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a_park((s + 1) & 1, ks * 4 + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    for (int s = 0; s < nstages; s += 2) {          // nstages is even (Cin % 64 == 0)
+        stage_body(s, bring[0], bring[1]);
+        stage_body(s + 1, bring[1], bring[0]);
+    }
+
+    const bool full = (mtile * WM + WM <= p.M) && (nblk * BN + BN <= p.Cout);
+    const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
+    // one fully unrolled instantiation per (epilogue, residual, full/ragged): the accumulators stay in registers
+    if (full) {
+        if (gelu) { if (p.res) w256_store<1, true, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<1, false, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+        else { if (p.res) w256_store<0, true, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<0, false, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+    } else {
+        if (gelu) { if (p.res) w256_store<1, true, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<1, false, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+        else { if (p.res) w256_store<0, true, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<0, false, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+    }
+}
+
 // pack fp32 [K][N] (strided) -> bf16 fragment-major [K/64][nb][ks(4)][half(2)][n(128)][8]
 __global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N, long long sk,
                                  long long sn, int nb, int nchunks, long long src_bstride, long long dst_bstride) {
@@ -341,6 +479,14 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
 #ifndef VF_GEMM_BF16_DIRECT
 #define VF_GEMM_BF16_DIRECT 1
 #endif
+#ifndef VF_GEMM_BF16_W256
+#define VF_GEMM_BF16_W256 1
+#endif
+    if (VF_GEMM_BF16_W256 && a.batch <= 1 && a.M >= 4 * WM) {       // Cin % 64 == 0 holds (checked above)
+        const int mt2 = (a.M + WM - 1) / WM;
+        hipLaunchKernelGGL(gemm_bf16_w256_kernel, dim3((unsigned)(mt2 * nb)), dim3(256), (size_t)2 * W_ABYTES, (hipStream_t)stream, a);
+        return vf_last_status();
+    }
     if (VF_GEMM_BF16_DIRECT && a.Cin % (2 * CK) == 0 && a.batch <= 1) {
         hipLaunchKernelGGL(gemm_bf16_direct_kernel, dim3((unsigned)(mt * nb)), dim3(256), (size_t)2 * A_BYTES, (hipStream_t)stream, a);
         return vf_last_status();

@@ -129,8 +129,8 @@ def pack_conv3_x3h(w_oihw):
 
 
 def conv3_x3h_supported(mode, Cin, Cout, Hout, Wout):
-    """shape rules of vf_conv3_halo_x3h (stride 1 and upsample only)"""
-    return mode in (MODE_CONV3_S1, MODE_CONV3_UP2) and conv3_x6_supported(mode, Cin, Cout, Hout, Wout)
+    """shape rules of vf_conv3_halo_x3h (the same as the x6 kernel's)"""
+    return conv3_x6_supported(mode, Cin, Cout, Hout, Wout)
 
 
 def pack_dense_kn_x6(w):

@@ -187,7 +187,8 @@ class VQGAN:
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
         bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
-        x3h = not bf16 and c.wp3h is not None and ops.conv3_x3h_supported(mode, c.cin, c.cout, Ho, Wo)
+        x3h = (not bf16 and c.wp3h is not None and ops.conv3_x3h_supported(mode, c.cin, c.cout, Ho, Wo)
+               and not (mode == ops.MODE_CONV3_S2PAD and pro is not None))
         x6 = (not bf16 and not x3h and c.wp6 is not None and ops.conv3_x6_supported(mode, c.cin, c.cout, Ho, Wo)
               and not (mode == ops.MODE_CONV3_S2PAD and pro is not None))
         # the halo kernels also emit the GroupNorm partial statistics of what they store, so the consumer's norm
