@@ -480,7 +480,7 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
 #define VF_GEMM_BF16_DIRECT 1
 #endif
 #ifndef VF_GEMM_BF16_W256
-#define VF_GEMM_BF16_W256 1
+#define VF_GEMM_BF16_W256 0       // A/B on MI355X: 433-450 TF vs 440-458 for the 128x128 direct kernel at M = 65536 (ties) -> opt-in
 #endif
     if (VF_GEMM_BF16_W256 && a.batch <= 1 && a.M >= 4 * WM) {       // Cin % 64 == 0 holds (checked above)
         const int mt2 = (a.M + WM - 1) / WM;
