@@ -98,16 +98,19 @@ class LPIPS:
 
     # ------------------------------------------------------------------ convolutions (frozen weights: packed once per kernel family)
     @staticmethod
-    def _conv(x, w, bias, cache, n, H, W):
+    def _conv(x, w, bias, cache, n, H, W, activations=False):
+        """``activations``: forward features (x3h applies); gradients stay on x6 (no range condition)"""
         cout, cin = w.shape[0], w.shape[1]
         if ops.conv3_small_cout_supported(ops.MODE_CONV3_S1, cin, cout, H, W):
             return ops.conv3_small_cout(x, w, bias, n, H, W, cin, cout)
         out = torch.empty((n * H * W, cout), dtype=torch.float32, device=x.device)
         x6 = ops.conv3_x6_supported(ops.MODE_CONV3_S1, cin, cout, H, W)
-        key = 'x6' if x6 else 'f32'
+        x3h = x6 and activations
+        key = 'x3h' if x3h else 'x6' if x6 else 'f32'
         if key not in cache:
-            cache[key] = ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
-        ops.igemm(x, cache[key], n * H * W, cin, cout, out, bias=bias, mode=ops.MODE_CONV3_S1, Hin=H, Win=W, Hout=H, Wout=W, x6=x6)
+            cache[key] = ops.pack_conv3_x3h(w) if x3h else ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w)
+        ops.igemm(x, cache[key], n * H * W, cin, cout, out, bias=bias, mode=ops.MODE_CONV3_S1, Hin=H, Win=W, Hout=H, Wout=W,
+                  x6=x6 and not x3h, x3h=x3h)
         return out
 
     def _features(self, img, n, H, W):
@@ -126,7 +129,7 @@ class LPIPS:
                 if c.cin == 3:
                     x = ops.conv_in(x.view(n, h, w, 3), c.w, c.b, n, h, w, c.cout).view(n * h * w, c.cout)
                 else:
-                    x = self._conv(x, c.w, c.b, c.fw, n, h, w)
+                    x = self._conv(x, c.w, c.b, c.fw, n, h, w, activations=True)
                 T.relu_(x)
                 so.append(x)
             outs.append(so)

@@ -117,8 +117,10 @@ class VQGANTrainer:
         return out
 
     # ------------------------------------------------------------------ convolution forward / backward
-    def _conv_launch(self, x, w, bias, n, H, W, mode, res=None):
-        """forward conv (3x3 modes or 1x1) of NHWC rows x with OIHW weight w; picks the fp32-equivalent kernels when the shape allows"""
+    def _conv_launch(self, x, w, bias, n, H, W, mode, res=None, activations=False):
+        """forward conv (3x3 modes or 1x1) of NHWC rows x with OIHW weight w; picks the fp32-equivalent kernels when the shape allows.
+        ``activations=True``: x is a forward activation (O(1) magnitudes) -> the three-product split-fp16 kernel (x3h) where it
+        applies; gradients (dX convolutions, ~1e-6) stay on x6, which has no range condition"""
         cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
         if k == 1:
             M = n * H * W
@@ -134,12 +136,13 @@ class VQGANTrainer:
             return ops.conv3_small_cout(x, w, bias, n, H, W, cin, cout), Ho, Wo
         out = torch.empty((n * Ho * Wo, cout), dtype=torch.float32, device=x.device)
         x6 = ops.conv3_x6_supported(mode, cin, cout, Ho, Wo)
-        ops.igemm(x, ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w), n * Ho * Wo, cin, cout, out, bias=bias, res=res, mode=mode,
-                  Hin=H, Win=W, Hout=Ho, Wout=Wo, x6=x6)
+        x3h = x6 and activations
+        ops.igemm(x, ops.pack_conv3_x3h(w) if x3h else ops.pack_conv3_x6(w) if x6 else ops.pack_conv_oihw(w), n * Ho * Wo, cin, cout, out,
+                  bias=bias, res=res, mode=mode, Hin=H, Win=W, Hout=Ho, Wout=Wo, x6=x6 and not x3h, x3h=x3h)
         return out, Ho, Wo
 
     def _conv_fw(self, name, x, n, H, W, mode=ops.MODE_CONV3_S1, res=None):
-        y, Ho, Wo = self._conv_launch(x, self.p(name + '.weight'), self.p(name + '.bias'), n, H, W, mode, res=res)
+        y, Ho, Wo = self._conv_launch(x, self.p(name + '.weight'), self.p(name + '.bias'), n, H, W, mode, res=res, activations=True)
         return y, (name, x, n, H, W, Ho, Wo, mode)
 
     def _conv_bw(self, ctx, dy, need_dx=True):
