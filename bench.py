@@ -52,7 +52,8 @@ def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: st
     # convolutions on bf16 MFMA (tolerance-bounded logits / pixels) — the split the north star specifies
     arm = 'bf16' if precision == 'mixed' else 'f32'
     vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith).load_state_dict(vsd).to(dev)
-    tr = MIGT(mcfg, precision=arm).load_state_dict(msd).to(dev)
+    # the transformer's fp32 dense layers follow the convolutions' arithmetic (x3h: LayerNorm / GELU / attention outputs are O(1))
+    tr = MIGT(mcfg, precision=arm, dense_arith=conv_arith).load_state_dict(msd).to(dev)
     return vq, tr, (vcfg, vsd, mcfg, msd)
 
 

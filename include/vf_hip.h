@@ -235,6 +235,11 @@ int vf_conv3_halo_x6(const vf_igemm_args* args /* host */, void* stream);
 size_t vf_conv3_x3h_packed_elems(int Cin, int Cout);      /* number of f16 elements (2 planes + the 1/S tail) */
 int vf_conv3_x3h_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
 int vf_conv3_halo_x3h(const vf_igemm_args* args /* host */, void* stream);
+/* dense / 1x1 sibling (csrc/gemm_x3h.hip): same contract as vf_gemm_x6 incl. split-K (reserved0), half the matrix instructions;
+ * forward activations only (range condition above) */
+size_t vf_gemm_x3h_packed_elems(int K, int N);
+int vf_gemm_x3h_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, void* stream);
+int vf_gemm_x3h(const vf_igemm_args* args /* host */, void* stream);
 /* dense / 1x1 sibling: VF_MODE_GEMM, Cin % 64 == 0, batch == 1, optional GroupNorm(+swish) prologue, bias / exact-erf GELU /
  * residual epilogue.  Replaces the same call sites as vf_igemm_f32's GEMM mode (Conv1D.call migt.py:89-96,
  * SharedEmbeddings._linear :51-56, the 1x1 convolutions of vqgan_th.py:72-76,99-118,332-333).

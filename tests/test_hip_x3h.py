@@ -115,3 +115,50 @@ def test_x3h_refuses_unsupported_shapes(dev):
     with pytest.raises(ops._lib.VfError):        # W % 16 != 0: refused, never rerouted
         ops.igemm(x, ops.pack_conv3_x3h(torch.zeros((128, 64, 3, 3), device=dev)), 2 * 16 * 12, 64, 128, out, mode=ops.MODE_CONV3_S1,
                   Hin=16, Win=12, Hout=16, Wout=12, x3h=True)
+
+
+@pytest.mark.parametrize('M,K,N,epi,res', [(128, 64, 128, 0, False), (300, 128, 64, 0, True), (448, 768, 2304, 0, False),
+                                           (1000, 3072, 768, 0, True), (70, 256, 1024, 1, True), (513, 768, 3072, 1, False)])
+def test_gemm_x3h_is_fp32_equivalent(dev, M, K, N, epi, res):
+    from viewformer_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((K, N), 2, 0.1), _rand((N,), 3), _rand((M, N), 4)
+    pre = x.double() @ w.double() + b.double()
+    ref = F.gelu(pre) if epi else pre
+    mag = x.double().abs() @ w.double().abs() + b.double().abs()
+    if res:
+        ref, mag = ref + r.double(), mag + r.double().abs()
+    kw = dict(bias=b.to(dev), res=r.to(dev) if res else None, epilogue=ops.EPI_GELU if epi else ops.EPI_NONE)
+    o3, o32, o3t = (torch.empty((M, N), device=dev) for _ in range(3))
+    ops.igemm(x.to(dev), ops.pack_dense_kn_x3h(w.to(dev)), M, K, N, o3, x3h=True, **kw)
+    ops.igemm(x.to(dev), ops.pack_dense_nk_x3h(w.t().contiguous().to(dev)), M, K, N, o3t, x3h=True, **kw)
+    ops.igemm(x.to(dev), ops.pack_dense_kn(w.to(dev)), M, K, N, o32, **kw)
+    assert torch.equal(o3, o3t)                       # both packings describe the same matrix
+    (mx3, rms3), (mx32, rms32) = _err(o3, ref, mag), _err(o32, ref, mag)
+    print(f'gemm {M}x{K}x{N} epi={epi}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
+    assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
+    with pytest.raises(ops._lib.VfError):             # K % 64 != 0 is refused, never rerouted
+        ops.igemm(x[:, :32].contiguous().to(dev), ops.pack_dense_kn_x3h(w[:32].contiguous().to(dev)), M, 32, N, o3, x3h=True)
+
+
+def test_migt_logits_x3h_vs_native_f32(dev):
+    """full-size transformer: the x3h dense arm is as close to the fp64 oracle as the native f32-MFMA arm"""
+    from oracle import migt_oracle as mg
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    cfg = MIGTConfig(sequence_size=4, localization_weight='1', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=0)
+    g = np.random.Generator(np.random.PCG64(17))
+    B, S = 2, 4
+    codes = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 6)
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], 1024)], 1)
+    ref = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)['logits'][:, -1]
+    errs = {}
+    for arith in ('f32', 'x3h'):
+        m = MIGT(cfg, dense_arith=arith).load_state_dict(sd).to(dev)
+        lg, _ = m.generate_and_localize(codes.to(dev), cams.to(dev))
+        errs[arith] = ((lg.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    print(f'logit error vs fp64 (relative to max |logit|): native f32 {errs["f32"]:.2e}, x3h {errs["x3h"]:.2e}')
+    assert errs['x3h'] < 1e-4 and errs['x3h'] < 2.0 * errs['f32'] + 1e-6

@@ -152,7 +152,7 @@ def test_backward_kernels_against_autograd(dev):
     assert _err(zc, z.double() * 3.0 / max(z.double().norm().item(), 3.0)) < 1e-6
 
 
-def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothing=0.0, **extra):
+def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothing=0.0, dense_arith='x3h', **extra):
     from viewformer_amd.config import MIGTConfig
     from viewformer_amd.migt import MIGT
     from viewformer_amd.train import MIGTTrainer
@@ -167,15 +167,16 @@ def _setup(loc, dev, seed=1, B=2, S=4, clip=0.0, precision='f32', label_smoothin
     tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, t, t)))
     _, cams = synthetic_scene_batch(B, S, 8, seed)
     poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])       # process_batch, train_transformer.py:31-64
-    model = MIGT(cfg, precision=precision).load_state_dict(sd).to(dev)
+    model = MIGT(cfg, precision=precision, dense_arith=dense_arith).load_state_dict(sd).to(dev)
     return cfg, sd, tokens, poses, MIGTTrainer(model, warmup_steps=4)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('loc', [False, True])
-def test_train_step_gradients_match_autograd(dev, loc):
+@pytest.mark.parametrize('loc,arith', [(False, 'x3h'), (True, 'x3h'), (True, 'x6'), (True, 'f32')])
+def test_train_step_gradients_match_autograd(dev, loc, arith):
+    """dense_arith: x3h = forward GEMMs on the split-fp16 kernel, backward on x6 (the default); x6 / f32 = everything on that arm"""
     from oracle import train_oracle as to
-    cfg, sd, tokens, poses, tr = _setup(loc, dev)
+    cfg, sd, tokens, poses, tr = _setup(loc, dev, dense_arith=arith)
     tr.step_count = 3                       # a non-trivial localization weight
     metrics = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     grads, ref_metrics = to.gradients(sd, cfg, poses, tokens, step=3)

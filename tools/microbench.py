@@ -63,10 +63,10 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
 def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
     x = torch.randn(M, K, device=dev)
     w = torch.randn(K, N, device=dev) * 0.02
-    wp = {'f32': ops.pack_dense_kn, 'x6': ops.pack_dense_kn_x6, 'bf16': ops.pack_dense_kn_bf16}[arith](w)
+    wp = {'f32': ops.pack_dense_kn, 'x6': ops.pack_dense_kn_x6, 'bf16': ops.pack_dense_kn_bf16, 'x3h': ops.pack_dense_kn_x3h}[arith](w)
     b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
-    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi, x6=arith == 'x6', bf16=arith == 'bf16'))
+    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi, x6=arith == 'x6', bf16=arith == 'bf16', x3h=arith == 'x3h'))
     print(f'gemm[{arith}] {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
 
 
@@ -129,6 +129,8 @@ ALL = dict(clockprobe=clockprobe,
            convbf16_256=lambda: conv(32, 256, 32, bf16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),
+           gemmx3h=lambda: gemm(16384, 768, 2304, arith='x3h'), gemmx3h_gelu=lambda: gemm(16384, 768, 3072, 1, 'x3h'),
+           gemmx3h_k3072=lambda: gemm(16384, 3072, 768, arith='x3h'),
            gemmx6=lambda: gemm(16384, 768, 2304, arith='x6'), gemmx6_gelu=lambda: gemm(16384, 768, 3072, 1, 'x6'),
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),

@@ -100,6 +100,9 @@ EXPORTS = {
     'vf_conv3_x3h_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_conv3_x3h_pack': (c_int, [P, P, c_int, c_int, P]),
     'vf_conv3_halo_x3h': (c_int, [POINTER(VfIgemmArgs), P]),
+    'vf_gemm_x3h_packed_elems': (c_size_t, [c_int, c_int]),
+    'vf_gemm_x3h_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, P]),
+    'vf_gemm_x3h': (c_int, [POINTER(VfIgemmArgs), P]),
     'vf_gemm_x6_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_gemm_x6_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, P]),
     'vf_gemm_x6': (c_int, [POINTER(VfIgemmArgs), P]),

@@ -29,14 +29,16 @@ class _Dense:
 
 class MIGT:
     def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True, precision: str = 'f32',
-                 dense_arith: str = 'x6'):
+                 dense_arith: str = 'x3h'):
         """``dense_arith`` picks how the fp32 dense layers are evaluated (precision='f32' only): 'f32' = native f32 MFMA,
-        'x6' = the fp32-EQUIVALENT six-term split-bf16 GEMM (csrc/gemm_x6.hip: same error against fp64, ~1.8x faster).
+        'x6' = the fp32-EQUIVALENT six-term split-bf16 GEMM (csrc/gemm_x6.hip: same error against fp64, ~1.8x faster),
+        'x3h' = the three-term split-fp16 GEMM (csrc/gemm_x3h.hip: same error for activations in fp16's range — LayerNorm / GELU /
+        attention outputs are —, half the matrix instructions; attention stays x6).
         ``precision='bf16'``: the dense layers (c_attn, c_proj, MLP, LM head, pose MLPs) run on the bf16-MFMA arm with
         fp32 activations / accumulation, and the attention contractions (q.k^T, p.v) on bf16 MFMA with an fp32 softmax;
         LayerNorm, the residual stream and the arg-max stay fp32.
         Logits are then tolerance-bounded (tests state the bound), as the north star allows for the transformer."""
-        assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6')
+        assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6', 'x3h')
         self.precision = precision
         self.dense_arith = dense_arith
         self.config = config or MIGTConfig()
@@ -114,8 +116,9 @@ class MIGT:
             d.w_raw = w
             d.wp = ops.pack_dense_kn(w) if (pack and d.k % 32 == 0) else None
             d.wp16 = ops.pack_dense_kn_bf16(w) if (self.precision == 'bf16' and pack and d.k % 64 == 0 and d.n >= 64) else None
-            d.wp6 = (ops.pack_dense_kn_x6(w) if (d.wp16 is None and self.dense_arith == 'x6' and pack and d.k % 64 == 0 and d.n >= 64)
-                     else None)
+            split = d.wp16 is None and self.dense_arith in ('x6', 'x3h') and pack and d.k % 64 == 0 and d.n >= 64
+            # the packing's dtype names the arithmetic: bf16 planes = x6, f16 planes = x3h (_dense_launch)
+            d.wp6 = (ops.pack_dense_kn_x3h(w) if self.dense_arith == 'x3h' else ops.pack_dense_kn_x6(w)) if split else None
             self._dense[name] = d
 
         def ln(name):
@@ -126,8 +129,8 @@ class MIGT:
         self._lm_head = ops.pack_dense_nk(self._wte, n_rows=c.n_embeddings)    # logits sliced to n_embeddings (migt.py:417)
         self._lm_head16 = (ops.pack_dense_nk_bf16(self._wte, n_rows=c.n_embeddings)
                            if self.precision == 'bf16' and c.d_model % 64 == 0 else None)
-        self._lm_head6 = (ops.pack_dense_nk_x6(self._wte, n_rows=c.n_embeddings)
-                          if self._lm_head16 is None and self.dense_arith == 'x6' and c.d_model % 64 == 0 else None)
+        self._lm_head6 = ((ops.pack_dense_nk_x3h if self.dense_arith == 'x3h' else ops.pack_dense_nk_x6)(self._wte, n_rows=c.n_embeddings)
+                          if self._lm_head16 is None and self.dense_arith in ('x6', 'x3h') and c.d_model % 64 == 0 else None)
         dense('pose_embedding.c_fc', pack=False)
         dense('pose_embedding.c_proj')
         dense('pose_criterion.pose_classifier.c_fc')
@@ -150,16 +153,18 @@ class MIGT:
     def _dense_launch(x, d, M, out, res=None, epilogue=ops.EPI_NONE):
         """one dense layer on the arm its packing selects: bf16 (tolerance arm) > x6 (fp32-equivalent) > native f32 MFMA"""
         bf16, x6 = d.wp16 is not None, d.wp16 is None and getattr(d, 'wp6', None) is not None
+        x3h = x6 and d.wp6.dtype == torch.float16
         ops.igemm(x, d.wp16 if bf16 else d.wp6 if x6 else d.wp, M, d.k, d.n, out, bias=d.bias, res=res, epilogue=epilogue,
-                  bf16=bf16, x6=x6)
+                  bf16=bf16, x6=x6 and not x3h, x3h=x3h)
 
     def _lm(self, h, M, out):
         """tied LM head: logits = h @ wte[:n_embeddings]^T  (SharedEmbeddings._linear, migt.py:51-56,417)"""
         c = self.config
         bf16 = getattr(self, '_lm_head16', None) is not None
         x6 = not bf16 and getattr(self, '_lm_head6', None) is not None
+        x3h = x6 and self._lm_head6.dtype == torch.float16
         ops.igemm(h, self._lm_head16 if bf16 else self._lm_head6 if x6 else self._lm_head, M, c.d_model, c.n_embeddings, out,
-                  bf16=bf16, x6=x6)
+                  bf16=bf16, x6=x6 and not x3h, x3h=x3h)
         return out
 
     def _pose_embed(self, poses):
@@ -194,7 +199,7 @@ class MIGT:
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
                                  3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16',
-                                 x6=self.precision == 'f32' and self.dense_arith == 'x6')
+                                 x6=self.precision == 'f32' and self.dense_arith in ('x6', 'x3h'))
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)

@@ -154,6 +154,27 @@ def pack_dense_nk_x6(w, n_rows=None):
     return out
 
 
+def pack_dense_kn_x3h(w):
+    """Conv1D weight [nx][nf] -> two-plane split-fp16 packing (w * S, 1/S behind the planes) for vf_gemm_x3h"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    k, n = w.shape
+    out = torch.empty(int(lib.vf_gemm_x3h_packed_elems(k, n)), dtype=torch.float16, device=w.device)
+    check(lib.vf_gemm_x3h_pack(_p(w), _p(out), k, n, n, 1, _stream()), 'vf_gemm_x3h_pack')
+    return out
+
+
+def pack_dense_nk_x3h(w, n_rows=None):
+    """transposed weight [N][K] (x @ W^T; tied LM head, 1x1 conv [Cout][Cin]) -> two-plane split-fp16 packing"""
+    lib = _lib.load()
+    w = _f32(w).contiguous()
+    n, k = w.shape
+    n = n if n_rows is None else n_rows
+    out = torch.empty(int(lib.vf_gemm_x3h_packed_elems(k, n)), dtype=torch.float16, device=w.device)
+    check(lib.vf_gemm_x3h_pack(_p(w), _p(out), k, n, 1, k, _stream()), 'vf_gemm_x3h_pack')
+    return out
+
+
 def gemm_x6_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulate=True):
     """dst[M][Cout] (+)= x @ W with the reduction split over ``splits`` workgroup groups (deterministic: slabs summed in order);
     for GEMMs whose output has too few 128x128 tiles to fill the chip but a long reduction (the training step's dW)"""
@@ -209,9 +230,12 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     for t in (x, out, bias, res):
         if t is not None:
             _f32(t)
-    if x3h:                                   # w_packed = pack_conv3_x3h: the 3-product split-fp16 kernel (3x3 s1 / up2 only)
+    if x3h:                                   # w_packed = pack_conv3_x3h / pack_dense_*_x3h: the 3-product split-fp16 kernels
         _chk(w_packed, torch.float16, 'w_packed')
-        check(lib.vf_conv3_halo_x3h(ctypes.byref(a), _stream()), 'vf_conv3_halo_x3h')
+        if mode == MODE_GEMM:
+            check(lib.vf_gemm_x3h(ctypes.byref(a), _stream()), 'vf_gemm_x3h')
+        else:
+            check(lib.vf_conv3_halo_x3h(ctypes.byref(a), _stream()), 'vf_conv3_halo_x3h')
         return out
     if x6:
         _chk(w_packed, torch.bfloat16, 'w_packed')

@@ -162,7 +162,8 @@ class MIGTTrainer:
         m, c = self.model, self.cfg
         nE, d = c.n_embeddings, c.d_model
         bf16 = m.precision == 'bf16'          # the reference trains with --fp16 (mixed_float16): bf16 MFMA, fp32 master weights
-        x6 = m.dense_arith == 'x6' and not bf16
+        x6 = m.dense_arith in ('x6', 'x3h') and not bf16
+        x3h = m.dense_arith == 'x3h'          # forward activations only; dX / dW (gradient magnitudes) stay on x6
         self.wpT6 = getattr(self, 'wpT6', {})
         self.wpT16 = getattr(self, 'wpT16', {})
         m._lm_head16 = None
@@ -177,7 +178,7 @@ class MIGTTrainer:
                 dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
                 self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
             if x6 and dn.wp is not None and dn.k % 64 == 0 and dn.n % 64 == 0:
-                dn.wp6 = ops.pack_dense_kn_x6(dn.w_raw)
+                dn.wp6 = ops.pack_dense_kn_x3h(dn.w_raw) if x3h else ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
         self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
