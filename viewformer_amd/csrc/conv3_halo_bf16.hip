@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
 
     const int nb = p.Cout / BN;
     const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
-    int bid = blockIdx.x;
+    int bid = (int)vf_xcd_bid();                        // XCD-contiguous logical workgroup id (vf_common.h)
     const int nblk = bid % nb; bid /= nb;
     int tx = 0, ty = 0, img;
     if (PAIR) { img = bid * 2; }

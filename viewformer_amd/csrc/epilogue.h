@@ -25,6 +25,7 @@ __device__ __forceinline__ void vf_store_tile(const f32x16& acc, float bias, flo
         for (int r = 0; r < 16; ++r) {
             float t = acc[r] + bias;
             if (EPI == 1) t = vf_gelu_erf(t);
+            if (EPI == 2) t = vf_gelu_erf_fast(t);
             v[r] = t + rr[r];
         }
     } else {
@@ -32,6 +33,7 @@ __device__ __forceinline__ void vf_store_tile(const f32x16& acc, float bias, flo
         for (int r = 0; r < 16; ++r) {
             float t = acc[r] + bias;
             if (EPI == 1) t = vf_gelu_erf(t);
+            if (EPI == 2) t = vf_gelu_erf_fast(t);
             v[r] = t;
         }
     }
@@ -53,6 +55,7 @@ __device__ __forceinline__ void vf_store_tile_ragged(const f32x16& acc, float bi
         const int row = (r & 3) + 8 * (r >> 2);
         float t = acc[r] + bias;
         if (EPI == 1) t = vf_gelu_erf(t);
+        if (EPI == 2) t = vf_gelu_erf_fast(t);
         if (HAS_RES) t += res[(long long)(row < rows_left ? row : 0) * ldr];
         v[r] = t;
     }

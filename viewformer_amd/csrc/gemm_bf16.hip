@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vf_igemm_args p) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const int bz = blockIdx.z;
     const float* __restrict__ X = p.x + (size_t)bz * p.stride_x;
     const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)bz * p.stride_w * 2
@@ -132,15 +133,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vf_igemm_args p) {
                 auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
                 auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
                 if (gelu) {
-                    if (Res) vf_store_tile<1, true>(acc[i][j], bias, o, rs, oo, ro);
-                    else vf_store_tile<1, false>(acc[i][j], bias, o, rs, oo, ro);
+                    if (Res) vf_store_tile<2, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<2, false>(acc[i][j], bias, o, rs, oo, ro);
                 } else {
                     if (Res) vf_store_tile<0, true>(acc[i][j], bias, o, rs, oo, ro);
                     else vf_store_tile<0, false>(acc[i][j], bias, o, rs, oo, ro);
                 }
             } else if (gelu) {
-                if (Res) vf_store_tile_ragged<1, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
-                else vf_store_tile_ragged<1, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                if (Res) vf_store_tile_ragged<2, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<2, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
             } else {
                 if (Res) vf_store_tile_ragged<0, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
                 else vf_store_tile_ragged<0, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
@@ -164,8 +165,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const float* __restrict__ X = p.x;
     const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * B_BYTES;
     const size_t stage_stride = (size_t)nb * B_BYTES;
@@ -262,15 +264,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                 auto oo = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldc; };
                 auto ro = [&](int r) { return (long long)((r & 3) + 8 * (r >> 2)) * ldr; };
                 if (gelu) {
-                    if (Res) vf_store_tile<1, true>(acc[i][j], bias, o, rs, oo, ro);
-                    else vf_store_tile<1, false>(acc[i][j], bias, o, rs, oo, ro);
+                    if (Res) vf_store_tile<2, true>(acc[i][j], bias, o, rs, oo, ro);
+                    else vf_store_tile<2, false>(acc[i][j], bias, o, rs, oo, ro);
                 } else {
                     if (Res) vf_store_tile<0, true>(acc[i][j], bias, o, rs, oo, ro);
                     else vf_store_tile<0, false>(acc[i][j], bias, o, rs, oo, ro);
                 }
             } else if (gelu) {
-                if (Res) vf_store_tile_ragged<1, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
-                else vf_store_tile_ragged<1, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                if (Res) vf_store_tile_ragged<2, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
+                else vf_store_tile_ragged<2, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
             } else {
                 if (Res) vf_store_tile_ragged<0, true>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
                 else vf_store_tile_ragged<0, false>(acc[i][j], bias, o, rs, ldc, ldr, rows_left);
@@ -327,8 +329,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_w256_kernel(vf_igemm_args p)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const float* __restrict__ X = p.x;
     const unsigned char* __restrict__ Wp = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * B_BYTES;
     const size_t chunk_stride = (size_t)nb * B_BYTES;          // one 64-deep packed chunk = two stages
@@ -409,10 +412,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_w256_kernel(vf_igemm_args p)
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
     // one fully unrolled instantiation per (epilogue, residual, full/ragged): the accumulators stay in registers
     if (full) {
-        if (gelu) { if (p.res) w256_store<1, true, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<1, false, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+        if (gelu) { if (p.res) w256_store<2, true, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<2, false, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
         else { if (p.res) w256_store<0, true, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<0, false, true>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
     } else {
-        if (gelu) { if (p.res) w256_store<1, true, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<1, false, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
+        if (gelu) { if (p.res) w256_store<2, true, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<2, false, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
         else { if (p.res) w256_store<0, true, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); else w256_store<0, false, false>(p, acc, mtile, nblk, wave_m, wave_n, half, l31); }
     }
 }

@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const float* __restrict__ X = p.x;
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * CHUNK_BYTES;
     const size_t chunk_stride = (size_t)nb * CHUNK_BYTES;

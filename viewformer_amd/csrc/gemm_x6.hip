@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(vf_igemm_args p) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const float* __restrict__ X = p.x;
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * CHUNK_BYTES;
     const size_t chunk_stride = (size_t)nb * CHUNK_BYTES;
@@ -267,8 +268,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(wgrad_args p) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const int tpt = p.Cin / BM;                      // row tiles per tap
     const int tap = mtile / tpt, cblk = mtile % tpt; // tap == 9: the ones row (bias gradient)
     const int ky = tap / 3, kx = tap % 3;

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(vf_igemm_args p) {
     const int l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
-    const int nblk = blockIdx.x % nb;
-    const int mtile = blockIdx.x / nb;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id (vf_common.h)
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
     const int bz = blockIdx.z;
 
     const float* __restrict__ X = p.x + (size_t)bz * p.stride_x;

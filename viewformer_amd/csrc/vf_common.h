@@ -42,6 +42,21 @@ __device__ __forceinline__ float vf_gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+__device__ __forceinline__ float vf_gelu_erf_fast(float v) {
+    // erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on the hardware exp2 / rcp: ~16 VALU instead
+    // of ~45 for erff.  Only for the bf16 tolerance arm, whose consumers round this value to 8 mantissa bits anyway (the erff
+    // epilogue was the bound of the c_fc GEMM there: 64 outputs per thread against 192 MFMAs per wave).
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = __builtin_fmaf(-p * t, e, 1.0f);
+    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+}
+
 __device__ __forceinline__ float vf_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -69,6 +84,24 @@ __host__ __device__ __forceinline__ uint32_t vf_dropout_hash(uint32_t seed, uint
     h *= 0xD3A2646Cu;
     h ^= h >> 16;
     return h;
+}
+
+// XCD-aware workgroup order.  The dispatcher hands consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2, so
+// the workgroups that share an operand tile (the column blocks of one GEMM row tile, the output-channel blocks and halo
+// neighbours of one conv tile) would land in 8 different L2s and the tile would be fetched from HBM 8 times (measured on the bf16
+// GEMM 65536x768x3072: FETCH_SIZE 1.65 GB for 0.25 GB of operands).  Remap so that every XCD works on one contiguous range of
+// logical ids: XCD x owns the physical ids {x + 8 i}; it gets the logical range starting at x*q + min(x, r), q = n / 8, r = n % 8.
+#ifndef VF_XCD_SWIZZLE
+#define VF_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ unsigned vf_xcd_bid() {
+#if VF_XCD_SWIZZLE
+    const unsigned n = gridDim.x, b = blockIdx.x;
+    const unsigned q = n >> 3, r = n & 7u, x = b & 7u, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+#else
+    return blockIdx.x;
+#endif
 }
 
 // shared host helper (defined in igemm_f32.hip): pack [taps][K][N] into the fragment-major B layout
