@@ -97,6 +97,14 @@ int vf_igemm_f32(const vf_igemm_args* args /* host */, void* stream);
  * (already-normalised NHWC float input, the Torch-convention entry). */
 int vf_conv_in_u8_f32(const uint8_t* img_u8, const float* img_f32, const float* w_oihw, const float* bias,
                       float* out, int n_img, int H, int W, int Cout, void* stream);
+/* the same entry on the fp16 matrix pipe with the x3h arithmetic (csrc/conv_in_x3h.hip: fp32-equivalent, inputs in [-1, 1]); the
+ * weights are packed once (vf_conv_in_x3h_pack, vf_conv_in_x3h_packed_elems(Cout) f16 elements); optional fused GroupNorm partial
+ * statistics of the output as in vf_conv3_halo_x6 (gn_part / gn_slots, NULL / 0 = off).  Needs H % 8 == 0, W % 16 == 0,
+ * Cout % 128 == 0 (VF_ERR_UNSUPPORTED otherwise: call vf_conv_in_u8_f32). */
+size_t vf_conv_in_x3h_packed_elems(int Cout);
+int vf_conv_in_x3h_pack(const float* w_oihw, void* dst, int Cout, void* stream);
+int vf_conv_in_x3h(const uint8_t* img_u8, const float* img_f32, const void* w_packed, const float* bias, float* out, float* gn_part,
+                   int gn_slots, int n_img, int H, int W, int Cout, void* stream);
 
 /* 3x3 stride-1 pad-1 convolution to 1..4 output channels (the decoder's conv_out, vqgan_th.py:285-289,316-318) with
  * the GroupNorm-apply(+swish) of the preceding norm_out (:313-315) fused; plain fp32 fmaf arithmetic.  x NHWC

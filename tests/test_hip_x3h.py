@@ -162,3 +162,30 @@ def test_migt_logits_x3h_vs_native_f32(dev):
         errs[arith] = ((lg.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     print(f'logit error vs fp64 (relative to max |logit|): native f32 {errs["f32"]:.2e}, x3h {errs["x3h"]:.2e}')
     assert errs['x3h'] < 1e-4 and errs['x3h'] < 2.0 * errs['f32'] + 1e-6
+
+
+@pytest.mark.parametrize('u8', [True, False])
+def test_conv_in_x3h_matches_fp64_and_the_valu_kernel(dev, u8):
+    """encoder.conv_in on the matrix pipe: error vs fp64 no larger than the VALU fp32 kernel's; fused GroupNorm partials"""
+    from viewformer_amd import ops
+    n, H, W, C = 3, 32, 48, 128
+    g = np.random.Generator(np.random.PCG64(5))
+    img = torch.from_numpy(g.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8))
+    xf = (img.float() * torch.tensor(1.0 / 255)) * 2 - 1
+    w, b = _rand((C, 3, 3, 3), 21, 0.2), _rand((C,), 22)
+    ref = F.conv2d(xf.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    mag = F.conv2d(xf.double().abs().permute(0, 3, 1, 2), w.double().abs(), b.double().abs(), padding=1).permute(0, 2, 3, 1)
+    src = img.to(dev) if u8 else xf.to(dev)
+    part = ops.new_gn_part(n, H, W, dev)
+    part.fill_(float('nan'))
+    o3 = ops.conv_in(src, w.to(dev), b.to(dev), n, H, W, C, wp3h=ops.pack_conv_in_x3h(w.to(dev)), gn_part=part)
+    ov = ops.conv_in(src, w.to(dev), b.to(dev), n, H, W, C)
+    (mx3, rms3), (mxv, rmsv) = _err(o3, ref, mag), _err(ov, ref, mag)
+    print(f'conv_in u8={u8}: x3h max {mx3:.2e} rms {rms3:.2e} | VALU fp32 max {mxv:.2e} rms {rmsv:.2e}')
+    assert mx3 < 4e-7 and rms3 < 1.25 * rmsv + 1e-9
+    gamma = (_rand((C,), 23) * 0.3 + 1).to(dev)
+    mean_f, scale_f = ops.groupnorm_finalize(part, gamma, n, H * W, C)
+    mean_s, scale_s = ops.groupnorm_stats(o3.view(n * H * W, C), gamma, n, H * W, C)
+    assert (mean_f - mean_s).abs().max().item() < 2e-6 * (1 + mean_s.abs().max().item())
+    assert ((scale_f - scale_s).abs() / scale_s.abs()).max().item() < 5e-6
+    assert not ops.conv_in_x3h_supported(20, 48, 128)

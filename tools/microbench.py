@@ -96,13 +96,14 @@ def gn(n_img=56, C=128, HW=16384):
     print(f'gn_stats {n_img}x{HW}x{C}: {ms:.4f} ms  {x.numel() * 4 / ms / 1e6:.1f} GB/s')
 
 
-def convin(n_img=224, H=128, C=128):
+def convin(n_img=224, H=128, C=128, x3h=False):
     img = torch.randint(0, 256, (n_img, H, H, 3), dtype=torch.uint8, device=dev)
     w = torch.randn(C, 3, 3, 3, device=dev) * 0.2
     b = torch.randn(C, device=dev)
     out = torch.empty((n_img, H, H, C), device=dev)
-    ms = timeit(lambda: ops.conv_in(img, w, b, n_img, H, H, C, out=out))
-    print(f'conv_in u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
+    wp = ops.pack_conv_in_x3h(w) if x3h else None
+    ms = timeit(lambda: ops.conv_in(img, w, b, n_img, H, H, C, out=out, wp3h=wp))
+    print(f'conv_in{" x3h" if x3h else ""} u8 {n_img}x{H}^2 -> {C}ch: {ms:.3f} ms  {out.numel() * 4 / ms / 1e6:.0f} GB/s written')
 
 
 def clockprobe(n_img=56, C=128, H=128):
@@ -135,7 +136,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmx6_k3072=lambda: gemm(16384, 3072, 768, arith='x6'), gemmf32=lambda: gemm(16384, 768, 2304),
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
-           convin=convin, conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
+           convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
            gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),

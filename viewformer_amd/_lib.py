@@ -36,6 +36,9 @@ EXPORTS = {
     'vf_igemm_pack_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int64, P]),
     'vf_igemm_f32': (c_int, [POINTER(VfIgemmArgs), P]),
     'vf_conv_in_u8_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'vf_conv_in_x3h_packed_elems': (c_size_t, [c_int]),
+    'vf_conv_in_x3h_pack': (c_int, [P, P, c_int, P]),
+    'vf_conv_in_x3h': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_crc32c': (ctypes.c_uint32, [P, c_size_t, ctypes.c_uint32]),
     'vf_conv3_small_cout_f32': (c_int, [P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_groupnorm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -273,8 +273,22 @@ def conv3_small_cout(x, w_oihw, bias, n_img, H, W, Cin, Cout, pro=None, pro_swis
     return out
 
 
-def conv_in(img, w_oihw, bias, n_img, H, W, Cout, out=None):
-    """img: uint8 NHWC [n,H,W,3] (TF evaluator entry) or float32 NHWC already in [-1,1]"""
+def pack_conv_in_x3h(w_oihw):
+    """encoder.conv_in weight [Cout][3][3][3] -> split-fp16 packing for the matrix-pipe form of conv_in (Cout % 128 == 0)"""
+    lib = _lib.load()
+    w = _f32(w_oihw).contiguous()
+    out = torch.empty(int(lib.vf_conv_in_x3h_packed_elems(w.shape[0])), dtype=torch.float16, device=w.device)
+    check(lib.vf_conv_in_x3h_pack(_p(w), _p(out), w.shape[0], _stream()), 'vf_conv_in_x3h_pack')
+    return out
+
+
+def conv_in_x3h_supported(H, W, Cout):
+    return H % 8 == 0 and W % 16 == 0 and Cout % 128 == 0
+
+
+def conv_in(img, w_oihw, bias, n_img, H, W, Cout, out=None, wp3h=None, gn_part=None):
+    """img: uint8 NHWC [n,H,W,3] (TF evaluator entry) or float32 NHWC already in [-1,1].  ``wp3h`` (pack_conv_in_x3h): run on the
+    matrix pipe (fp32-equivalent x3h arithmetic), optionally emitting the GroupNorm partial statistics of the output (gn_part)"""
     lib = _lib.load()
     if out is None:
         out = torch.empty((n_img, H, W, Cout), dtype=torch.float32, device=img.device)
@@ -282,6 +296,13 @@ def conv_in(img, w_oihw, bias, n_img, H, W, Cout, out=None):
         u8, f32 = _p(_chk(img, torch.uint8)), None
     else:
         u8, f32 = None, _p(_f32(img))
+    if wp3h is not None:
+        _chk(wp3h, torch.float16, 'wp3h')
+        check(lib.vf_conv_in_x3h(u8, f32, _p(wp3h), _p(bias), _p(out), _p(gn_part) if gn_part is not None else None,
+                                 gn_part.shape[1] if gn_part is not None else 0, n_img, H, W, Cout, _stream()), 'vf_conv_in_x3h')
+        return out
+    if gn_part is not None:
+        raise _lib.VfError('conv_in: fused GroupNorm statistics need the x3h form (wp3h)')
     check(lib.vf_conv_in_u8_f32(u8, f32, _p(_f32(w_oihw)), _p(bias), _p(out), n_img, H, W, Cout, _stream()),
           'vf_conv_in_u8_f32')
     return out

@@ -132,6 +132,8 @@ class VQGAN:
             c.wp6 = None
             c.wp3h = None
             split = self.conv_arith in ('x6', 'x3h')
+            if self.conv_arith == 'x3h' and c.k == 3 and c.cin == 3 and c.cout % 128 == 0:
+                c.wp3h = ops.pack_conv_in_x3h(w)
             if split and c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                 c.wp6 = ops.pack_conv3_x6(w)
                 if self.conv_arith == 'x3h':
@@ -257,7 +259,13 @@ class VQGAN:
             if kind == 'conv3':
                 c = self._conv[name]
                 if c.wp is None:      # 3-channel conv_in (fused uint8 -> [-1,1])
-                    x = ops.conv_in(x, c.w_raw, c.bias, n, H, W, c.cout).view(n * H * W, c.cout)
+                    if c.wp3h is not None and ops.conv_in_x3h_supported(H, W, c.cout):      # matrix-pipe form + fused GN statistics
+                        part = ops.new_gn_part(n, H, W, x.device) if self.fuse_gn_stats and c.cout in (128, 256, 512, 1024) else None
+                        x = ops.conv_in(x, c.w_raw, c.bias, n, H, W, c.cout, wp3h=c.wp3h, gn_part=part).view(n * H * W, c.cout)
+                        self._stats_of = (x, part) if part is not None else None
+                    else:
+                        x = ops.conv_in(x, c.w_raw, c.bias, n, H, W, c.cout).view(n * H * W, c.cout)
+                        self._stats_of = None
                 else:
                     x, H, W = self._conv3(x, name, n, H, W, pro=self._pending_pro, pro_swish=True)
                 self._pending_pro = None
