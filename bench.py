@@ -224,11 +224,19 @@ def main():
         }
     # ---- roofline of the dominant kernel (igemm_f32, all conv + dense layers), rank 0 only -----------
     if rank == 0:
-        prof = IgemmProfiler()
-        prof.install()
-        step()
-        ms, fl, n, top = prof.summary()
-        prof.uninstall()
+        # two instrumented passes, the one with the smaller total kept: the first launches after the timed loop occasionally run
+        # at a lower clock (seen once: 5.5 ms instead of 3.7 ms for the dominant launch while the rocprofv3 trace of the same
+        # box said 3.75 ms)
+        best = None
+        for _ in range(2):
+            prof = IgemmProfiler()
+            prof.install()
+            step()
+            res = prof.summary()
+            prof.uninstall()
+            if best is None or res[0] < best[0]:
+                best = res
+        ms, fl, n, top = best
         fam = fl / (ms * 1e-3) / 1e12
         # dominant kernel = the halo-tile 3x3 conv at its dominant launch shape: 128->128 @128x128 (mode 1,
         # M = images*128*128): SURVEY §8(d) per-unit figure 2*9*128*128 FLOP per output pixel x M pixels.
