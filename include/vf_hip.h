@@ -172,9 +172,9 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
                             float scale, int skip_masked, int twin_view, void* stream);
 /* same contract on the bf16 matrix pipe (Q, K, V and the probabilities rounded to bf16, fp32 sums and softmax): the
  * tolerance-bounded transformer arm.  fp32 tensors in, fp32 out. */
-int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, float* out,
-                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                             float scale, int skip_masked, int twin_view, void* stream);
+int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, void* out, int out_bf16 /* 0: fp32 out, 1: bf16 out (ldo in
+                            elements) for a bf16-GEMM consumer */, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                            float scale, int skip_masked, int twin_view, void* stream);
 /* same contract, fp32-EQUIVALENT on the bf16 pipe (x6: every operand split into three bf16 pieces, six partial products per
  * fp32 product, fp32 softmax) — the default attention of the fp32 transformer arm */
 int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float* out,
@@ -189,6 +189,9 @@ int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream
 /* LayerNormalization(eps) over the last dim (migt.py:225,227,292) */
 int vf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out,
                      int64_t rows, int d, float eps, void* stream);
+/* the same with a bf16 output row (rounded to nearest even, exactly as a bf16-MFMA consumer would round the fp32 value on load) */
+int vf_layernorm_bf16out_f32(const float* x, const float* gamma, const float* beta, void* out_bf16, int64_t rows, int d, float eps,
+                             void* stream);
 /* h0[b][s][l][:] = wte[ids[b][s][l]] + wpe[l] + add[b][s][:]   (migt.py:358-368,392) */
 int vf_embed_sum_f32(const int32_t* ids, const float* wte, const float* wpe, const float* add,
                      float* out, int64_t BS, int L, int d, int vocab, void* stream);
@@ -219,6 +222,9 @@ size_t vf_gemm_bf16_packed_elems(int K, int N);            /* number of bf16 ele
 int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int batch,
                       int64_t src_bstride, void* stream);
 int vf_gemm_bf16(const vf_igemm_args* args /* host */, void* stream);
+/* vf_gemm_bf16 reads args->reserved0 as dtype flags: bit 0 = x is bf16 [M][lda] (lda in elements, % 8 == 0), bit 1 = out is bf16
+ * [M][ldc] (no residual).  Both need Cin % 128 == 0.  For activations that only bf16 GEMMs consume (LayerNorm / GELU / attention
+ * outputs): bit-identical results, half the traffic. */
 size_t vf_conv3_bf16_packed_elems(int Cin, int Cout);
 int vf_conv3_bf16_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* stream);
 int vf_conv3_halo_bf16(const vf_igemm_args* args /* host */, void* stream);

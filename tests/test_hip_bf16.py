@@ -183,3 +183,48 @@ def test_attention_bf16_all_mask_modes(dev, B, H, S, L, mode):
         outs.append(out)
     assert torch.equal(outs[0], outs[1])        # skipping fully masked tiles == the dense "-1e4" form, also in bf16
     print(f'bf16 attention {mode} B={B} H={H} S={S} L={L}: rel err {err:.2e}')
+
+
+def test_bf16_activation_chain_is_bit_identical(dev):
+    """LayerNorm / GELU / attention outputs written as bf16 by their producers and read as bf16 by the GEMMs (a16 / o16): the same
+    rounding the GEMM applies to an fp32 operand on load, so everything downstream is bit-identical — kernel by kernel and for the
+    full-size transformer's logits"""
+    from viewformer_amd import ops
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    M, K, N = 300, 256, 384
+    x, w, b = _rand((M, K), 61).to(dev), _rand((K, N), 62, 0.1).to(dev), _rand((N,), 63).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    g, be = (_rand((K,), 64) * 0.3 + 1).to(dev), _rand((K,), 65).to(dev)
+    ln32, ln16 = ops.layernorm(x, g, be, M, K), ops.layernorm(x, g, be, M, K, out_bf16=True)
+    assert ln16.dtype == torch.bfloat16 and torch.equal(ln16, ln32.to(torch.bfloat16))
+    for epi in (ops.EPI_NONE, ops.EPI_GELU):
+        o_ref, o_a16 = torch.empty((M, N), device=dev), torch.empty((M, N), device=dev)
+        ops.igemm(ln32, wp, M, K, N, o_ref, bias=b, epilogue=epi, bf16=True)
+        ops.igemm(ln16, wp, M, K, N, o_a16, bias=b, epilogue=epi, bf16=True, a16=True)
+        assert torch.equal(o_ref, o_a16)
+        o16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        ops.igemm(ln16, wp, M, K, N, o16, bias=b, epilogue=epi, bf16=True, a16=True, o16=True)
+        assert torch.equal(o16, o_ref.to(torch.bfloat16))
+    B, H, S, L, d = 2, 2, 3, 64, 128
+    qkv = _rand((B * S * L, 3 * d), 66).to(dev)
+    a32 = torch.empty((B * S * L, d), device=dev)
+    a16 = torch.empty((B * S * L, d), dtype=torch.bfloat16, device=dev)
+    for out in (a32, a16):
+        ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, S * L, L, 3 * d, 3 * d, 3 * d, d, 0.3, True, -1, bf16=True)
+    assert torch.equal(a16, a32.to(torch.bfloat16))
+    # whole transformer
+    cfg = MIGTConfig(sequence_size=4, localization_weight='1', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=0)
+    gen = np.random.Generator(np.random.PCG64(17))
+    codes = torch.from_numpy(gen.integers(0, 1024, size=(2, 4, 8, 8)))
+    _, cams = synthetic_scene_batch(2, 4, 8, 6)
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    outs = []
+    for flag in (False, True):
+        m = MIGT(cfg, precision='bf16', bf16_activations=flag).load_state_dict(sd).to(dev)
+        lg, pose = m.generate_and_localize(codes.to(dev), cams.to(dev))
+        outs.append((lg, pose))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -72,8 +72,7 @@ EXPORTS = {
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, P]),
-    'vf_attn_blockcausal_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                         c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_bf16': (c_int, [P, P, P, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -84,6 +83,7 @@ EXPORTS = {
                                 c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
     'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
+    'vf_layernorm_bf16out_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),

@@ -27,7 +27,7 @@ constexpr int VT_LDB = 136; // bytes per V^T row ([feature][key] bf16): 34 banks
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int skip_masked, int twin) {
+                                                                  float scale, int skip_masked, int twin, int out16) {
     __shared__ __attribute__((aligned(16))) unsigned char Ks[KT * K_LDB];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[DH * VT_LDB];
 
@@ -247,6 +247,13 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = ot[d][4 * j + e] / l_tot;
+                if (out16) {                           // bf16 output for a bf16-MFMA consumer (ldo in elements)
+                    bf16x4 ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob[e] = (__bf16)o[e];
+                    __bf16* o16 = reinterpret_cast<__bf16*>(out) + b * (size_t)T * ldo + h * DH + (size_t)qrow * ldo + 4 * half;
+                    *reinterpret_cast<bf16x4*>(o16 + d * 32 + 8 * j) = ob;
+                } else
                 *reinterpret_cast<f32x4*>(orow + d * 32 + 8 * j) = o;
             }
     }
@@ -256,15 +263,15 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
 
 extern "C" {
 
-int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, float* out, int B, int H, int T, int L,
+int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, void* out, int out_bf16, int B, int H, int T, int L,
                             int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
                             void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attn_blockcausal_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view);
+    hipLaunchKernelGGL(attn_blockcausal_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, reinterpret_cast<float*>(out),
+                       T, L, ldq, ldk, ldv, ldo, scale, skip_masked, twin_view, out_bf16);
     return vf_last_status();
 }
 

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vf_igemm_args p) {
 // is fragment-major, so a lane's B fragment is one 16-byte L2 load — and are fetched one whole 64-deep stage ahead into a
 // register ring pinned with sched_barrier (the recipe of conv3_halo_x6.hip).  LDS then carries only the A tile: half the
 // LDS traffic of the kernel above, which was LDS-bandwidth-bound (16 ds_read_b128 per 16 MFMAs per wave).
+// A16: the activation matrix is already bf16 in HBM ([M][lda] bf16, lda in elements: LayerNorm / GELU / attention outputs written by
+// their producers in the format this kernel would round them to anyway) -> a 16 KB stage copied 16 B per thread, no conversion.
+// O16: the output is written as bf16 (a value consumed only by another bf16 GEMM; no residual).
+template <bool A16, bool O16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][A_BYTES]
     unsigned char* As = smem_b;
@@ -173,24 +177,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     const size_t stage_stride = (size_t)nb * B_BYTES;
     const int nstages = p.Cin / CK;
 
-    const int a_c4 = tid & 15, a_r0 = tid >> 4;
-    const float* arow[8];
+    // fp32 A: thread -> float4 column (tid & 15), rows (tid >> 4) + 16 q (8 loads); bf16 A: 16-byte piece (tid & 7), rows (tid >> 3) + 32 q
+    const int a_c4 = A16 ? (tid & 7) : (tid & 15), a_r0 = A16 ? (tid >> 3) : (tid >> 4);
+    constexpr int NQ = A16 ? 4 : 8, RSTEP = A16 ? 32 : 16;
+    const float* arow[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        int m = mtile * BM + a_r0 + 16 * q;
+    for (int q = 0; q < NQ; ++q) {
+        int m = mtile * BM + a_r0 + RSTEP * q;
         m = m < p.M ? m : p.M - 1;
-        arow[q] = X + (size_t)m * p.lda + a_c4 * 4;
+        arow[q] = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(X) + (size_t)m * p.lda + a_c4 * 8)
+                      : X + (size_t)m * p.lda + a_c4 * 4;
     }
-    f32x4 areg[8];
+    f32x4 areg[NQ];
     auto a_fetch = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const f32x4*>(arow[q] + s * CK);
+        for (int q = 0; q < NQ; ++q)
+            areg[q] = A16 ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(arow[q]) + s * CK)
+                          : *reinterpret_cast<const f32x4*>(arow[q] + s * CK);
     };
     auto a_park = [&](int buf, int q) {
-        bf16x4 v;
+        if (A16) {
+            if (q < NQ) *reinterpret_cast<f32x4*>(As + buf * A_BYTES + (a_r0 + RSTEP * q) * A_LDB + a_c4 * 16) = areg[q < NQ ? q : 0];
+        } else {
+            bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[q][e];
-        *reinterpret_cast<bf16x4*>(As + buf * A_BYTES + (a_r0 + 16 * q) * A_LDB + a_c4 * 8) = v;
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[q < NQ ? q : 0][e];
+            *reinterpret_cast<bf16x4*>(As + buf * A_BYTES + (a_r0 + RSTEP * q) * A_LDB + a_c4 * 8) = v;
+        }
     };
     const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
     bf16x8 bring[2][4][2];             // [stage parity][ks][j]
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     a_fetch(0);
     b_load(bring[0], 0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a_park(0, q);
+    for (int q = 0; q < NQ; ++q) a_park(0, q);
     __syncthreads();
 
     auto stage_body = [&](int s, bf16x8 (&bcur)[4][2], bf16x8 (&bnext)[4][2]) {
@@ -232,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], bcur[ks][j], acc[i][j], 0, 0, 0);
-            a_park((s + 1) & 1, ks * 2);
-            a_park((s + 1) & 1, ks * 2 + 1);
+            if (A16) a_park((s + 1) & 1, ks);
+            else { a_park((s + 1) & 1, ks * 2); a_park((s + 1) & 1, ks * 2 + 1); }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -243,6 +256,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
         stage_body(s + 1, bring[1], bring[0]);
     }
 
+    if (O16) {                       // bf16 store (bias + optional GELU; no residual), element by element, rows / columns guarded
+        const bool gelu16 = p.epilogue == VF_EPI_GELU_ERF;
+        __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+            const float bias = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (r & 3) + 8 * (r >> 2);
+                    float t = acc[i][j][r] + bias;
+                    if (gelu16) t = vf_gelu_erf_fast(t);
+                    if (m < p.M && n < p.Cout) O[(size_t)m * p.ldc + n] = (__bf16)t;
+                }
+            }
+        }
+        return;
+    }
     float* __restrict__ Out = p.out;
     const float* __restrict__ Res = p.res;
     const bool full = (mtile * BM + BM <= p.M) && (nblk * BN + BN <= p.Cout);
@@ -490,8 +524,19 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
         hipLaunchKernelGGL(gemm_bf16_w256_kernel, dim3((unsigned)(mt2 * nb)), dim3(256), (size_t)2 * W_ABYTES, (hipStream_t)stream, a);
         return vf_last_status();
     }
+    const bool a16 = a.reserved0 & 1, o16 = a.reserved0 & 2;      // bf16 activations in / out (see gemm_bf16_direct_kernel)
+    if (a16 || o16) {
+        if (a.Cin % (2 * CK) != 0 || a.batch > 1) return VF_ERR_UNSUPPORTED;
+        if ((a16 && (a.lda & 7)) || (o16 && a.res)) return VF_ERR_BAD_ARG;
+        const dim3 g((unsigned)(mt * nb));
+        hipStream_t st = (hipStream_t)stream;
+        if (a16 && o16) hipLaunchKernelGGL((gemm_bf16_direct_kernel<true, true>), g, dim3(256), (size_t)2 * A_BYTES, st, a);
+        else if (a16) hipLaunchKernelGGL((gemm_bf16_direct_kernel<true, false>), g, dim3(256), (size_t)2 * A_BYTES, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_direct_kernel<false, true>), g, dim3(256), (size_t)2 * A_BYTES, st, a);
+        return vf_last_status();
+    }
     if (VF_GEMM_BF16_DIRECT && a.Cin % (2 * CK) == 0 && a.batch <= 1) {
-        hipLaunchKernelGGL(gemm_bf16_direct_kernel, dim3((unsigned)(mt * nb)), dim3(256), (size_t)2 * A_BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gemm_bf16_direct_kernel<false, false>), dim3((unsigned)(mt * nb)), dim3(256), (size_t)2 * A_BYTES, (hipStream_t)stream, a);
         return vf_last_status();
     }
     dim3 grid((unsigned)(mt * nb), 1, (unsigned)(a.batch > 0 ? a.batch : 1));

@@ -9,7 +9,7 @@ namespace {
 // ---------------------------------------------------------------- LayerNorm (migt.py:225,227,292)
 // one wave per row; two-pass (mean, then centred variance) on register-resident data; d <= 64*4*MAXV
 constexpr int LN_MAXV = 8;   // up to 2048 features
-template <int MAXV>
+template <int MAXV, bool OUT16 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ out,
                                                         long long rows, int d, float eps) {
@@ -50,6 +50,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (OUT16) {                               // bf16 row for a bf16-MFMA consumer (rounded exactly as it would round on load)
+                typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+                ln_bf16x4 ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ob[e] = (__bf16)o[e];
+                *reinterpret_cast<ln_bf16x4*>(reinterpret_cast<__bf16*>(out) + (size_t)row * d + c * 4) = ob;
+            } else
             *reinterpret_cast<f32x4*>(orow + c * 4) = o;
         }
     }
@@ -275,6 +282,21 @@ int vf_layernorm_f32(const float* x, const float* gamma, const float* beta, floa
     else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
     else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
     else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, gamma, beta, out, (long long)rows, d, eps);
+    return vf_last_status();
+}
+
+int vf_layernorm_bf16out_f32(const float* x, const float* gamma, const float* beta, void* out_bf16, int64_t rows, int d, float eps,
+                             void* stream) {
+    if (!x || !gamma || !beta || !out_bf16 || rows < 0 || d <= 0) return VF_ERR_BAD_ARG;
+    if ((d & 3) || d > 64 * 4 * LN_MAXV) return VF_ERR_UNSUPPORTED;
+    if (rows == 0) return VF_OK;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    float* o = reinterpret_cast<float*>(out_bf16);
+    if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, x, gamma, beta, o, (long long)rows, d, eps);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, s, x, gamma, beta, o, (long long)rows, d, eps);
+    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, x, gamma, beta, o, (long long)rows, d, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<8, true>), grid, dim3(256), 0, s, x, gamma, beta, o, (long long)rows, d, eps);
     return vf_last_status();
 }
 

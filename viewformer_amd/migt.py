@@ -29,7 +29,7 @@ class _Dense:
 
 class MIGT:
     def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True, precision: str = 'f32',
-                 dense_arith: str = 'x3h'):
+                 dense_arith: str = 'x3h', bf16_activations: bool = True):
         """``dense_arith`` picks how the fp32 dense layers are evaluated (precision='f32' only): 'f32' = native f32 MFMA,
         'x6' = the fp32-EQUIVALENT six-term split-bf16 GEMM (csrc/gemm_x6.hip: same error against fp64, ~1.8x faster),
         'x3h' = the three-term split-fp16 GEMM (csrc/gemm_x3h.hip: same error for activations in fp16's range — LayerNorm / GELU /
@@ -41,6 +41,9 @@ class MIGT:
         assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6', 'x3h')
         self.precision = precision
         self.dense_arith = dense_arith
+        # bf16 arm only: LayerNorm / GELU / attention outputs — values that only bf16 GEMMs consume — are written as bf16 by their
+        # producers (exactly the rounding the GEMM would apply on load: bit-identical logits, half the traffic of the widest tensors)
+        self.bf16_activations = bf16_activations
         self.config = config or MIGTConfig()
         c = self.config
         self.n_image_tokens = c.token_image_size ** 2
@@ -143,9 +146,9 @@ class MIGT:
         torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ helpers
-    def _gemm(self, x, name, M, epilogue=ops.EPI_NONE, res=None):
+    def _gemm(self, x, name, M, epilogue=ops.EPI_NONE, res=None, out_bf16=False):
         d = self._dense[name]
-        out = torch.empty((M, d.n), dtype=torch.float32, device=x.device)
+        out = torch.empty((M, d.n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
         self._dense_launch(x, d, M, out, res=res, epilogue=epilogue)
         return out
 
@@ -155,7 +158,7 @@ class MIGT:
         bf16, x6 = d.wp16 is not None, d.wp16 is None and getattr(d, 'wp6', None) is not None
         x3h = x6 and d.wp6.dtype == torch.float16
         ops.igemm(x, d.wp16 if bf16 else d.wp6 if x6 else d.wp, M, d.k, d.n, out, bias=d.bias, res=res, epilogue=epilogue,
-                  bf16=bf16, x6=x6 and not x3h, x3h=x3h)
+                  bf16=bf16, x6=x6 and not x3h, x3h=x3h, a16=x.dtype == torch.bfloat16, o16=out.dtype == torch.bfloat16)
 
     def _lm(self, h, M, out):
         """tied LM head: logits = h @ wte[:n_embeddings]^T  (SharedEmbeddings._linear, migt.py:51-56,417)"""
@@ -190,10 +193,14 @@ class MIGT:
         ids32 = ids.reshape(M).to(torch.int32).contiguous()
         h = ops.embed_sum(ids32, self._wte, self._wpe, add, B * V, L, d, c.n_embeddings + 2)   # migt.py:392
         qkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
-        att = torch.empty((M, d), dtype=torch.float32, device=dev)
+        l0 = self._dense['h.0.mlp.c_proj'] if c.n_layer else None
+        act16 = (self.precision == 'bf16' and self.bf16_activations and d % 128 == 0 and l0 is not None and l0.k % 128 == 0
+                 and all(self._dense[f'h.{i}.{n}'].wp16 is not None for i in range(c.n_layer)
+                         for n in ('attn.c_attn', 'attn.c_proj', 'mlp.c_fc', 'mlp.c_proj')))
+        att = torch.empty((M, d), dtype=torch.bfloat16 if act16 else torch.float32, device=dev)
         for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
             p = f'h.{i}'
-            a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d)
+            a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d, out_bf16=act16)
             ca = self._dense[p + '.attn.c_attn']
             self._dense_launch(a, ca, M, qkv)
             # thirds are (V, Q, K): migt.py:207-213
@@ -201,8 +208,8 @@ class MIGT:
                                  3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16',
                                  x6=self.precision == 'f32' and self.dense_arith in ('x6', 'x3h'))
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
-            m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d)
-            f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU)
+            m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d, out_bf16=act16)
+            f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU, out_bf16=act16)
             h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
         return ops.layernorm(h, *self._ln['ln_f'], M, d)                    # migt.py:408
 

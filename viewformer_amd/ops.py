@@ -196,7 +196,7 @@ def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
-          x3h=False):
+          x3h=False, a16=False, o16=False):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
@@ -227,7 +227,13 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     if gn_part is not None:
         a.gn_part = _f32(gn_part).data_ptr()
         a.gn_slots = gn_part.shape[1]
-    for t in (x, out, bias, res):
+    if a16 or o16:                            # bf16 activations in / out: the bf16 GEMM only (dtype flags in reserved0)
+        if not bf16 or mode != MODE_GEMM:
+            raise _lib.VfError('a16 / o16 need bf16=True, mode GEMM')
+        _chk(x, torch.bfloat16 if a16 else torch.float32, 'x')
+        _chk(out, torch.bfloat16 if o16 else torch.float32, 'out')
+        a.reserved0 = (1 if a16 else 0) | (2 if o16 else 0)
+    for t in ((None if a16 else x), (None if o16 else out), bias, res):
         if t is not None:
             _f32(t)
     if x3h:                                   # w_packed = pack_conv3_x3h / pack_dense_*_x3h: the 3-product split-fp16 kernels
@@ -387,8 +393,9 @@ def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, sk
               'vf_attn_blockcausal_x6')
         return out
     if bf16:
-        check(lib.vf_attn_blockcausal_bf16(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
-                                           ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
+        o16 = out.dtype == torch.bfloat16          # bf16 output for a bf16-GEMM consumer (igemm(..., a16=True))
+        check(lib.vf_attn_blockcausal_bf16(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
+                                           ldq, ldk, ldv, ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
               'vf_attn_blockcausal_bf16')
         return out
     check(lib.vf_attn_blockcausal_f32(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
@@ -402,7 +409,13 @@ def softmax_rows_(x, rows, n, scale=1.0):
     return x
 
 
-def layernorm(x, gamma, beta, rows, d, eps=1e-5, out=None):
+def layernorm(x, gamma, beta, rows, d, eps=1e-5, out=None, out_bf16=False):
+    """``out_bf16``: write the normalised rows as bf16 (for a bf16-GEMM consumer: ``igemm(..., bf16=True, a16=True)``)"""
+    if out_bf16:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if out is None else _chk(out, torch.bfloat16, 'out')
+        check(_lib.load().vf_layernorm_bf16out_f32(_p(_f32(x)), _p(_f32(gamma)), _p(_f32(beta)), _p(out), rows, d, eps, _stream()),
+              'vf_layernorm_bf16out_f32')
+        return out
     if out is None:
         out = torch.empty_like(x)
     check(_lib.load().vf_layernorm_f32(_p(_f32(x)), _p(_f32(gamma)), _p(_f32(beta)), _p(out), rows, d, eps, _stream()),
