@@ -172,9 +172,10 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
                             float scale, int skip_masked, int twin_view, void* stream);
 /* same contract on the bf16 matrix pipe (Q, K, V and the probabilities rounded to bf16, fp32 sums and softmax): the
  * tolerance-bounded transformer arm.  fp32 tensors in, fp32 out. */
-int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, void* out, int out_bf16 /* 0: fp32 out, 1: bf16 out (ldo in
-                            elements) for a bf16-GEMM consumer */, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                            float scale, int skip_masked, int twin_view, void* stream);
+int vf_attn_blockcausal_bf16(const void* q, const void* k, const void* v, int in_bf16 /* 0: fp32 q/k/v, 1: bf16 (ld* in elements, % 8) */,
+                            void* out, int out_bf16 /* 0: fp32 out, 1: bf16 out (ldo in elements) for a bf16-GEMM consumer */, int B,
+                            int H, int T, int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
+                            void* stream);
 /* same contract, fp32-EQUIVALENT on the bf16 pipe (x6: every operand split into three bf16 pieces, six partial products per
  * fp32 product, fp32 softmax) — the default attention of the fp32 transformer arm */
 int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float* out,

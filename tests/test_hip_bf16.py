@@ -215,6 +215,12 @@ def test_bf16_activation_chain_is_bit_identical(dev):
     for out in (a32, a16):
         ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, S * L, L, 3 * d, 3 * d, 3 * d, d, 0.3, True, -1, bf16=True)
     assert torch.equal(a16, a32.to(torch.bfloat16))
+    q16 = qkv.to(torch.bfloat16)                              # bf16 q/k/v (the c_attn GEMM's o16 output) == fp32 q/k/v of the same values
+    a_in16, a_ref = torch.empty_like(a32), torch.empty_like(a32)
+    ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], a_in16, B, H, S * L, L, 3 * d, 3 * d, 3 * d, d, 0.3, True, -1, bf16=True)
+    qr = q16.float()
+    ops.attn_blockcausal(qr[:, d:2 * d], qr[:, 2 * d:], qr[:, :d], a_ref, B, H, S * L, L, 3 * d, 3 * d, 3 * d, d, 0.3, True, -1, bf16=True)
+    assert torch.equal(a_in16, a_ref)
     # whole transformer
     cfg = MIGTConfig(sequence_size=4, localization_weight='1', pose_multiplier=0.2)
     sd = make_migt_weights(cfg, seed=0)

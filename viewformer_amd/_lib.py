@@ -72,7 +72,7 @@ EXPORTS = {
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, P]),
-    'vf_attn_blockcausal_bf16': (c_int, [P, P, P, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_bf16': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -27,7 +27,7 @@ constexpr int VT_LDB = 136; // bytes per V^T row ([feature][key] bf16): 34 banks
 __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ v, float* __restrict__ out,
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int skip_masked, int twin, int out16) {
+                                                                  float scale, int skip_masked, int twin, int out16, int in16) {
     __shared__ __attribute__((aligned(16))) unsigned char Ks[KT * K_LDB];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[DH * VT_LDB];
 
@@ -40,9 +40,14 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
     const size_t b = blockIdx.z;
     const int q0 = blockIdx.x * QT;
 
+    // in16: q, k, v are bf16 in HBM (ld* in elements) — the fused c_attn output written as bf16 by its GEMM; loaded and widened
+    // exactly, so the rest of the kernel (which rounds fp32 inputs to bf16) sees the same values
     const float* qb_ptr = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;
     const float* vb = v + b * (size_t)T * ldv + h * DH;
+    const __bf16* q16 = reinterpret_cast<const __bf16*>(q) + b * (size_t)T * ldq + h * DH;
+    const __bf16* k16 = reinterpret_cast<const __bf16*>(k) + b * (size_t)T * ldk + h * DH;
+    const __bf16* v16 = reinterpret_cast<const __bf16*>(v) + b * (size_t)T * ldv + h * DH;
     float* ob = out + b * (size_t)T * ldo + h * DH;
 
     // ---- Q fragment (B operand): qb[ks][e] = bf16(Q[qrow][16 ks + 8 half + e]) ------------------------
@@ -51,8 +56,10 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
     bf16x8 qb[4];
     {
         const float* src = qb_ptr + (size_t)(qvalid ? qrow : 0) * ldq + 8 * half;
+        const __bf16* src16 = q16 + (size_t)(qvalid ? qrow : 0) * ldq + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (in16) { qb[ks] = *reinterpret_cast<const bf16x8*>(src16 + 16 * ks); continue; }
             const f32x4 t0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
             const f32x4 t1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
 #pragma unroll
@@ -104,8 +111,13 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
             const int key = kt * KT + s_row0 + 16 * i;
             const int vkey = kt * KT + 2 * (s_row0 + 16 * (i >> 1)) + (i & 1);
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-            if (key < T) a = *reinterpret_cast<const f32x4*>(kb + (size_t)key * ldk + s_col4 * 4);
-            if (vkey < T) c = *reinterpret_cast<const f32x4*>(vb + (size_t)vkey * ldv + s_col4 * 4);
+            if (in16) {
+                if (key < T) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(k16 + (size_t)key * ldk + s_col4 * 4); a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+                if (vkey < T) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(v16 + (size_t)vkey * ldv + s_col4 * 4); c = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+            } else {
+                if (key < T) a = *reinterpret_cast<const f32x4*>(kb + (size_t)key * ldk + s_col4 * 4);
+                if (vkey < T) c = *reinterpret_cast<const f32x4*>(vb + (size_t)vkey * ldv + s_col4 * 4);
+            }
             kreg[i] = a;
             vreg[i] = c;
         }
@@ -263,15 +275,17 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
 
 extern "C" {
 
-int vf_attn_blockcausal_bf16(const float* q, const float* k, const float* v, void* out, int out_bf16, int B, int H, int T, int L,
+int vf_attn_blockcausal_bf16(const void* q, const void* k, const void* v, int in_bf16, void* out, int out_bf16, int B, int H, int T, int L,
                             int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
                             void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
+    if (in_bf16 && ((ldq | ldk | ldv) & 7)) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attn_blockcausal_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, reinterpret_cast<float*>(out),
-                       T, L, ldq, ldk, ldv, ldo, scale, skip_masked, twin_view, out_bf16);
+    hipLaunchKernelGGL(attn_blockcausal_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(q),
+                       reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<float*>(out), T, L, ldq,
+                       ldk, ldv, ldo, scale, skip_masked, twin_view, out_bf16, in_bf16);
     return vf_last_status();
 }
 

@@ -15,6 +15,8 @@ bias / exact-erf GELU / residual epilogues, tied LM head.  torch = memory + stre
 """
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 
@@ -192,12 +194,15 @@ class MIGT:
         add = add_emb.contiguous().view(B * V, d)
         ids32 = ids.reshape(M).to(torch.int32).contiguous()
         h = ops.embed_sum(ids32, self._wte, self._wpe, add, B * V, L, d, c.n_embeddings + 2)   # migt.py:392
-        qkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
         l0 = self._dense['h.0.mlp.c_proj'] if c.n_layer else None
         act16 = (self.precision == 'bf16' and self.bf16_activations and d % 128 == 0 and l0 is not None and l0.k % 128 == 0
                  and all(self._dense[f'h.{i}.{n}'].wp16 is not None for i in range(c.n_layer)
                          for n in ('attn.c_attn', 'attn.c_proj', 'mlp.c_fc', 'mlp.c_proj')))
         att = torch.empty((M, d), dtype=torch.bfloat16 if act16 else torch.float32, device=dev)
+        # the fused c_attn output could be bf16 too (the attention kernel takes bf16 q/k/v, bit-identical), but A/B on MI355X it is
+        # 1.3 % slower end to end (938 vs 925 views/s: the 2-byte strided stores of the GEMM epilogue cost more than the bytes saved)
+        qkv16 = act16 and os.environ.get('VF_QKV16', '0') == '1'
+        qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if qkv16 else torch.float32, device=dev)
         for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
             p = f'h.{i}'
             a = ops.layernorm(h, *self._ln[p + '.ln_1'], M, d, out_bf16=act16)

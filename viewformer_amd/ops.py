@@ -394,7 +394,10 @@ def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, sk
         return out
     if bf16:
         o16 = out.dtype == torch.bfloat16          # bf16 output for a bf16-GEMM consumer (igemm(..., a16=True))
-        check(lib.vf_attn_blockcausal_bf16(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
+        i16 = q.dtype == torch.bfloat16            # bf16 q/k/v: the fused c_attn output written by its GEMM with o16=True
+        for t in (q, k, v):
+            _chk(t, torch.bfloat16 if i16 else torch.float32, 'q/k/v')
+        check(lib.vf_attn_blockcausal_bf16(_p(q), _p(k), _p(v), 1 if i16 else 0, _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
                                            ldq, ldk, ldv, ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
               'vf_attn_blockcausal_bf16')
         return out
