@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0
 X3H_PMC_KB = (532920e3, 501760e3)   # FETCH_SIZE, WRITE_SIZE of the x3h conv (profiles/r1_conv_x3h_pmc.txt), 56-image launch
 
 
-def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h'):
+def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h', bf16_activations: bool = True):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -53,7 +53,7 @@ def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: st
     arm = 'bf16' if precision == 'mixed' else 'f32'
     vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith).load_state_dict(vsd).to(dev)
     # the transformer's fp32 dense layers follow the convolutions' arithmetic (x3h: LayerNorm / GELU / attention outputs are O(1))
-    tr = MIGT(mcfg, precision=arm, dense_arith=conv_arith).load_state_dict(msd).to(dev)
+    tr = MIGT(mcfg, precision=arm, dense_arith=conv_arith, bf16_activations=bf16_activations).load_state_dict(msd).to(dev)
     return vq, tr, (vcfg, vsd, mcfg, msd)
 
 
@@ -153,6 +153,8 @@ def main():
                          "carried at 2^11, cross terms in their own accumulator; error vs fp64 <= the f32 MFMA for activations in "
                          "fp16's range, tests/test_hip_x3h.py) for the stride-1 / upsample convs, x6 elsewhere; x6 = six-term "
                          "split-bf16 products everywhere (no range condition, tests/test_hip_x6.py); f32 = native f32 MFMA")
+    ap.add_argument('--fp32-activations', action='store_true',
+                    help='mixed arm: keep LayerNorm / GELU / attention outputs fp32 in HBM (A/B of the bf16 activation chain; same results)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -169,7 +171,7 @@ def main():
     localization = not args.no_localization
     S, B = args.views, args.batch
 
-    vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith)
+    vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith, not args.fp32_activations)
     frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
     frames_d = torch.from_numpy(frames).to(dev)
     cams_d = torch.from_numpy(cams).to(dev)
