@@ -256,9 +256,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
         stage_body(s + 1, bring[1], bring[0]);
     }
 
-    if (O16) {                       // bf16 store (bias + optional GELU; no residual), element by element, rows / columns guarded
+    if (O16) {
+        // bf16 store (bias + optional GELU; no residual).  A lane holds one column of 16 rows; neighbouring lanes hold neighbouring
+        // columns, so each pair of lanes swaps half of its rows (one DPP move per row) and every lane stores 8 x 4 bytes — two
+        // adjacent columns of one row — instead of 16 x 2 bytes.  Ragged edges fall back to single elements.
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         const bool gelu16 = p.epilogue == VF_EPI_GELU_ERF;
         __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
+        const bool pairs = (p.ldc & 1) == 0 && (p.Cout & 1) == 0;
+        const int odd = l31 & 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
@@ -266,12 +272,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
+                float t[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (r & 3) + 8 * (r >> 2);
-                    float t = acc[i][j][r] + bias;
-                    if (gelu16) t = vf_gelu_erf_fast(t);
-                    if (m < p.M && n < p.Cout) O[(size_t)m * p.ldc + n] = (__bf16)t;
+                    t[r] = acc[i][j][r] + bias;
+                    if (gelu16) t[r] = vf_gelu_erf_fast(t[r]);
+                }
+                if (pairs) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        // even lane: row r of columns (n, n+1); odd lane: row r+1 of columns (n-1, n)
+                        const float give = odd ? t[r] : t[r + 1];
+                        const float got = __shfl_xor(give, 1, 64);
+                        const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
+                        bf16x2_t v;
+                        v[0] = (__bf16)(odd ? got : t[r]);
+                        v[1] = (__bf16)(odd ? t[r + 1] : got);
+                        const int n0 = n - odd;
+                        if (m < p.M && n0 < p.Cout) *reinterpret_cast<bf16x2_t*>(O + (size_t)m * p.ldc + n0) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (r & 3) + 8 * (r >> 2);
+                        if (m < p.M && n < p.Cout) O[(size_t)m * p.ldc + n] = (__bf16)t[r];
+                    }
                 }
             }
         }
