@@ -7,7 +7,6 @@ Pinned by tests/golden/vqgan_train_tiny.npz, recorded from the reference itself 
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import vqgan_oracle as vq
 

@@ -22,7 +22,7 @@ import json
 import os
 import struct
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict
 
 import numpy as np
 

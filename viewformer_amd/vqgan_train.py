@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops
+from . import ops
 from . import train_ops as T
 from .vq_train import QuantizeEMATrainer
 from .vqgan import VQGAN
