@@ -36,9 +36,11 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_bf16_kernel(const flo
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int h = blockIdx.y;
-    const size_t b = blockIdx.z;
-    const int q0 = blockIdx.x * QT;
+    // grid (H, B, query tiles): the query tiles of one (scene, head) are gridDim.x * gridDim.y ids apart, i.e. on the SAME XCD
+    // whenever H * B % 8 == 0, and share its L2 copy of that head's K / V (consecutive ids go round-robin over the 8 XCDs)
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * QT;
 
     // in16: q, k, v are bf16 in HBM (ld* in elements) — the fused c_attn output written as bf16 by its GEMM; loaded and widened
     // exactly, so the rest of the kernel (which rounds fp32 inputs to bf16) sees the same values
@@ -282,7 +284,7 @@ int vf_attn_blockcausal_bf16(const void* q, const void* k, const void* v, int in
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     if (in_bf16 && ((ldq | ldk | ldv) & 7)) return VF_ERR_BAD_ARG;
-    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(q),
                        reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<float*>(out), T, L, ldq,
                        ldk, ldv, ldo, scale, skip_masked, twin_view, out_bf16, in_bf16);

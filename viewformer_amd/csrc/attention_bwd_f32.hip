@@ -72,9 +72,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float Kt[DH * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, H = gridDim.y;
-    const size_t b = blockIdx.z;
-    const int q0 = blockIdx.x * OT;
+    const int h = blockIdx.x, H = gridDim.x;      // grid (H, B, tiles): the tiles of one (scene, head) share an XCD's L2 (attention_f32.hip)
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * OT;
     const float* qb = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;
     const float* vb = v + b * (size_t)T * ldv + h * DH;
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
     float* Ds = Ls + TT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, H = gridDim.y;
-    const size_t b = blockIdx.z;
-    const int k0 = blockIdx.x * OT;
+    const int h = blockIdx.x, H = gridDim.x;      // grid (H, B, tiles)
+    const size_t b = blockIdx.y;
+    const int k0 = blockIdx.z * OT;
     const float* qb = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;
     const float* vb = v + b * (size_t)T * ldv + h * DH;
@@ -384,7 +384,7 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
     if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
     const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
     const float dscale = 1.0f / (1.0f - drop_rate);
-    dim3 grid((unsigned)((T + OT - 1) / OT), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, q, k, v, dout, lse, D, dq, T, L, ldq, ldk, ldv, lddo, lddq,
                        scale, twin_view, thresh, dscale, drop_seed, drop_site);

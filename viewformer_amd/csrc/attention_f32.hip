@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int h = blockIdx.y;
-    const size_t b = blockIdx.z;
-    const int q0 = blockIdx.x * QT;
+    // grid (H, B, query tiles): the query tiles of one (scene, head) are gridDim.x * gridDim.y ids apart, i.e. on the SAME XCD
+    // whenever H * B % 8 == 0, and share its L2 copy of that head's K / V (consecutive ids go round-robin over the 8 XCDs)
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * QT;
 
     const float* qb = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
                 psum += p;                                   // the softmax normaliser is over the undropped weights
                 if (drop_thresh) {                           // attn_dropout (branching_attention.py:15-17): applied to softmax(w)
                     const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const uint64_t e = (((uint64_t)b * gridDim.y + h) * T + qrow) * (uint64_t)T + key;
+                    const uint64_t e = (((uint64_t)b * gridDim.x + h) * T + qrow) * (uint64_t)T + key;
                     p = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh ? p * drop_scale : 0.f;
                 }
                 st[t2][r] = p;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
     // ---- normalise and store: lane = query, regs 4j..4j+3 = 4 consecutive features -------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     // log-sum-exp of the (scaled, masked) scores of this query: what the backward pass needs to re-materialise P
-    if (lse && qvalid && half == 0) lse[((size_t)b * gridDim.y + h) * T + qrow] = m_run + logf(l_tot);
+    if (lse && qvalid && half == 0) lse[((size_t)b * gridDim.x + h) * T + qrow] = m_run + logf(l_tot);
     if (qvalid) {
         float* orow = ob + (size_t)qrow * ldo + 4 * half;
 #pragma unroll
@@ -260,7 +262,7 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
-    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
                        ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr, 0u, 1.0f, 0u, 0u);
     return vf_last_status();
@@ -274,7 +276,7 @@ int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, 
     const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
-    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
                        ldv, ldo, scale, skip_masked, twin_view, lse, thresh, 1.0f / (1.0f - drop_rate), drop_seed, drop_site);
     return vf_last_status();

@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_x6_kernel(const float
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int h = blockIdx.y;
-    const size_t b = blockIdx.z;
-    const int q0 = blockIdx.x * QT;
+    // grid (H, B, query tiles): the query tiles of one (scene, head) are gridDim.x * gridDim.y ids apart, i.e. on the SAME XCD
+    // whenever H * B % 8 == 0, and share its L2 copy of that head's K / V (consecutive ids go round-robin over the 8 XCDs)
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * QT;
 
     const float* qb_ptr = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;
@@ -299,7 +301,7 @@ int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
-    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_x6_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
                        ldv, ldo, scale, skip_masked, twin_view);
     return vf_last_status();
