@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0
 X3H_PMC_KB = (532920e3, 501760e3)   # FETCH_SIZE, WRITE_SIZE of the x3h conv (profiles/r1_conv_x3h_pmc.txt), 56-image launch
 
 
-def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h', bf16_activations: bool = True):
+def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h', bf16_activations: bool = True,
+                 encoder_chunk: int = 1024):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -51,7 +52,8 @@ def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: st
     # precision 'mixed': encoder + codebook lookup exact fp32 (bit-exact tokens), transformer dense layers and decoder
     # convolutions on bf16 MFMA (tolerance-bounded logits / pixels) — the split the north star specifies
     arm = 'bf16' if precision == 'mixed' else 'f32'
-    vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith).load_state_dict(vsd).to(dev)
+    vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith,
+               max_images_per_call=encoder_chunk).load_state_dict(vsd).to(dev)
     # the transformer's fp32 dense layers follow the convolutions' arithmetic (x3h: LayerNorm / GELU / attention outputs are O(1))
     tr = MIGT(mcfg, precision=arm, dense_arith=conv_arith, bf16_activations=bf16_activations).load_state_dict(msd).to(dev)
     return vq, tr, (vcfg, vsd, mcfg, msd)
@@ -155,6 +157,7 @@ def main():
                          "split-bf16 products everywhere (no range condition, tests/test_hip_x6.py); f32 = native f32 MFMA")
     ap.add_argument('--fp32-activations', action='store_true',
                     help='mixed arm: keep LayerNorm / GELU / attention outputs fp32 in HBM (A/B of the bf16 activation chain; same results)')
+    ap.add_argument('--encoder-chunk', type=int, default=1024, help='images per encoder / decoder launch chunk (VQGAN max_images_per_call)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -171,7 +174,7 @@ def main():
     localization = not args.no_localization
     S, B = args.views, args.batch
 
-    vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith, not args.fp32_activations)
+    vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith, not args.fp32_activations, args.encoder_chunk)
     frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
     frames_d = torch.from_numpy(frames).to(dev)
     cams_d = torch.from_numpy(cams).to(dev)

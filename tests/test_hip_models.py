@@ -360,3 +360,26 @@ def test_empty_batches_are_not_errors():
     quant, diff, codes = model.encode(torch.zeros((0, 3, 32, 32), device='cuda'))
     assert codes.shape == (0, 16, 16) and codes.dtype == torch.int64 and quant.shape == (0, 32, 16, 16)
     assert model.decode_code(codes).shape == (0, 3, 32, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,chunk', [(600, 150), (1040, 260)])
+def test_encoder_large_launches_match_chunked_launches(dev, full_vq, n, chunk):
+    """size-independent property at full size: one launch chunk of n images (activation tensors past 2^32 bytes at n = 600 and past
+    2^31 elements at n = 1040) gives bit-identical codes to the same images in chunks — no 32-bit index anywhere on the path"""
+    from viewformer_amd.weights import synthetic_scene_batch
+    cfg, sd, g = full_vq
+    frames, _ = synthetic_scene_batch(2, 8, 128, seed=77)
+    base = torch.from_numpy(frames.reshape(16, 128, 128, 3))
+    imgs = base.repeat((n + 15) // 16, 1, 1, 1)[:n].contiguous().to(dev)
+    imgs[1::3] = imgs[1::3].flip(1)                                      # not just 16 distinct images
+    imgs[2::5] = imgs[2::5].flip(2)
+    from viewformer_amd.vqgan import VQGAN
+    big = VQGAN(cfg, data_format='NHWC', max_images_per_call=n).load_state_dict(sd).to(dev)
+    small = VQGAN(cfg, data_format='NHWC', max_images_per_call=chunk).load_state_dict(sd).to(dev)
+    c_big = big.encode(imgs)[-1]
+    c_small = small.encode(imgs)[-1]
+    assert c_big.shape == (n, 8, 8) and torch.equal(c_big, c_small)
+    dec_big = big.decode_code(c_big[:n // 2])
+    dec_small = small.decode_code(c_big[:n // 2])
+    assert torch.equal(dec_big, dec_small)

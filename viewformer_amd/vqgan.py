@@ -29,7 +29,7 @@ class _Conv:
 
 
 class VQGAN:
-    def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 256,
+    def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 1024,
                  decoder_precision: str = 'f32', conv_arith: str = 'x3h'):
         """``conv_arith`` picks how the fp32 3x3 convolutions are evaluated: 'f32' = native f32 MFMA, 'x6' = the
         fp32-EQUIVALENT six-term split-bf16 kernel (same error against fp64 as the f32 MFMA, ~1.6x faster; see
