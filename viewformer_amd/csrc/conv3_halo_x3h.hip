@@ -403,8 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
 __global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
     float m = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
-    m = vf_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    vf_block_max_atomic(m, out);
 }
 
 // OIHW fp32 -> two fragment-packed f16 planes of w * S, S = 2^(13 - floor(log2 max|w|)); thread 0 leaves 1/S in the tail
@@ -471,7 +470,7 @@ int vf_conv3_x3h_pack(const float* w_oihw, void* dst, int Cin, int Cout, void* s
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(tail, 0, TAIL_BYTES, s) != hipSuccess) return vf_last_status();
     const long long nw = (long long)Cout * Cin * 9;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0, s, w_oihw, nw,
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nw + 2047) / 2048 > 128 ? 128 : (nw + 2047) / 2048)), dim3(256), 0, s, w_oihw, nw,
                        reinterpret_cast<unsigned*>(tail + 4));
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_conv_x3h_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, (_Float16*)dst, Cin, Cout, nb, nchunks, tail);

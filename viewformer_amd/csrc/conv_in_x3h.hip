@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256) void conv_in_x3h_kernel(vf_igemm_args p, const
 __global__ void absmax27_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
     float m = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
-    m = vf_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    vf_block_max_atomic(m, out);
 }
 
 // OIHW [Cout][3][3][3] -> [nblk][ks(3)][plane(2)][half(2)][n(128)][8]; k = (ks*2 + half)*8 + e -> tap = k / 4, channel = k % 4

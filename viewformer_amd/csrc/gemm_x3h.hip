@@ -217,8 +217,7 @@ __global__ void absmax_strided_kernel(const float* __restrict__ w, int K, int N,
     const long long n = (long long)K * N;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         m = fmaxf(m, fabsf(w[(i / N) * sk + (i % N) * sn]));
-    m = vf_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    vf_block_max_atomic(m, out);
 }
 
 // fp32 [K][N] (strided) -> two f16 planes of w * S, fragment-major [K/32][nb][ks(2)][plane(2)][half(2)][n(128)][8]
@@ -276,7 +275,7 @@ int vf_gemm_x3h_pack(const float* src, void* dst, int K, int N, int64_t sk, int6
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(tail, 0, TAIL_BYTES, s) != hipSuccess) return vf_last_status();
     const long long nw = (long long)K * N;
-    hipLaunchKernelGGL(absmax_strided_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0, s, src, K,
+    hipLaunchKernelGGL(absmax_strided_kernel, dim3((unsigned)((nw + 2047) / 2048 > 128 ? 128 : (nw + 2047) / 2048)), dim3(256), 0, s, src, K,
                        N, (long long)sk, (long long)sn, reinterpret_cast<unsigned*>(tail + 4));
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_gemm_x3h_kernel, dim3(blocks), dim3(256), 0, s, src, (_Float16*)dst, K, N, (long long)sk, (long long)sn, nb,

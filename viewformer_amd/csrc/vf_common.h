@@ -69,6 +69,17 @@ __device__ __forceinline__ float vf_wave_max(float v) {
     return v;
 }
 
+// block-wide max of a non-negative value into *out (bits of a non-negative float order like unsigned): ONE atomic per workgroup
+// (the first version issued one per wavefront from 1024 workgroups — 4096 serialised atomics on one address, 50 us per weight
+// tensor, 4 % of a training step that re-packs every weight)
+__device__ __forceinline__ void vf_block_max_atomic(float m, unsigned* out) {
+    __shared__ float vf_bm_red[4];
+    m = vf_wave_max(m);
+    if ((threadIdx.x & 63) == 0) vf_bm_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(vf_bm_red[0], vf_bm_red[1]), fmaxf(vf_bm_red[2], vf_bm_red[3]))));
+}
+
 // Counter-based dropout mask (training step): keep element `idx` of dropout site `site` iff hash >= thresh, where
 // thresh = floor(rate * 2^32).  A pure function of (seed, site, idx): the forward and backward passes recompute the same mask
 // and nothing is stored; oracle/train_oracle.py restates it in numpy for the tests.
