@@ -383,3 +383,20 @@ def test_encoder_large_launches_match_chunked_launches(dev, full_vq, n, chunk):
     dec_big = big.decode_code(c_big[:n // 2])
     dec_small = small.decode_code(c_big[:n // 2])
     assert torch.equal(dec_big, dec_small)
+
+
+@pytest.mark.gpu
+def test_evaluators_resize_frames_of_another_size(dev, tiny_vq):
+    """evaluate_codebook.py:67-77 / evaluate_transformer.py:105: frames that are not image_size go through the reference's resize
+    (here on the GPU) before the encoder: same codes as encoding the oracle-resized frames"""
+    from oracle import vqgan_oracle as vq
+    from viewformer_amd.evaluate import codebook_batch_predictions
+    cfg, sd, g = tiny_vq
+    m = _vq_model(cfg, sd, dev, 'NHWC')
+    rng = np.random.default_rng(9)
+    big = rng.integers(0, 256, size=(3, 80, 80, 3), dtype=np.uint8)
+    out = codebook_batch_predictions(m, torch.from_numpy(big))
+    small = vq.resize_u8(big, cfg.image_size)
+    ref = codebook_batch_predictions(m, torch.from_numpy(small))
+    assert torch.equal(out['codes'], ref['codes']) and torch.equal(out['generated_images'], ref['generated_images'])
+    assert out['ground_truth_images'].shape == (3, 80, 80, 3)             # the ground truth is returned as given (:75)

@@ -72,7 +72,10 @@ def codebook_batch_predictions(codebook_model, images):
     """evaluate_codebook.py:67-77 — encode -> decode round trip (BASELINE config #1)."""
     dev = codebook_model.device
     images = torch.as_tensor(images).to(dev)
-    codes = codebook_model.encode(images)[-1]
+    frames = images
+    if images.dtype == torch.uint8 and images.shape[-2] != codebook_model.config.image_size:      # resize_tf, evaluate_codebook.py:15-16,68
+        frames = ops.resize_u8(images, codebook_model.config.image_size)
+    codes = codebook_model.encode(frames)[-1]
     dec = codebook_model.decode_code(codes)
     if codebook_model.data_format == 'NCHW':
         dec = dec.permute(0, 2, 3, 1)
