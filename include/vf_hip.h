@@ -399,6 +399,9 @@ int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream);
 int vf_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);
 /* tf.clip_by_norm per tensor (migt.py:486-487): x *= clip / max(||x||, clip); scratch1 = one float */
 int vf_clip_by_norm_f32(float* x, int64_t n, float clip, float* scratch1, void* stream);
+/* global-norm clip of a flat gradient buffer as pytorch_lightning's Trainer(gradient_clip_val=...) applies it to the codebook model
+ * (train_codebook_th.py:69 -> torch.nn.utils.clip_grad_norm_): x *= max_norm / (||x|| + 1e-6) when that factor is < 1 */
+int vf_clip_grad_norm_f32(float* x, int64_t n, float max_norm, float* scratch1, void* stream);
 
 #ifdef __cplusplus
 }

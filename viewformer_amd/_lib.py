@@ -128,6 +128,7 @@ EXPORTS = {
     'vf_axpby_f32': (c_int, [c_float, P, c_float, P, P, c_int64, P]),
     'vf_add_inplace_f32': (c_int, [P, P, c_int64, P]),
     'vf_clip_by_norm_f32': (c_int, [P, c_int64, c_float, P, P]),
+    'vf_clip_grad_norm_f32': (c_int, [P, c_int64, c_float, P, P]),
 }
 
 _lib = None

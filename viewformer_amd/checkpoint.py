@@ -251,7 +251,7 @@ def write_tensor_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
 
 # ------------------------------------------------------------------------------------------------ name mapping
 _SUFFIX = '/.ATTRIBUTES/VARIABLE_VALUE'
-_IGNORED_PREFIXES = ('optimizer', '_CHECKPOINTABLE_OBJECT_GRAPH', 'save_counter', 'global_step', 'pose_loss_weighting_criterion')
+_IGNORED_PREFIXES = ('optimizer', '_CHECKPOINTABLE_OBJECT_GRAPH', 'save_counter', 'global_step')
 
 
 def keras_to_state_dict(bundle: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":

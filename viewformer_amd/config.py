@@ -74,11 +74,8 @@ class MIGTConfig:
     @property
     def use_localization(self) -> bool:
         """Reference: migt.py:268-269 (``not localization_weight.is_zero()``)."""
-        s = str(self.localization_weight).strip()
-        try:
-            return float(s) != 0.0
-        except ValueError:
-            return True   # a non-constant schedule is never identically zero
+        from .schedules import parse
+        return not parse(self.localization_weight).with_total_steps(self.total_steps).is_zero()
 
     def asdict(self):
         return asdict(self)
@@ -89,15 +86,17 @@ _CONFIGS = {'vqgan': VQGANConfig, 'migt': MIGTConfig}
 
 def load_config(config: dict):
     """Build a config object from a ``config.json`` dict (reference:
-    viewformer/models/__init__.py:62-78). Unknown model names raise ``ValueError``;
-    unknown keys raise ``TypeError`` like a dataclass constructor would."""
+    viewformer/models/__init__.py:62-78).  Unknown model names raise ``ValueError``; keys that are not fields of the
+    config class are ignored, as the reference's ``_build_dataclass`` (:63-74) does: it walks the dataclass fields and
+    never looks at the rest, so a ``config.json`` the reference accepts loads here too.  Schedule-typed fields stay
+    text (``str(Schedule)`` is what ``asdict`` writes, config.py:14-15)."""
     config = dict(config)
     name = config.pop('model')
     if name not in _CONFIGS:
         raise ValueError(f'Model {name} is not supported')
     cls = _CONFIGS[name]
     known = {f.name for f in fields(cls)}
-    extra = set(config) - known
-    if extra:
-        raise TypeError(f'unexpected config keys for {name}: {sorted(extra)}')
-    return cls(**config)
+    kw = {k: v for k, v in config.items() if k in known}
+    if 'localization_weight' in kw:
+        kw['localization_weight'] = str(kw['localization_weight'])
+    return cls(**kw)

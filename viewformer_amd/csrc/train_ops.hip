@@ -342,6 +342,12 @@ __global__ void scale_kernel(float* __restrict__ x, const float* __restrict__ su
     const float f = clip / fmaxf(norm, clip);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
 }
+__global__ void scale_gradnorm_kernel(float* __restrict__ x, const float* __restrict__ sumsq, float max_norm, long long n) {
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6); grads *= coef only when coef < 1
+    const float f = max_norm / (sqrtf(*sumsq) + 1e-6f);
+    if (!(f < 1.0f)) return;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
+}
 
 }  // namespace
 
@@ -510,6 +516,16 @@ int vf_clip_by_norm_f32(float* x, int64_t n, float clip, float* scratch1, void* 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n, 256, 1024)), dim3(256), 0, s, x, scratch1, (long long)n);
     hipLaunchKernelGGL(scale_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, s, x, scratch1, clip, (long long)n);
+    return vf_last_status();
+}
+
+int vf_clip_grad_norm_f32(float* x, int64_t n, float max_norm, float* scratch1, void* stream) {
+    if (!x || !scratch1 || n <= 0 || !(max_norm > 0.f)) return VF_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n, 256, 1024)), dim3(256), 0, s, x, scratch1, (long long)n);
+    hipLaunchKernelGGL(scale_gradnorm_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, s, x, scratch1, max_norm, (long long)n);
     return vf_last_status();
 }
 

@@ -11,6 +11,20 @@ from . import geometry
 from . import ops
 
 
+def _frames_for_encode(images, image_size):
+    """The evaluators resize only INSIDE their ``encode`` helper (resize_tf, evaluate_transformer.py:18-19,105;
+    evaluate_transformer_multictx.py:45-47): the caller's frames — and therefore ``ground_truth_images`` (:142) — keep their
+    original resolution.  The reference compares ``shape[-2]`` (the width of an NHWC batch) with image_size.
+    images [B,S,H,W,3] -> [B*S,h,w,3] for the codebook."""
+    B, S = images.shape[:2]
+    flat = images.reshape(B * S, *images.shape[2:])
+    if images.shape[-2] != image_size and images.shape[-3] != image_size:
+        if images.dtype != torch.uint8:
+            raise TypeError('frames of another size than config.image_size must be uint8 (data/_common.py:19-45 resizes uint8)')
+        flat = ops.resize_u8(flat, image_size)
+    return flat
+
+
 def generate_batch_predictions(transformer_model, codebook_model, images, cameras, return_codes: bool = False,
                                fused_passes: bool = True):
     """``fused_passes``: run the generation pass and the localization pass as one twin-view pass
@@ -27,13 +41,9 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
 
     B, S = images.shape[:2]
     t = transformer_model.config.token_image_size
-    if images.shape[2] != codebook_model.config.image_size:                 # resize_tf, evaluate_transformer.py:18-19,105
-        if images.dtype != torch.uint8:
-            raise TypeError('frames of another size than config.image_size must be uint8 (data/_common.py:19-45 resizes uint8)')
-        images = ops.resize_u8(images.reshape(B * S, *images.shape[2:]), codebook_model.config.image_size)
-        images = images.view(B, S, *images.shape[1:])
+    frames = _frames_for_encode(images, codebook_model.config.image_size)       # resize_tf inside encode(), :105
     # encode every view, target included, exactly as the reference does (:114-116)
-    codes = codebook_model.encode(images.reshape(B * S, *images.shape[2:]))[-1]
+    codes = codebook_model.encode(frames)[-1]
     codes = codes.to(torch.int32).view(B, S, t, t)                      # :110,116
 
     pose_last = None
@@ -73,7 +83,7 @@ def codebook_batch_predictions(codebook_model, images):
     dev = codebook_model.device
     images = torch.as_tensor(images).to(dev)
     frames = images
-    if images.dtype == torch.uint8 and images.shape[-2] != codebook_model.config.image_size:      # resize_tf, evaluate_codebook.py:15-16,68
+    if images.dtype == torch.uint8:                                       # resize_tf, evaluate_codebook.py:15-16,68 (identity at image_size)
         frames = ops.resize_u8(images, codebook_model.config.image_size)
     codes = codebook_model.encode(frames)[-1]
     dec = codebook_model.decode_code(codes)

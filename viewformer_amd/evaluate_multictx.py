@@ -10,6 +10,7 @@ import torch
 
 from . import geometry
 from . import ops
+from .evaluate import _frames_for_encode
 
 
 def generate_batch_predictions(transformer_model, codebook_model, images, cameras):
@@ -24,7 +25,7 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
 
     B, S = images.shape[:2]
     t = transformer_model.config.token_image_size
-    codes = codebook_model.encode(images.reshape(B * S, *images.shape[2:]))[-1]
+    codes = codebook_model.encode(_frames_for_encode(images, codebook_model.config.image_size))[-1]     # resize_tf, :45-47
     codes = codes.to(torch.int32).view(B, S, t, t)                      # :53-56
 
     input_ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], transformer_model.mask_token)], 1)   # :61-62

@@ -83,8 +83,10 @@ class MIGT:
             keys += [d + '.weight', d + '.bias']
         for l in lns:
             keys += [l + '.gamma', l + '.beta']
-        if c.use_dynamic_pose_loss and self.use_localization:
-            keys.append('pose_loss_weighting_criterion.pos_ori_weights')      # DynamicLossWeightingCriterion, migt.py:107-113 (training only)
+        if c.use_dynamic_pose_loss:
+            # DynamicLossWeightingCriterion (migt.py:105-112) is built whenever the flag is set (:279-280), localization head or not,
+            # so a checkpoint of such a model always carries the pair; only the training step reads it
+            keys.append('pose_loss_weighting_criterion.pos_ori_weights')
         return keys
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -284,8 +286,14 @@ class MIGT:
             add_streams.append(self._wte[self.localization_token].view(1, 1, d).expand(B, S, d))
             pose_ptr = len(ids_streams) - 1
         NS = len(ids_streams)
-        hf = self._blocks(torch.cat(ids_streams, 1), torch.cat(add_streams, 1), B, NS * S, L,
-                          mask_spec=(-S if NS > 1 else -1)).view(B, NS, S, L, d)
+        if NS > 1 and S == 1:
+            # one view per stream: a branch position 0 sees no main view (j < 0) and its own tile, the main view sees itself — every
+            # (scene, stream) is an independent 1-view sequence.  The kernels' STREAMS encoding (-S <= -2) cannot say S = 1 (-1 is
+            # plain block-causal, where the streams would see each other), so run them as B*NS scenes of one view: same rows exactly.
+            hf = self._blocks(torch.cat(ids_streams, 1), torch.cat(add_streams, 1), B * NS, 1, L, mask_spec=-1).view(B, NS, S, L, d)
+        else:
+            hf = self._blocks(torch.cat(ids_streams, 1), torch.cat(add_streams, 1), B, NS * S, L,
+                              mask_spec=(-S if NS > 1 else -1)).view(B, NS, S, L, d)
         out = dict(hidden_states=[hf[:, s] for s in range(NS)])
         M = B * S * L
         hi = hf[:, img_ptr].contiguous().view(M, d)

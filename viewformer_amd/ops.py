@@ -204,6 +204,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     ``gn_part``: fp32 [Nimg][halo_gn_slots(Hout, Wout)][32][2] buffer that receives the GroupNorm partial statistics of the
     output (halo kernels only; reduce with groupnorm_finalize)."""
     lib = _lib.load()
+    if not 0 <= M < 2 ** 31 or max(Cin, Cout, Hin, Win, Hout, Wout, batch) >= 2 ** 31:
+        # vf_igemm_args carries 32-bit row / channel counts (byte offsets inside the kernels are 64-bit): refuse instead of wrapping
+        raise _lib.VfError(f'igemm: M = {M} rows do not fit the int32 fields of vf_igemm_args — split the launch '
+                           '(VQGAN(max_images_per_call=...))')
     a = VfIgemmArgs()
     a.x = x.data_ptr()
     a.w_packed = w_packed.data_ptr()
@@ -460,7 +464,9 @@ def resize_u8(images, image_size, method=None):
     if method not in (None, 'nearest', 'bilinear'):
         raise ValueError("method must be None, 'nearest' or 'bilinear'")
     n, H, W, C = images.shape
-    if H == image_size:
+    # resize() tests the NHWC batch's shape[-2] (= W), then resize_th() tests the NCHW tensor's shape[-2] (= H): either match
+    # returns the frames untouched (data/_common.py:26-27,54-55); the enlarge/shrink choice below uses H (:34-37)
+    if W == image_size or H == image_size:
         return images
     if method is None:
         method = 'nearest' if image_size > H else 'bilinear'

@@ -40,15 +40,12 @@ from . import sharding
 from .migt import MIGT
 
 
-def parse_schedule(s):
-    """'1', '5.' or 'cosine(a,b,N)' -> callable(step) (viewformer/utils/schedules.py:72-112,194-201)"""
-    s = str(s).strip()
-    m = re.fullmatch(r'cosine\(([^,]+),([^,]+),([^)]+)\)', s)
-    if m:
-        a, b, n = float(m.group(1)), float(m.group(2)), float(m.group(3))
-        return lambda t: b + (a - b) * 0.5 * (math.cos(min(1.0, t / n) * math.pi) + 1.0)
-    v = float(s)
-    return lambda t: v
+def parse_schedule(s, total_steps=None):
+    """'1', '5.', 'linear(a,b[,N])', 'cosine(a,b[,N])', 'warmup(<inner>,W)' -> callable(step) with ``is_zero()``
+    (viewformer/utils/schedules.py:72-248; a missing N is the model's total_steps, migt.py:268)"""
+    from .schedules import parse
+    sch = parse(s)
+    return sch.with_total_steps(total_steps) if total_steps is not None else sch
 
 
 def learning_rate(step, init_lr, total_steps, warmup_steps):
@@ -95,7 +92,7 @@ class MIGTTrainer:
         self.warmup_steps, self.b1, self.b2, self.eps = warmup_steps, beta1, beta2, eps
         self.group = process_group
         self.step_count = 0                          # optimizer.iterations == model._train_counter
-        self.loc_weight = parse_schedule(cfg.localization_weight)
+        self.loc_weight = parse_schedule(cfg.localization_weight, cfg.total_steps)
         self._layout()
         self._bind()
 
@@ -301,6 +298,9 @@ class MIGTTrainer:
         skip = c.n_loss_skip
         if not 0 <= skip < S:
             raise ValueError('n_loss_skip must be < sequence length')
+        if S < 2:
+            raise ValueError('train_step needs sequences of at least 2 views (the STREAMS attention mask encodes the stream '
+                             'length as -S <= -2; a 1-view sequence has nothing to condition on)')
         self.flat_g.zero_()
 
         # ---- forward with saved activations --------------------------------------------------------------

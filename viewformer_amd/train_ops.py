@@ -130,6 +130,12 @@ def clip_by_norm_(x, clip, scratch1):
     return x
 
 
+def clip_grad_norm_(x, max_norm, scratch1):
+    """global-norm clip of a flat gradient buffer (torch.nn.utils.clip_grad_norm_ semantics)"""
+    check(_lib.load().vf_clip_grad_norm_f32(_p(_f32(x)), x.numel(), max_norm, _p(scratch1), _stream()), 'vf_clip_grad_norm_f32')
+    return x
+
+
 def attn_fwd_lse(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1, drop=(0.0, 0, 0)):
     """forward attention that also returns the per-query log-sum-exp [B,H,T] the flash backward needs;
     ``drop`` = (rate, seed, site) applies attn_dropout to softmax(w) with the counter-based mask of vf_common.h"""

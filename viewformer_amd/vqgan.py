@@ -300,7 +300,8 @@ class VQGAN:
         return x.view(n, H, W, self.config.out_ch)
 
     def _chunks(self, n):
-        m = self.max_images_per_call
+        # a launch addresses its rows (images x pixels) with 32-bit counts: keep images * image_size^2 below 2^31
+        m = max(1, min(self.max_images_per_call, (2 ** 31 - 1) // max(1, self.config.image_size ** 2)))
         return [(i, min(n, i + m)) for i in range(0, n, m)]
 
     # ------------------------------------------------------------------ public protocol

@@ -406,6 +406,11 @@ class VQGANTrainer:
 
     def apply_gradients(self):
         """torch.optim.Adam(lr, betas=(0.5, 0.9)), vqgan_th.py:427-429"""
+        clip = float(getattr(self.cfg, "gradient_clip_val", 0.0) or 0.0)
+        if clip > 0:                                 # pl.Trainer(gradient_clip_val=...), train_codebook_th.py:69: global 2-norm clip
+            if getattr(self, '_clip_scratch', None) is None:
+                self._clip_scratch = torch.zeros(1, dtype=torch.float32, device=self.flat_g.device)
+            T.clip_grad_norm_(self.flat_g, clip, self._clip_scratch)
         self.step_count += 1
         t = self.step_count
         c2 = math.sqrt(1.0 - self.b2 ** t)

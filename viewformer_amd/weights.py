@@ -202,7 +202,7 @@ def make_migt_weights(cfg: MIGTConfig = None, seed: int = 0, jitter_norm: bool =
     ln('ln_f')
     dense('pose_criterion.pose_classifier.c_fc', d, 2 * d)
     dense('pose_criterion.pose_classifier.c_proj', 2 * d, 7)
-    if cfg.use_dynamic_pose_loss and cfg.use_localization:
+    if cfg.use_dynamic_pose_loss:
         sd['pose_loss_weighting_criterion.pos_ori_weights'] = np.array([0.0, -3.0], dtype=np.float32)     # migt.py:113
     return sd
 
