@@ -2,6 +2,7 @@
 The reference transformer is TensorFlow-only and cannot run here: parity unpinned,
 these are the known-answer properties derivable from branching_attention.py / migt.py."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import TINY_MIGT
@@ -122,3 +123,78 @@ def test_relative_cameras_round_trip_and_reduce():
     assert (n[..., 3] >= 0).all() and torch.allclose(n[..., 3:].norm(dim=-1), torch.ones(3, 5, dtype=torch.float64))
     r = mg.reduce_cameras(n.unsqueeze(2).expand(3, 5, 16, 7), -2)
     assert torch.allclose(r, n, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the INDEPENDENT fp64 numpy transliteration (oracle/migt_numpy64.py: no code shared with migt_oracle.py,
+# written op for op from migt.py:338-455 + branching_attention.py:82-126) against the torch restatement the GPU tests use.
+def _np_inputs(ids, cams):
+    return ids.numpy(), cams.numpy().astype(np.float32)
+
+
+def test_independent_numpy64_transliteration_agrees_on_inference_graphs():
+    from oracle import migt_numpy64 as n64
+    for loc in (False, True):
+        cfg, sd, ids, cams = _setup(loc, seed=4, S=5)
+        i_np, c_np = _np_inputs(ids, cams)
+        # generation pass: all S poses
+        a = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)
+        b = n64.migt_call(sd, cfg, dict(input_ids=i_np, poses=c_np))
+        assert np.abs(a['logits'].numpy() - b['logits']).max() < 1e-10
+        assert np.abs(a['hidden_states'][0].numpy() - b['hidden_states'][0].reshape(a['hidden_states'][0].shape)).max() < 1e-10
+        if loc:
+            # localization pass: S - 1 poses, LOC embedding on the last view (migt.py:387-390)
+            a = mg.migt_forward(sd, cfg, ids, cams[:, :-1], dtype=torch.float64)
+            b = n64.migt_call(sd, cfg, dict(input_ids=i_np, poses=c_np[:, :-1]))
+            assert np.abs(a['pose_prediction'].numpy() - b['pose_prediction']).max() < 1e-10
+            assert np.abs(a['logits'].numpy() - b['logits']).max() < 1e-10
+            # multi-context evaluator graph: MASK stream + LOC stream (evaluate_transformer_multictx.py:60-73)
+            q_cam = cams[:, -1:].expand(-1, ids.shape[1], -1).contiguous()
+            q_tok = ids[:, -1:].expand(-1, ids.shape[1], -1, -1).contiguous()
+            a = mg.migt_forward(sd, cfg, ids, cams, localization_tokens=q_tok, output_poses=q_cam, dtype=torch.float64)
+            b = n64.migt_call(sd, cfg, dict(input_ids=i_np, poses=c_np, localization_tokens=q_tok.numpy(), output_poses=q_cam.numpy()))
+            assert len(b['hidden_states']) == 3
+            assert np.abs(a['logits'].numpy() - b['logits']).max() < 1e-10
+            assert np.abs(a['pose_prediction'].numpy() - b['pose_prediction']).max() < 1e-10
+
+
+@pytest.mark.parametrize('opts', [dict(), dict(label_smoothing=0.1, image_generation_weight=0.7),
+                                  dict(use_dynamic_pose_loss=True, localization_weight='cosine(0,2,10)'),
+                                  dict(localization_weight='0')])
+def test_independent_numpy64_transliteration_agrees_on_training_losses(opts):
+    """the 2-/3-stream training graph and every loss term (migt.py:416-448) — two restatements, one number"""
+    from oracle import migt_numpy64 as n64
+    from oracle import train_oracle as to
+    kw = dict(TINY_MIGT, pose_multiplier=0.2, n_loss_skip=1, localization_weight='1')
+    kw.update(opts)
+    cfg = MIGTConfig(**kw)
+    sd = make_migt_weights(cfg, seed=9, std=0.08)
+    g = np.random.Generator(np.random.PCG64(5))
+    ids = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(3, 4, 4, 4)))
+    _, cams = synthetic_scene_batch(3, 4, 8, 6)
+    cams = torch.from_numpy(cams)
+    rpm = np.array([1.3, 0.6, 1.0])
+    sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    total, met = to.losses(sd_t, cfg, cams, ids, step=3, pose_factors=torch.from_numpy(rpm))
+    b = n64.migt_call(sd, cfg, dict(input_ids=ids.numpy(), poses=cams.numpy()), compute_losses=True, train_counter=3,
+                      random_pose_multiplier=rpm)
+    assert abs(float(total) - float(np.mean(b['loss']))) < 1e-10 * max(1.0, abs(float(total)))      # reduce_mean(loss), migt.py:476
+    assert abs(float(met['ce_loss']) - float(b['ce_loss'].mean())) < 1e-10
+    if cfg.use_localization:
+        assert abs(float(met['pose_pos_loss']) - float(b['pose_pos_loss'].mean())) < 1e-10
+        assert abs(float(met['pose_ori_loss']) - float(b['pose_ori_loss'].mean())) < 1e-10
+        assert abs(met['localization_weight'] - b['localization_weight']) < 1e-12
+    else:
+        assert 'pose_prediction' not in b
+
+
+def test_independent_numpy64_camera_frames_agree():
+    from oracle import migt_numpy64 as n64
+    _, cams = synthetic_scene_batch(3, 5, 8, 2)
+    c = torch.from_numpy(cams).double()
+    rel, tr = mg.to_relative_cameras(c)
+    rel2, tr2 = n64.to_relative_cameras(cams.astype(np.float64))
+    assert np.abs(rel.numpy() - rel2).max() < 1e-12 and np.abs(tr.numpy() - tr2).max() == 0
+    assert np.abs(mg.normalize_cameras(rel).numpy() - n64.normalize_cameras(rel2)).max() < 1e-12
+    x = torch.randn(2, 3, 16, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    assert np.abs(mg.reduce_cameras(x, -2).numpy() - n64.reduce_cameras(x.numpy(), -2)).max() < 1e-12
