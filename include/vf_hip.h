@@ -141,6 +141,16 @@ int vf_vq_pack_codebook_f32(const float* E /* [D][Kc] */, float* dst, int D, int
 int vf_colsumsq_f32(const float* E /* [D][Kc] */, float* e_sq /* [Kc] */, int D, int Kc, void* stream);
 int vf_vq_argmin_f32(const float* z, const float* E_packed, const float* e_sq, int64_t M, int D, int Kc,
                      int64_t* idx, void* stream);
+/* The same lookup — same contract, same indices bit for bit (csrc/vq_filter.hip) — as a 16-bit candidate filter on the fp16 matrix
+ * pipe (16x the f32 MFMA rate) followed by an exact fp32 re-rank of the few codes inside a proven error window: dist of every
+ * candidate is re-evaluated in vf_vq_argmin_f32's own arithmetic, rows the filter cannot certify are scanned exactly.  D must be 256,
+ * Kc % 32 == 0, Kc <= 1024 (VF_ERR_UNSUPPORTED otherwise: call vf_vq_argmin_f32).  packed: vf_vq_filter_packed_bytes(D, Kc) bytes
+ * written by vf_vq_filter_pack from the reference's `embeddings` [D][Kc].  stats4 (NULL or 4 zero-initialised uint32): rows decided
+ * by the filter alone / rows re-ranked / exact distances evaluated in the re-rank / rows scanned over the whole codebook. */
+size_t vf_vq_filter_packed_bytes(int D, int Kc);
+int vf_vq_filter_pack(const float* E /* [D][Kc] */, void* dst, int D, int Kc, void* stream);
+int vf_vq_argmin_filtered_f32(const float* z, const void* packed, int64_t M, int D, int Kc, int64_t* idx, uint32_t* stats4,
+                              void* stream);
 /* embed_code (utils_th.py:70-72): out[m][:] = E[:, idx[m]]  (NHWC rows) */
 int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, float* out /* [M][D] */,
                            int64_t M, int D, int Kc, void* stream);

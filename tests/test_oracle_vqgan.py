@@ -168,3 +168,21 @@ def test_resize_oracle_matches_reference_golden():
         dst, meth = (int(v) for v in g[f'meta{i}'])
         got = vq.resize_u8(g[f'in{i}'], dst, None if meth < 0 else ['nearest', 'bilinear'][meth])
         assert got.dtype == np.uint8 and np.array_equal(got, g[f'out{i}']), i
+
+
+def test_oracle_matches_reference_codes_on_a_slice_of_the_20k_golden():
+    """the CPU restatement against the reference's own recorded tokens beyond the 4-image golden: the first 16 images (1024
+    tokens) of tests/golden/vqgan_codes_20k.npz (make_codes_golden.py) — the GPU test covers all 20 480"""
+    from conftest import load_golden
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.weights import make_vqgan_weights, synthetic_scene_batch
+    g = load_golden('vqgan_codes_20k.npz')
+    cfg = VQGANConfig()
+    sd = make_vqgan_weights(cfg, seed=int(g['seed']), codebook_scale=float(g['codebook_scale']))
+    frames, _ = synthetic_scene_batch(int(g['n_scenes']), int(g['n_views']), 128, seed=int(g['input_seed']))
+    x = vq.preprocess_u8(torch.from_numpy(frames.reshape(-1, 128, 128, 3)[:16]))
+    codes = vq.encode(sd, cfg, x)[-1].numpy()
+    ref = g['codes'][:16].astype(np.int64)
+    bad = codes != ref
+    assert bad.sum() == 0 or (g['margin'][:16][bad] < 1e-4).all(), (int(bad.sum()), g['margin'][:16][bad])
+    assert (g['runner_up'] != g['codes']).all() and g['codes'].size == 20480 and (g['margin'] >= 0).all()

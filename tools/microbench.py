@@ -79,6 +79,45 @@ def vq(M=64 * 448):
     print(f'vq_argmin M={M}: {ms:.4f} ms  {2.0 * M * 256 * 1024 / ms / 1e9:.1f} TF  {by / ms / 1e6:.1f} GB/s algorithmic')
 
 
+def vqf(M=64 * 896, zscale=0.18):
+    """filtered lookup at the bench's launch size (896 images); z at the encoder's magnitude (|z| ~ 3)"""
+    z = torch.randn(M, 256, device=dev) * zscale
+    E = (torch.rand(256, 1024, device=dev) * 2 - 1) * (3 ** 0.5) * 0.05
+    blob = ops.vq_filter_pack(E)
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.vq_argmin_filtered(z, blob, 256, 1024, stats=st)
+    ms = timeit(lambda: ops.vq_argmin_filtered(z, blob, 256, 1024), iters=20)
+    by = M * 256 * 4 + 256 * 1024 * 4 + M * 8
+    s = st.cpu().tolist()
+    print(f'vq_filtered M={M}: {ms * 1e3:.1f} us  {2.0 * M * 256 * 1024 / ms / 1e9:.1f} TF (fp16 filter)  {by / ms / 1e6:.1f} GB/s algorithmic = '
+          f'{by / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s; certified {s[0]} reranked {s[1]} exact evals {s[2]} scanned {s[3]}')
+
+
+def vqf_stamps(M=64 * 896, zscale=0.18):
+    """phase timeline of the filtered lookup (library built with -DVQF_STAMPS): s_memtime at phase boundaries, wave 0 of every workgroup"""
+    import numpy as np
+    z = torch.randn(M, 256, device=dev) * zscale
+    E = (torch.rand(256, 1024, device=dev) * 2 - 1) * (3 ** 0.5) * 0.05
+    blob = ops.vq_filter_pack(E)
+    st = torch.zeros(4 + 1024 * 20, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        st.zero_()
+        ops.vq_argmin_filtered(z, blob, 256, 1024, stats=st)
+    torch.cuda.synchronize()
+    t = st[4:].cpu().numpy().view(np.uint64).reshape(1024, 10)[:min(1024, (M + 127) // 128)].astype(np.float64)
+    # order of events: 0 start, 1 A ready, 2 main loop done, 6 barrier passed, 7 row max done, 8 window flags done, 3 pairs queued,
+    # 9 first pass staged, 4 re-rank done, 5 end
+    order = [0, 1, 2, 6, 7, 8, 3, 9, 4, 5]
+    names = ['loadA', 'main', 'barrier', 'rowmax', 'flags', 'queue', 'stage1', 'rerank', 'final']
+    print(f'M={M}: {len(t)} workgroups')
+    for name, a, b in zip(names, order[:-1], order[1:]):
+        ok = (t[:, a] > 0) & (t[:, b] > 0)
+        col = (t[ok, b] - t[ok, a])
+        if len(col):
+            print('  %-8s n %4d  min %7.0f  median %7.0f  p90 %7.0f  max %7.0f' % (name, len(col), col.min(), np.median(col), np.percentile(col, 90), col.max()))
+    print('  per-WG total: median %.0f max %.0f' % (np.median(t[:, 5] - t[:, 0]), (t[:, 5] - t[:, 0]).max()))
+
+
 def attn(B=32, H=12, S=8, L=64, bf16=False, x6=False):
     d, T = H * 64, S * L
     qkv = torch.randn(B * T, 3 * d, device=dev) * 0.3
@@ -137,7 +176,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), vq=vq, attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

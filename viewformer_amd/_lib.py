@@ -50,6 +50,9 @@ EXPORTS = {
     'vf_vq_pack_codebook_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_colsumsq_f32': (c_int, [P, P, c_int, c_int, P]),
     'vf_vq_argmin_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),
+    'vf_vq_filter_packed_bytes': (c_size_t, [c_int, c_int]),
+    'vf_vq_filter_pack': (c_int, [P, P, c_int, c_int, P]),
+    'vf_vq_argmin_filtered_f32': (c_int, [P, P, c_int64, c_int, c_int, P, P, P]),
     'vf_gather_transpose_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, P]),
     'vf_upsample2_bwd_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'vf_groupnorm_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -115,6 +115,13 @@ __device__ __forceinline__ unsigned vf_xcd_bid() {
 #endif
 }
 
+// sum of squares of four consecutive z values with a FIXED association and explicit fmas (no contraction freedom): the unit of the
+// codebook lookup's zz = sum z^2, shared by the exact kernel (vq_argmin.hip) and the re-rank of the filtered one (vq_filter.hip) so
+// that both produce the same distance bit for bit
+__device__ __forceinline__ float vf_vq_sq4(const f32x4 v) {
+    return __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
+}
+
 // shared host helper (defined in igemm_f32.hip): pack [taps][K][N] into the fragment-major B layout
 int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long long sk, long long sn, long long st,
                    int BN, int batch, long long src_bstride, hipStream_t stream);

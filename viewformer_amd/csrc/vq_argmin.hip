@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = areg[q];
-            if (first_tile) zpart[q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (first_tile) zpart[q] += vf_vq_sq4(v);
             *reinterpret_cast<f32x4*>(a_dst + (a_row0 + 32 * q) * A_LD + a_col4 * 4) = v;
         }
         float* b_dst = Bs + buf * (CK * BN);

@@ -379,6 +379,38 @@ def vq_argmin(z_rows, E_packed, e_sq, D, Kc):
     return idx
 
 
+def vq_filter_supported(D, Kc):
+    """shape rules of the filtered lookup (vf_vq_argmin_filtered_f32): otherwise call vq_argmin (same result, f32 MFMA)"""
+    return int(_lib.load().vf_vq_filter_packed_bytes(D, Kc)) > 0
+
+
+def vq_filter_pack(E):
+    """reference ``embeddings`` [D][Kc] -> the filtered lookup's blob (fp16 fragment tiles, fp32 transpose, e_sq, window constants)"""
+    lib = _lib.load()
+    E = _f32(E).contiguous()
+    D, Kc = E.shape
+    n = int(lib.vf_vq_filter_packed_bytes(D, Kc))
+    if n == 0:
+        raise _lib.VfError(f'vq_filter_pack: unsupported codebook shape D={D}, Kc={Kc} (need D == 256, Kc % 32 == 0, Kc <= 1024)')
+    out = torch.empty(n, dtype=torch.uint8, device=E.device)
+    check(lib.vf_vq_filter_pack(_p(E), _p(out), D, Kc, _stream()), 'vf_vq_filter_pack')
+    return out
+
+
+def vq_argmin_filtered(z_rows, blob, D, Kc, stats=None):
+    """codebook lookup through the fp16 candidate filter + exact fp32 re-rank: the same indices as vq_argmin, bit for bit.
+    ``stats``: optional zero-initialised int32[4] device tensor receiving (filter-certified rows, re-ranked rows, exact distance
+    evaluations, fully scanned rows)"""
+    lib = _lib.load()
+    z_rows = _f32(z_rows)
+    M = z_rows.numel() // D
+    idx = torch.empty(M, dtype=torch.int64, device=z_rows.device)
+    check(lib.vf_vq_argmin_filtered_f32(_p(z_rows), _p(_chk(blob, torch.uint8, 'blob')), M, D, Kc, _p(idx),
+                                        _p(_chk(stats, torch.int32, 'stats')) if stats is not None else None, _stream()),
+          'vf_vq_argmin_filtered_f32')
+    return idx
+
+
 def codebook_gather(E, idx, D, Kc):
     lib = _lib.load()
     idx = _chk(idx, torch.int64, 'codes').contiguous()

@@ -30,7 +30,7 @@ class _Conv:
 
 class VQGAN:
     def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 1024,
-                 decoder_precision: str = 'f32', conv_arith: str = 'x3h'):
+                 decoder_precision: str = 'f32', conv_arith: str = 'x3h', lookup: str = 'filter'):
         """``conv_arith`` picks how the fp32 3x3 convolutions are evaluated: 'f32' = native f32 MFMA, 'x6' = the
         fp32-EQUIVALENT six-term split-bf16 kernel (same error against fp64 as the f32 MFMA, ~1.6x faster; see
         csrc/conv3_halo_x6.hip), 'x3h' = x6 everywhere except the stride-1 / upsample 3x3 convolutions, which run the
@@ -41,7 +41,8 @@ class VQGAN:
         exact fp32 so token indices stay bit-exact."""
         self.config = config or VQGANConfig()
         assert data_format in ('NCHW', 'NHWC')
-        assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6', 'x3h')
+        assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6', 'x3h') and lookup in ('filter', 'exact')
+        self.lookup = lookup
         self.decoder_precision = decoder_precision
         self.conv_arith = conv_arith
         self.data_format = data_format
@@ -171,6 +172,10 @@ class VQGAN:
         conv('post_quant_conv')
         self._E = dev_t('quantize.embeddings')                      # [D][Kc]
         self._E_packed, self._e_sq = ops.vq_pack_codebook(self._E)
+        # the filtered lookup (fp16 candidate filter + exact re-rank: identical indices, ~10x less matrix time) where its shape
+        # rules hold; the exact f32-MFMA kernel otherwise.  ``lookup='exact'`` forces the latter (tests cross-check the two).
+        self._E_filter = (ops.vq_filter_pack(self._E) if self.lookup == 'filter' and ops.vq_filter_supported(*self._E.shape)
+                          else None)
         torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ building blocks (NHWC rows)
@@ -290,7 +295,10 @@ class VQGAN:
         x, h, w = self._run_plan(self._enc_plan, img.contiguous(), n, H, W)
         z = self._conv1(x, 'quant_conv', n * h * w)                     # vqgan_th.py:381
         cfg = self.config
-        codes = ops.vq_argmin(z, self._E_packed, self._e_sq, cfg.embed_dim, cfg.n_embed)
+        if self._E_filter is not None:
+            codes = ops.vq_argmin_filtered(z, self._E_filter, cfg.embed_dim, cfg.n_embed)
+        else:
+            codes = ops.vq_argmin(z, self._E_packed, self._e_sq, cfg.embed_dim, cfg.n_embed)
         return z, codes.view(n, h, w)
 
     def _decode_rows(self, q_rows, n, h, w):
