@@ -186,6 +186,15 @@ int vf_attn_blockcausal_bf16(const void* q, const void* k, const void* v, int in
                             void* out, int out_bf16 /* 0: fp32 out, 1: bf16 out (ldo in elements) for a bf16-GEMM consumer */, int B,
                             int H, int T, int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
                             void* stream);
+/* the bf16 arm's current kernel (csrc/attention_lp.hip): same contract and rounding points as vf_attn_blockcausal_bf16; a wave owns 64
+ * queries as two MFMA tiles sharing every K / V fragment, 5 instead of 8 VALU per score in the softmax */
+int vf_attn_blockcausal_bf16_v2(const void* q, const void* k, const void* v, int in_bf16, void* out, int out_bf16, int B, int H, int T, int L,
+                                int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view, void* stream);
+/* the same kernel with OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 (BASELINE configs[4] "fp8 MFMA attention"): Q, K, V clamped to
+ * +-448 and rounded to e4m3, probabilities carried at 2^8 and rounded to e4m3, fp32 sums and softmax; tolerances in
+ * tests/test_hip_fp8.py (the reference's un-scaled logits, branching_attention.py:7, are what makes this arm loose) */
+int vf_attn_blockcausal_fp8(const void* q, const void* k, const void* v, int in_bf16, void* out, int out_bf16, int B, int H, int T, int L,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view, void* stream);
 /* same contract, fp32-EQUIVALENT on the bf16 pipe (x6: every operand split into three bf16 pieces, six partial products per
  * fp32 product, fp32 softmax) — the default attention of the fp32 transformer arm */
 int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float* out,

@@ -1,0 +1,155 @@
+"""GPU: the fp8 attention arm (BASELINE configs[4] "fp8 MFMA attention": csrc/attention_lp.hip MODE 1, OCP e4m3 operands on
+v_mfma_f32_32x32x16_fp8_fp8, fp32 softmax) and the large-batch all-images evaluator loop that uses it.
+
+STATED TOLERANCES.  e4m3 carries 3 mantissa bits (relative rounding error up to 2^-4); the reference's logits are UN-SCALED
+(branching_attention.py:7: no 1/sqrt(d)), so a score q.k of magnitude s carries an absolute error ~ s * 2^-4 / sqrt(d_h) * sqrt(2)
+into the exponent.  Measured on the kernel (scores up to +-8): attention output within 6e-2 of max|out|; bounds asserted below."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+FP8_ATTN_TOL = 1.5e-1        # max |out - out_f32| / max |out_f32| for one attention call, |score| <= ~8 (measured 5e-2 .. 1.1e-1)
+FP8_LOGIT_TOL_REL = 1.5e-1   # 12-layer MIGT, bf16 dense layers + fp8 attention: max |logit err| / max |logit|
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _report(**kw):
+    try:
+        with open(os.path.join(REPO, 'gpurun_out', 'parity_report.jsonl'), 'a') as f:
+            f.write(json.dumps(kw) + '\n')
+    except OSError:
+        pass
+    print(json.dumps(kw))
+
+
+@pytest.mark.parametrize('B,H,S,L,mode', [(2, 2, 4, 16, 'causal'), (1, 12, 7, 64, 'causal'), (1, 2, 5, 48, 'causal'),
+                                          (2, 3, 8, 64, 'twin'), (1, 2, 3, 64, 'streams'), (2, 12, 10, 64, 'streams'), (1, 4, 21, 64, 'twin')])
+def test_attention_fp8_all_mask_modes(dev, B, H, S, L, mode):
+    """fp8 attention against the SAME contract in exact fp32 (vf_attn_blockcausal_f32, itself pinned to the oracle): every mask mode;
+    skipping masked tiles == the dense -1e4 form bit for bit; the bf16 kernel of the same file for scale"""
+    from viewformer_amd import ops
+    d = H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = {'causal': -1, 'twin': S - 2, 'streams': -S}[mode]
+    qkv = _rand((B * T, 3 * d), 71, 0.35).to(dev)
+    ref = torch.empty((B * T, d), device=dev)
+    ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], ref, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, spec)
+    errs = {}
+    for arm in ('fp8', 'bf16'):
+        outs = []
+        for skip in (True, False):
+            out = torch.empty((B * T, d), device=dev)
+            ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, skip, spec,
+                                 bf16=True, fp8=arm == 'fp8')
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (arm, mode)
+        errs[arm] = ((outs[0] - ref).abs().max() / ref.abs().max()).item()
+    _report(test='attention_fp8', mode=mode, B=B, H=H, S=S, L=L, rel_err_fp8=errs['fp8'], rel_err_bf16=errs['bf16'])
+    assert errs['fp8'] < FP8_ATTN_TOL and errs['bf16'] < 1.5e-2
+    assert errs['fp8'] > errs['bf16']                                  # it IS the coarser arm (guards a silent fall-through to bf16)
+
+
+def test_attention_fp8_large_unscaled_scores_and_range(dev):
+    """the hazard SURVEY §7 flags: un-scaled logits.  Scores of +-60 (q, k of norm ~8) — the softmax is nearly one-hot; the output must
+    stay finite and the arg-max key must carry the weight.  Values beyond e4m3's range (448) are clamped, not turned into NaN."""
+    from viewformer_amd import ops
+    B, H, S, L = 1, 2, 3, 64
+    d, T = H * 64, S * L
+    qkv = _rand((B * T, 3 * d), 5, 1.0).to(dev)
+    ref, out = torch.empty((B * T, d), device=dev), torch.empty((B * T, d), device=dev)
+    ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], ref, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, -1)
+    ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, -1, bf16=True, fp8=True)
+    assert torch.isfinite(out).all()
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    _report(test='attention_fp8_large_scores', rel_err=err)
+    assert err < 0.6                                                    # near-one-hot softmax: a flipped winner moves a whole row
+    big = qkv.clone()
+    big[:7, :d] = 1.0e4                                                 # V beyond 448
+    big[3, d:2 * d] = -1.0e4                                            # a Q row beyond -448
+    ops.attn_blockcausal(big[:, d:2 * d], big[:, 2 * d:], big[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 1.0, True, -1, bf16=True, fp8=True)
+    assert torch.isfinite(out).all() and out.abs().max() <= 448.0 * 1.01
+
+
+def test_migt_fp8_attention_arm_and_allimg_loop(dev, full_vq):
+    """full-size transformer with bf16 dense layers + fp8 attention against the fp64 oracle (stated tolerance), then the all-images
+    evaluator loop (evaluate_transformer_multictx_allimg.py:15-63: transformer batch 128, decode batch 64) on it"""
+    from oracle import migt_oracle as mg
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    cfg = MIGTConfig(sequence_size=10, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05)    # README.md:250-264 (CO3D)
+    sd = make_migt_weights(cfg, seed=0)
+    g = np.random.Generator(np.random.PCG64(31))
+    B, S = 2, 10
+    ids = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 14)
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    gen_ids = torch.cat([ids[:, :-1], torch.full_like(ids[:, :1], cfg.n_embeddings)], 1)
+    ref = mg.migt_forward(sd, cfg, gen_ids, cams, dtype=torch.float64)['logits'][:, -1]
+    errs = {}
+    for att in ('bf16', 'fp8'):
+        m = MIGT(cfg, precision='bf16', attention=att).load_state_dict(sd).to(dev)
+        lg = m(dict(input_ids=gen_ids.to(dev), poses=cams.to(dev)), last_view_logits_only=True)['logits_last']
+        errs[att] = ((lg.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    _report(test='migt_fp8_attention', rel_logit_err_fp8=errs['fp8'], rel_logit_err_bf16=errs['bf16'], logit_max=float(ref.abs().max()))
+    assert errs['fp8'] < FP8_LOGIT_TOL_REL and errs['bf16'] < 3e-2
+    with pytest.raises(ValueError):
+        MIGT(cfg, precision='f32', attention='fp8')
+
+
+def test_allimg_loop_matches_per_scene_multictx_calls(dev, tiny_vq):
+    """evaluate_allimg.evaluate_sequence (batches of 128 scenes / 64 decodes) == the multi-context evaluator called scene by scene;
+    batch splitting (run_with_batchsize) does not change a single code or pixel"""
+    from viewformer_amd import evaluate_allimg as ea
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.evaluate_multictx import generate_batch_predictions as multictx
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    vcfg, vsd, _ = tiny_vq
+    mcfg = MIGTConfig(n_embeddings=vcfg.n_embed, n_head=2, d_model=128, n_layer=2, token_image_size=vcfg.image_size // vcfg.stride, sequence_size=4,
+                      localization_weight='1', pose_multiplier=0.2)
+    msd = make_migt_weights(mcfg, seed=4, std=0.08)
+    vq = VQGAN(vcfg, data_format='NHWC').load_state_dict(vsd).to(dev)
+    tr = MIGT(mcfg).load_state_dict(msd).to(dev)
+    F = 9
+    frames, cams = synthetic_scene_batch(1, F, vcfg.image_size, seed=6)
+    ctx = [4, 0, 7]
+    res = ea.evaluate_sequence(tr, vq, frames[0], cams[0], ctx)
+    S = len(ctx) + 1
+    assert tuple(res['generated_images'].shape) == (F, S, vcfg.image_size, vcfg.image_size, 3) and res['generated_images'].dtype == torch.uint8
+    assert res['eval_frames'] == [1, 2, 3, 5, 6, 8]
+    for i in (0, 3, 8):
+        sel = ctx + [i]
+        one = multictx(tr, vq, frames[:, sel], cams[:, sel])
+        assert torch.equal(one['generated_codes'][0], res['generated_codes'][i])
+        assert torch.equal(one['generated_images'][0], res['generated_images'][i])
+        assert torch.allclose(one['generated_cameras'][0], res['generated_cameras'][i], atol=1e-6)
+    old = ea.TRANSFORMER_BATCH, ea.DECODE_BATCH
+    try:
+        ea.TRANSFORMER_BATCH, ea.DECODE_BATCH = 4, 2                    # 9 scenes -> 3 transformer batches, 5 decode batches
+        res2 = ea.evaluate_sequence(tr, vq, frames[0], cams[0], ctx)
+    finally:
+        ea.TRANSFORMER_BATCH, ea.DECODE_BATCH = old
+    assert torch.equal(res2['generated_codes'], res['generated_codes']) and torch.equal(res2['generated_images'], res['generated_images'])
+    chain = ea.evaluate_sequence(tr, vq, frames[0], cams[0], ctx, keep_last_frame=True)
+    assert tuple(chain['generated_codes'].shape) == tuple(res['generated_codes'].shape)
+    assert torch.equal(chain['generated_codes'][0], res['generated_codes'][0])       # the first scene has no previous frame yet

@@ -118,14 +118,22 @@ def vqf_stamps(M=64 * 896, zscale=0.18):
     print('  per-WG total: median %.0f max %.0f' % (np.median(t[:, 5] - t[:, 0]), (t[:, 5] - t[:, 0]).max()))
 
 
-def attn(B=32, H=12, S=8, L=64, bf16=False, x6=False):
+def attn(B=128, H=12, S=8, L=64, bf16=False, x6=False, fp8=False, twin=6, a16=False):
+    """the bench's attention call: 128 scenes x 12 heads, the fused twin pass of 6 context views + MASK view + LOC view (T = 512);
+    useful FLOPs = the (query view, key view) tile pairs the mask keeps"""
     d, T = H * 64, S * L
     qkv = torch.randn(B * T, 3 * d, device=dev) * 0.3
-    out = torch.empty(B * T, d, device=dev)
+    if a16:
+        qkv = qkv.to(torch.bfloat16)
+    out = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16 if a16 else torch.float32)
     ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
-                                             3 * d, d, 1.0, True, bf16=bf16, x6=x6))
-    useful = 4.0 * H * 64 * L * L * S * (S + 1) / 2 * B
-    print(f'attn{"[bf16]" if bf16 else "[x6]" if x6 else ""} B={B} T={T}: {ms:.4f} ms  {useful / ms / 1e9:.1f} TF useful')
+                                             3 * d, d, 1.0, True, twin, bf16=bf16, x6=x6, fp8=fp8), iters=20)
+    pairs = S * (S + 1) // 2 if twin < 0 else (twin * (twin + 1) // 2 + (S - twin) * (twin + 1))
+    useful = 4.0 * H * 64 * L * L * pairs * B
+    arm = 'fp8' if fp8 else 'bf16' + ('/v1' if os.environ.get('VF_ATTN_BF16_V1') == '1' else '') if bf16 else 'x6' if x6 else 'f32'
+    peak = 2500.0 if (bf16 or fp8) else 2500.0 / 6 if x6 else 157.3
+    print(f'attn[{arm}{",bf16 io" if a16 else ""}] B={B} H={H} T={T} twin={twin}: {ms * 1e3:.1f} us  {useful / ms / 1e9:.1f} TF useful = '
+          f'{useful / ms / 1e9 / peak * 100:.1f} % of {peak:.0f}')
 
 
 def gn(n_img=56, C=128, HW=16384):
@@ -167,7 +175,8 @@ def clockprobe(n_img=56, C=128, H=128):
 ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True),
-           attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True),
+           attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True),
+           attnbf16_s20=lambda: attn(B=12, S=21, twin=19, bf16=True), attnfp8_s20=lambda: attn(B=12, S=21, twin=19, fp8=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx3h=lambda: gemm(16384, 768, 2304, arith='x3h'), gemmx3h_gelu=lambda: gemm(16384, 768, 3072, 1, 'x3h'),
            gemmx3h_k3072=lambda: gemm(16384, 3072, 768, arith='x3h'),

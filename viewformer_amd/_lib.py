@@ -76,6 +76,8 @@ EXPORTS = {
     'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_bf16': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_bf16_v2': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
+    'vf_attn_blockcausal_fp8': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -31,7 +31,7 @@ class _Dense:
 
 class MIGT:
     def __init__(self, config: MIGTConfig = None, device=None, skip_masked: bool = True, precision: str = 'f32',
-                 dense_arith: str = 'x3h', bf16_activations: bool = True):
+                 dense_arith: str = 'x3h', bf16_activations: bool = True, attention: str = None):
         """``dense_arith`` picks how the fp32 dense layers are evaluated (precision='f32' only): 'f32' = native f32 MFMA,
         'x6' = the fp32-EQUIVALENT six-term split-bf16 GEMM (csrc/gemm_x6.hip: same error against fp64, ~1.8x faster),
         'x3h' = the three-term split-fp16 GEMM (csrc/gemm_x3h.hip: same error for activations in fp16's range — LayerNorm / GELU /
@@ -40,7 +40,12 @@ class MIGT:
         fp32 activations / accumulation, and the attention contractions (q.k^T, p.v) on bf16 MFMA with an fp32 softmax;
         LayerNorm, the residual stream and the arg-max stay fp32.
         Logits are then tolerance-bounded (tests state the bound), as the north star allows for the transformer."""
-        assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6', 'x3h')
+        assert precision in ('f32', 'bf16') and dense_arith in ('f32', 'x6', 'x3h') and attention in (None, 'bf16', 'fp8')
+        if attention is not None and precision != 'bf16':
+            raise ValueError("attention='bf16' / 'fp8' belong to the tolerance arm: use precision='bf16'")
+        # ``attention='fp8'`` (BASELINE configs[4]): q.k^T and p.v on v_mfma_f32_32x32x16_fp8_fp8 with OCP e4m3 operands, fp32 softmax
+        # (csrc/attention_lp.hip); the dense layers stay on the bf16 arm.  Tolerances: tests/test_hip_fp8.py.
+        self.attention = attention or ('bf16' if precision == 'bf16' else 'f32')
         self.precision = precision
         self.dense_arith = dense_arith
         # bf16 arm only: LayerNorm / GELU / attention outputs — values that only bf16 GEMMs consume — are written as bf16 by their
@@ -213,7 +218,7 @@ class MIGT:
             # thirds are (V, Q, K): migt.py:207-213
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
                                  3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16',
-                                 x6=self.precision == 'f32' and self.dense_arith in ('x6', 'x3h'))
+                                 x6=self.precision == 'f32' and self.dense_arith in ('x6', 'x3h'), fp8=self.attention == 'fp8')
             h = self._gemm(att, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d, out_bf16=act16)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU, out_bf16=act16)

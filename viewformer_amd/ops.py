@@ -5,6 +5,7 @@ device pointers to libvf_hip.so and launches on torch's current HIP stream.  Not
 computes with torch ops, and nothing falls back to them.
 """
 import ctypes
+import os
 
 import torch
 
@@ -421,8 +422,13 @@ def codebook_gather(E, idx, D, Kc):
 
 
 # ------------------------------------------------------------------ attention / transformer glue
-def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1, bf16=False, x6=False):
+def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1, bf16=False, x6=False,
+                     fp8=False):
+    """``bf16`` / ``fp8``: the tolerance arms (bf16 or OCP e4m3 operands, fp32 softmax; csrc/attention_lp.hip — VF_ATTN_BF16_V1=1
+    selects the first bf16 kernel, csrc/attention_bf16.hip, for A/B); ``x6``: fp32-equivalent; default: native f32 MFMA."""
     lib = _lib.load()
+    if fp8:
+        bf16 = True
     if x6:
         check(lib.vf_attn_blockcausal_x6(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
                                          ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
@@ -433,9 +439,10 @@ def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, sk
         i16 = q.dtype == torch.bfloat16            # bf16 q/k/v: the fused c_attn output written by its GEMM with o16=True
         for t in (q, k, v):
             _chk(t, torch.bfloat16 if i16 else torch.float32, 'q/k/v')
-        check(lib.vf_attn_blockcausal_bf16(_p(q), _p(k), _p(v), 1 if i16 else 0, _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
-                                           ldq, ldk, ldv, ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
-              'vf_attn_blockcausal_bf16')
+        fn = (lib.vf_attn_blockcausal_fp8 if fp8 else lib.vf_attn_blockcausal_bf16 if os.environ.get('VF_ATTN_BF16_V1') == '1'
+              else lib.vf_attn_blockcausal_bf16_v2)
+        check(fn(_p(q), _p(k), _p(v), 1 if i16 else 0, _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
+                 ldq, ldk, ldv, ldo, scale, 1 if skip_masked else 0, twin_view, _stream()), 'vf_attn_blockcausal_lp')
         return out
     check(lib.vf_attn_blockcausal_f32(_p(_f32(q)), _p(_f32(k)), _p(_f32(v)), _p(_f32(out)), B, H, T, L, ldq, ldk, ldv,
                                       ldo, scale, 1 if skip_masked else 0, twin_view, _stream()),
