@@ -220,6 +220,14 @@ int vf_dense_small_k_gelu_f32(const float* x, const float* W, const float* b, fl
                               int64_t rows, int K, int N, int gelu, void* stream);
 /* first-max index over each row of n floats (tf.argmax, evaluate_transformer.py:123; ties -> lowest) */
 int vf_argmax_rows_f32(const float* x, int64_t rows, int n, int ld, int64_t* idx, void* stream);
+/* tied LM head with the arg-max fused into its epilogue (bf16 arm; csrc/lmhead_argmax.hip): idx[m] = first arg-max over n < N of
+ * sum_k bf16(h[m][k]) * bf16(W[n][k]) — SharedEmbeddings._linear (migt.py:51-56) + the :417 slice + tf.argmax
+ * (evaluate_transformer.py:123) without writing the [M][N] logits.  h: fp32 rows (h_bf16 = 0) or bf16 rows (1), ldh in elements;
+ * w_packed = vf_gemm_bf16_pack of wte[:N] (sk = 1, sn = K).  Same arithmetic as vf_gemm_bf16 on that packing: the index equals
+ * vf_argmax_rows_f32 of its logits.  max_logit (NULL or [M]): the winning logit.  K in {128, 768}, N % 128 == 0
+ * (VF_ERR_UNSUPPORTED otherwise: compute the logits and call vf_argmax_rows_f32). */
+int vf_lmhead_argmax_bf16(const void* h, int h_bf16, int64_t ldh, const void* w_packed, int64_t M, int K, int N, int64_t* idx,
+                          float* max_logit, void* stream);
 /* host-side CRC-32C (Castagnoli) of a HOST buffer, for the TFRecord / TensorBundle files of the reference's datasets and
  * Keras checkpoints (viewformer_amd/codes_dataset.py, checkpoint.py); crc = 0 starts a new checksum */
 uint32_t vf_crc32c(const void* data, size_t n, uint32_t crc);

@@ -234,3 +234,50 @@ def test_bf16_activation_chain_is_bit_identical(dev):
         lg, pose = m.generate_and_localize(codes.to(dev), cams.to(dev))
         outs.append((lg, pose))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('M,K,N', [(8192, 768, 1024), (1000, 768, 1024), (77, 128, 256)])
+def test_fused_lmhead_argmax_equals_argmax_of_the_gemm_logits(dev, M, K, N):
+    """vf_lmhead_argmax_bf16 (arg-max in the LM head's epilogue, logits never written) == vf_argmax_rows_f32(vf_gemm_bf16 logits), bit
+    for bit: same packing, same k order, one fp32 chain per (row, code); fp32 and bf16 hidden rows; ties -> lowest index"""
+    from viewformer_amd import ops
+    wte = _rand((N + 2, K), 91, 0.05).to(dev)                         # [n_embeddings + 2][d] like the reference's wte (migt.py:288)
+    wp = ops.pack_dense_nk_bf16(wte, n_rows=N)
+    h = _rand((M, K), 92).to(dev)
+    h[5] = h[4]                                                       # identical rows -> identical results
+    logits = torch.empty((M, N), device=dev)
+    ops.igemm(h, wp, M, K, N, logits, bf16=True)
+    want = ops.argmax_rows(logits, M, N)
+    got, mx = ops.lmhead_argmax_bf16(h, wp, M, K, N, want_max=True)
+    assert torch.equal(got, want)
+    assert torch.equal(mx, logits.gather(1, want.view(-1, 1)).view(-1))
+    got16 = ops.lmhead_argmax_bf16(h.to(torch.bfloat16), wp, M, K, N)
+    assert torch.equal(got16, want)                                   # bf16 rows = the rounding the kernel applies to fp32 rows
+    # exact ties: duplicate codes -> the lowest index wins, as tf.argmax / vf_argmax_rows_f32
+    if N > 900:
+        wte2 = wte.clone()
+        wte2[900] = wte2[17]
+        g2 = ops.lmhead_argmax_bf16(h, ops.pack_dense_nk_bf16(wte2, n_rows=N), M, K, N)
+        assert not (g2 == 900).any()
+    assert not ops.lmhead_argmax_supported(768, 1000) and not ops.lmhead_argmax_supported(256, 1024)
+
+
+def test_evaluator_with_fused_lmhead_is_bit_identical(dev, full_vq):
+    """generate_batch_predictions without return_codes takes the fused LM-head arg-max; its images / cameras equal the logits path's"""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    vcfg, vsd, _ = full_vq
+    vq_m = VQGAN(vcfg, data_format='NHWC', decoder_precision='bf16').load_state_dict(vsd).to(dev)
+    frames, cams = synthetic_scene_batch(3, 4, 128, seed=5)
+    for loc in ('1', '0'):
+        mcfg = MIGTConfig(sequence_size=3, localization_weight=loc, pose_multiplier=0.2, n_layer=3)
+        tr_m = MIGT(mcfg, precision='bf16').load_state_dict(make_migt_weights(mcfg, seed=2)).to(dev)
+        a = generate_batch_predictions(tr_m, vq_m, frames, cams, return_codes=True)
+        b = generate_batch_predictions(tr_m, vq_m, frames, cams)
+        assert torch.equal(a['generated_images'], b['generated_images'])
+        assert torch.equal(a['generated_cameras'], b['generated_cameras'])
+        c = generate_batch_predictions(tr_m, vq_m, frames, cams, fused_passes=False)
+        assert torch.equal(a['generated_images'], c['generated_images'])

@@ -91,6 +91,7 @@ EXPORTS = {
     'vf_layernorm_bf16out_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_embed_sum_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     'vf_dense_small_k_gelu_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'vf_lmhead_argmax_bf16': (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P, P, P]),
     'vf_argmax_rows_f32': (c_int, [P, c_int64, c_int, c_int, P, P]),
     'vf_postprocess_u8': (c_int, [P, P, c_int64, P]),
     'vf_resize_u8': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -46,15 +46,27 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     codes = codebook_model.encode(frames)[-1]
     codes = codes.to(torch.int32).view(B, S, t, t)                      # :110,116
 
-    pose_last = None
+    # ``return_codes`` also hands back the last view's logits; without it the arg-max is fused into the LM head's epilogue where the
+    # arm supports it (the [B*64, 1024] logits never reach HBM)
+    pose_last, lg = None, None
     if transformer_model.use_localization and fused_passes:
-        lg, pose_last = transformer_model.generate_and_localize(codes, cameras)       # :119-123 + :134-136
+        first, pose_last = transformer_model.generate_and_localize(codes, cameras, codes_only=not return_codes)   # :119-123 + :134-136
+        if return_codes:
+            lg = first
+        else:
+            generated_codes = first
     else:
         ids = torch.cat([codes[:, :-1], torch.full_like(codes[:, :1], transformer_model.mask_token)], 1)   # :120-121
-        out = transformer_model(dict(input_ids=ids, poses=cameras), training=False, last_view_logits_only=True)
-        lg = out['logits_last']                                         # == output['logits'][:, -1]
-    nE = lg.shape[-1]
-    generated_codes = ops.argmax_rows(lg.view(-1, nE), B * t * t, nE).view(B, t, t)   # :123 (ties -> lowest index)
+        out = transformer_model(dict(input_ids=ids, poses=cameras), training=False, last_view_logits_only=return_codes,
+                                last_view_codes_only=not return_codes)
+        if return_codes:
+            lg = out['logits_last']                                     # == output['logits'][:, -1]
+        else:
+            generated_codes = out['codes_last']
+    if lg is not None:
+        nE = lg.shape[-1]
+        generated_codes = ops.argmax_rows(lg.view(-1, nE), B * t * t, nE).view(B, t, t)   # :123 (ties -> lowest index)
+    generated_codes = generated_codes.view(B, t, t)
 
     dec = codebook_model.decode_code(generated_codes)                   # :127
     if codebook_model.data_format == 'NCHW':

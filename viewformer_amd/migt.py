@@ -179,6 +179,15 @@ class MIGT:
                   bf16=bf16, x6=x6 and not x3h, x3h=x3h)
         return out
 
+    def _lm_argmax(self, h, M):
+        """arg-max of the tied LM head WITHOUT materialising the logits (fused epilogue, csrc/lmhead_argmax.hip; bf16 arm): the codes
+        ``tf.argmax(logits, -1)`` would give (evaluate_transformer.py:123), or None where the fused form does not apply (fp32 arm,
+        odd shapes) — callers then compute the logits and call ops.argmax_rows."""
+        c = self.config
+        if getattr(self, '_lm_head16', None) is None or not ops.lmhead_argmax_supported(c.d_model, c.n_embeddings):
+            return None
+        return ops.lmhead_argmax_bf16(h, self._lm_head16, M, c.d_model, c.n_embeddings)
+
     def _pose_embed(self, poses):
         """pose_embedding(get_model_input(poses)) — migt.py:139-145,291,354 (fp32; multiplier 1 at inference)"""
         B, Sp, _ = poses.shape
@@ -225,7 +234,7 @@ class MIGT:
             h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
         return ops.layernorm(h, *self._ln['ln_f'], M, d)                    # migt.py:408
 
-    def generate_and_localize(self, codes, cameras):
+    def generate_and_localize(self, codes, cameras, codes_only: bool = False):
         """The evaluator's two transformer passes (evaluate_transformer.py:119-123 and :134-136) as ONE pass.
 
         Pass 1 feeds [codes[:, :-1], MASK] with all S poses; pass 2 feeds all S real code maps with S-1 poses
@@ -237,7 +246,8 @@ class MIGT:
         row bit-for-bit (tests/test_hip_models.py), at 8/14 of the transformer work for S = 7.
 
         codes [B,S,t,t] int (all S views encoded), cameras [B,S,7] float32 (relative + normalised).
-        Returns (logits_last [B,t,t,n_embeddings], pose_prediction_last [B,1,L,7])."""
+        Returns (logits_last [B,t,t,n_embeddings], pose_prediction_last [B,1,L,7]); with ``codes_only`` the first member is the
+        generated code map [B,t,t] int64 instead (arg-max fused into the LM head where the arm supports it)."""
         if not self.use_localization:
             raise RuntimeError('generate_and_localize needs a model with the localization head')
         c, dev = self.config, self.device
@@ -257,12 +267,15 @@ class MIGT:
         hf = self._blocks(ids, add, B, S + 1, L, mask_spec=S - 1).view(B, S + 1, L, d)
         h_mask = hf[:, S - 1].contiguous().view(B * L, d)
         h_loc = hf[:, S].contiguous().view(B * L, d)
-        lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
-        self._lm(h_mask, B * L, lg)                                                     # migt.py:417
+        gen = self._lm_argmax(h_mask, B * L) if codes_only else None
+        if gen is None:
+            lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
+            self._lm(h_mask, B * L, lg)                                                 # migt.py:417
+            gen = ops.argmax_rows(lg, B * L, nE) if codes_only else None
         p1 = self._gemm(h_loc, 'pose_criterion.pose_classifier.c_fc', B * L, epilogue=ops.EPI_GELU)
         p2 = self._gemm(p1, 'pose_criterion.pose_classifier.c_proj', B * L)
         pose = geometry.pose_head_postprocess(p2.view(B, 1, L, 7), c.pose_multiplier)
-        return lg.view(B, *tshape, nE), pose
+        return (gen.view(B, *tshape) if codes_only else lg.view(B, *tshape, nE)), pose
 
     def _call_streams(self, ids, pose_emb, loc_tokens, out_poses, B, S, L, orig_shape):
         """Multi-stream ("branching") forward, migt.py:371-455 with training=False.
@@ -314,7 +327,7 @@ class MIGT:
         return out
 
     # ------------------------------------------------------------------ forward (single stream, inference)
-    def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False):
+    def __call__(self, inputs, training=False, compute_losses=False, last_view_logits_only=False, last_view_codes_only=False):
         if training:
             raise RuntimeError('the training graph (dropout, losses, backward, optimizer: MIGT.train_step migt.py:464-505) is '
                                'viewformer_amd.train.MIGTTrainer(model).train_step(poses, tokens); __call__ is inference')
@@ -350,19 +363,27 @@ class MIGT:
             if out_poses is None:
                 out_poses = poses
         if loc_tokens is not None or out_poses is not None:
-            if last_view_logits_only:
-                raise ValueError('last_view_logits_only applies to the single-stream call')
+            if last_view_logits_only or last_view_codes_only:
+                raise ValueError('last_view_logits_only / last_view_codes_only apply to the single-stream call')
             return self._call_streams(ids, pose_emb, loc_tokens, out_poses, B, S, L, orig_shape)
 
         hf = self._blocks(ids, pose_emb, B, S, L)
 
         out = dict(hidden_states=[hf.view(B, S, L, d)])
         nE = c.n_embeddings
+        if last_view_codes_only:
+            last_view_logits_only = True
         if last_view_logits_only:
             hl = hf.view(B, S, L, d)[:, -1].contiguous().view(B * L, d)
-            lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
-            self._lm(hl, B * L, lg)
-            out['logits_last'] = lg.view(B, *orig_shape[2:], nE)
+            gen = self._lm_argmax(hl, B * L) if last_view_codes_only else None
+            if gen is None:
+                lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
+                self._lm(hl, B * L, lg)
+                out['logits_last'] = lg.view(B, *orig_shape[2:], nE)
+                if last_view_codes_only:
+                    gen = ops.argmax_rows(lg, B * L, nE)
+            if gen is not None:
+                out['codes_last'] = gen.view(B, *orig_shape[2:])                  # argmax(logits, -1)[:, -1], evaluate_transformer.py:123
         else:
             lg = torch.empty((M, nE), dtype=torch.float32, device=dev)
             self._lm(hf, M, lg)                                              # migt.py:417,51-56

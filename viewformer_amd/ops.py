@@ -490,6 +490,22 @@ def argmax_rows(x, rows, n, ld=None):
     return idx
 
 
+def lmhead_argmax_supported(K, N):
+    return K in (128, 768) and N % 128 == 0
+
+
+def lmhead_argmax_bf16(h, w_packed_bf16, M, K, N, want_max=False):
+    """fused tied LM head + arg-max (bf16 arm): h [M][K] fp32 or bf16 rows, w_packed_bf16 = pack_dense_nk_bf16(wte, n_rows=N).
+    Returns idx int64 [M] (and the winning logits if ``want_max``); the [M][N] logits are never materialised."""
+    idx = torch.empty(M, dtype=torch.int64, device=h.device)
+    mx = torch.empty(M, dtype=torch.float32, device=h.device) if want_max else None
+    h16 = h.dtype == torch.bfloat16
+    _chk(h, torch.bfloat16 if h16 else torch.float32, 'h')
+    check(_lib.load().vf_lmhead_argmax_bf16(_p(h), 1 if h16 else 0, h.stride(0), _p(_chk(w_packed_bf16, torch.bfloat16, 'w_packed')), M, K, N,
+                                            _p(idx), _p(mx) if mx is not None else None, _stream()), 'vf_lmhead_argmax_bf16')
+    return (idx, mx) if want_max else idx
+
+
 def postprocess_u8(x):
     x = _f32(x).contiguous()
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
