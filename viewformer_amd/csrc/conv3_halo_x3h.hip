@@ -32,6 +32,11 @@
 #ifndef VF_X3H_SB
 #define VF_X3H_SB 1       // sched_barrier(0) at every stage boundary (pins the prefetch distance)
 #endif
+#ifndef VF_X3H_TALL
+#define VF_X3H_TALL 1     // wave tile = all 128 pixels x 32 channels (4 x 1 MFMA tiles) instead of 64 pixels x 64 channels (2 x 2): a stage
+#endif                    // then needs 2 weight fragments through the L1 -> VGPR return path instead of 4 (and 8 activation fragments
+                          // from LDS instead of 4).  PMC of the 2 x 2 form (profiles/r2_conv_x3h_l1path_pmc.txt): TD (the vector-memory
+                          // data-return unit) 92 % busy, TA 71 %, matrix pipe 54 % — the return path was the bound, LDS had 4x headroom.
 #ifndef VF_X3H_PRECISE_SWISH
 #define VF_X3H_PRECISE_SWISH 0
 #endif
@@ -72,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    constexpr bool TALL = VF_X3H_TALL != 0;
+    constexpr int MI = TALL ? 4 : 2, NJ = TALL ? 1 : 2;           // MFMA tiles per wave: pixels (tile rows / 2) x channels / 32
+    const int wave_m = TALL ? 0 : wave >> 1, wave_n = TALL ? wave : wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = p.Cout / BN;
@@ -150,9 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     };
 
     const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
-    int a_base[2], a_r[2];
+    int a_base[MI], a_r[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int a0 = wave_m * 4 + mi * 2 + trow;
         a_r[mi] = a0;
         const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
@@ -162,27 +169,27 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     // packed weights [chunk][tap][nblk][ks(2)][plane(2)][half(2)][n(128)][8 f16]; one pipeline stage = one (tap, ks)
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
-    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    const int b_lane = (half * BN + wave_n * (32 * NJ) + l31) * 16;
     // software pipeline over stages g = chunk*18 + tap*2 + ks: B two stages ahead in a 3-deep register ring (an L2 hit
     // costs about one stage of MFMA time, so one-ahead left the matrix pipe waiting), A one stage ahead (2-deep)
     constexpr int BD = VF_X3H_BD, RING = BD + 1, AD = VF_X3H_AD;
     static_assert(18 % RING == 0 && (AD == 0 || AD == 1), "ring indices must repeat per chunk");
-    f16x8 bring[RING][2][2];
-    f16x8 aring[2][2][2];
+    f16x8 bring[RING][2][NJ];
+    f16x8 aring[2][MI][2];
     const int last_g = nchunks * 18 - 1;
-    auto b_load = [&](f16x8 (&dst)[2][2], int g) {
+    auto b_load = [&](f16x8 (&dst)[2][NJ], int g) {
         g = min(g, last_g);
         const unsigned char* src = Wb + (size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES + b_lane;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+            for (int j = 0; j < NJ; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
     };
-    auto a_load = [&](f16x8 (&dst)[2][2], const unsigned char* patch, int s) {
+    auto a_load = [&](f16x8 (&dst)[MI][2], const unsigned char* patch, int s) {
         const int tap = s >> 1, ks = s & 1;
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             int aoff;
             if (UP2) {
                 const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
@@ -195,11 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
         }
     };
 
-    f32x16 acc[2][2], accx[2][2];          // main products ah*bh; cross products (al*2^11)*bh + ah*(bl*2^11)
+    f32x16 acc[MI][NJ], accx[MI][NJ];      // main products ah*bh; cross products (al*2^11)*bh + ah*(bl*2^11)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
@@ -228,9 +235,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
                     if (s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         if (t == 0) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][1], bring[s % RING][0][j], accx[mi][j], 0, 0, 0);
                         else if (t == 1) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][0], bring[s % RING][1][j], accx[mi][j], 0, 0, 0);
                         else acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[s & 1][mi][0], bring[s % RING][0][j], acc[mi][j], 0, 0, 0);
@@ -247,12 +254,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     // out = (acc + accx * 2^-11) / S with S the power-of-two weight scale stored behind the packed planes
     const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nchunks * 9 * nb * TAP_BYTES);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
-    vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+    vf_halo_epilogue_t<PAIR, MI, NJ>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
 

@@ -28,55 +28,69 @@ static inline int vf_halo_gn_check(const vf_igemm_args& a) {
     return VF_OK;
 }
 
-// One workgroup's epilogue: wave (wave_m, wave_n) owns rows [wave_m*4, +4) x 16 px of the 8x16 tile and 64 output channels,
-// as acc[mi][j] = (2 tile rows) x (32 channels).  PAIR: the tile is two 8x8 images (img, img1) side by side.
-template <bool PAIR>
-__device__ __forceinline__ void vf_halo_epilogue(const vf_igemm_args& p, const f32x16 (&acc)[2][2], int img, int img1, int y0,
-                                                 int x0, int tile_slot, int nblk, int wave_m, int wave_n, int half, int l31) {
+// One workgroup's epilogue.  A wave owns MI x NJ accumulator tiles: acc[mi][j] = tile rows [wave_m * 4 + 2 mi, +2) x 16 px, output
+// channels [wave_n * 32 NJ + 32 j, +32).  (MI, NJ) = (2, 2): the 2 x 2 wave grid of the original kernels (wave_m in {0, 1} = rows
+// 0-3 / 4-7); (4, 1): the "tall" form, every wave covers all 8 rows and 32 channels (wave_m = 0, wave_n = wave).  The fused GroupNorm
+// partial statistics keep their layout either way: slot tile_slot + (row >> 2) holds the sums over rows 4 (row >> 2) .. +3.
+// PAIR: the tile is two 8x8 images (img, img1) side by side.
+template <bool PAIR, int MI, int NJ>
+__device__ __forceinline__ void vf_halo_epilogue_t(const vf_igemm_args& p, const f32x16 (&acc)[MI][NJ], int img, int img1, int y0,
+                                                   int x0, int tile_slot, int nblk, int wave_m, int wave_n, int half, int l31) {
     constexpr int BN = 128;
     float* __restrict__ Out = p.out + (size_t)img * p.Hout * p.Wout * p.ldc;
     const float* __restrict__ Res = p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : nullptr;
     const bool stats = p.gn_part != nullptr;
     const int cg = p.Cout >> 5;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nblk * BN + wave_n * (32 * NJ) + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
-        float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int py = y0 + wave_m * 4 + mi * 2;
-            auto ppx = [&](int r) { const int i0 = (r & 3) + 8 * (r >> 2); return half ? vf_perm_px(i0 + 4) : vf_perm_px(i0); };
-            auto pix = [&](int r) {
-                const int i0 = (r & 3) + 8 * (r >> 2);
-                const int prow = half ? vf_perm_row(i0 + 4) : vf_perm_row(i0);
-                if (PAIR) return (ppx(r) >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx(r) & 7);
-                return (py + prow) * p.Wout + x0 + ppx(r);
-            };
-            auto oo = [&](int r) { return pix(r) * p.ldc; };
-            auto ro = [&](int r) { return pix(r) * p.ldr; };
-            auto sel = [&](int r) { return PAIR ? (ppx(r) >> 3) : 0; };
-            if (stats) {
-                if (Res) vf_store_tile_stats<true>(acc[mi][j], bias, Out + n, Res + n, oo, ro, sel, s, q);
-                else vf_store_tile_stats<false>(acc[mi][j], bias, Out + n, Res, oo, ro, sel, s, q);
-            } else {
-                if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
-                else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
+        for (int sl = 0; sl < MI / 2; ++sl) {                       // one statistics slot = 4 tile rows = 2 accumulator tiles
+            float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int mi = sl * 2 + mm;
+                const int py = y0 + wave_m * 4 + mi * 2;
+                auto ppx = [&](int r) { const int i0 = (r & 3) + 8 * (r >> 2); return half ? vf_perm_px(i0 + 4) : vf_perm_px(i0); };
+                auto pix = [&](int r) {
+                    const int i0 = (r & 3) + 8 * (r >> 2);
+                    const int prow = half ? vf_perm_row(i0 + 4) : vf_perm_row(i0);
+                    if (PAIR) return (ppx(r) >> 3) * (img1 - img) * p.Hout * p.Wout + (py + prow) * p.Wout + (ppx(r) & 7);
+                    return (py + prow) * p.Wout + x0 + ppx(r);
+                };
+                auto oo = [&](int r) { return pix(r) * p.ldc; };
+                auto ro = [&](int r) { return pix(r) * p.ldr; };
+                auto sel = [&](int r) { return PAIR ? (ppx(r) >> 3) : 0; };
+                if (stats) {
+                    if (Res) vf_store_tile_stats<true>(acc[mi][j], bias, Out + n, Res + n, oo, ro, sel, s, q);
+                    else vf_store_tile_stats<false>(acc[mi][j], bias, Out + n, Res, oo, ro, sel, s, q);
+                } else {
+                    if (Res) vf_store_tile<0, true>(acc[mi][j], bias, Out + n, Res + n, oo, ro);
+                    else vf_store_tile<0, false>(acc[mi][j], bias, Out + n, Res, oo, ro);
+                }
             }
-        }
-        if (stats) {
+            if (stats) {
 #pragma unroll
-            for (int k = 0; k < (PAIR ? 2 : 1); ++k) {
-                float ss = s[k], qq = q[k];
-                vf_gn_group_reduce(ss, qq, cg);
-                // an odd image count duplicates the last image into the second half of its pair tile: that half is not a new image
-                if (half == 0 && (l31 & (cg - 1)) == 0 && (k == 0 || img1 != img)) {
-                    const int im = k ? img1 : img;
-                    float* dst = p.gn_part + ((((size_t)im * p.gn_slots) + tile_slot + wave_m) * 32 + n / cg) * 2;
-                    dst[0] = ss;
-                    dst[1] = qq;
+                for (int k = 0; k < (PAIR ? 2 : 1); ++k) {
+                    float ss = s[k], qq = q[k];
+                    vf_gn_group_reduce(ss, qq, cg);
+                    // an odd image count duplicates the last image into the second half of its pair tile: that half is not a new image
+                    if (half == 0 && (l31 & (cg - 1)) == 0 && (k == 0 || img1 != img)) {
+                        const int im = k ? img1 : img;
+                        float* dst = p.gn_part + ((((size_t)im * p.gn_slots) + tile_slot + wave_m + sl) * 32 + n / cg) * 2;
+                        dst[0] = ss;
+                        dst[1] = qq;
+                    }
                 }
             }
         }
     }
+}
+
+// the original 2 x 2 wave grid (conv3_halo_x6 / _bf16 / _f32, the stride-2 kernels)
+template <bool PAIR>
+__device__ __forceinline__ void vf_halo_epilogue(const vf_igemm_args& p, const f32x16 (&acc)[2][2], int img, int img1, int y0,
+                                                 int x0, int tile_slot, int nblk, int wave_m, int wave_n, int half, int l31) {
+    vf_halo_epilogue_t<PAIR, 2, 2>(p, acc, img, img1, y0, x0, tile_slot, nblk, wave_m, wave_n, half, l31);
 }
