@@ -200,6 +200,12 @@ int vf_attn_blockcausal_fp8(const void* q, const void* k, const void* v, int in_
 int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float* out,
                            int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
                            float scale, int skip_masked, int twin_view, void* stream);
+/* Single-head spatial self-attention of the VQGAN AttnBlock, fused (csrc/attn_spatial.hip): replaces the core of AttnBlock.forward
+ * (vqgan_th.py:124-141) — scores = q^T k * scale, softmax over the keys, h = v . p^T — per image of HW tokens x C channels, from the
+ * fused q|k|v projection qkv [n_img * HW][ld] (q at column 0, k at C, v at 2C); out [n_img * HW][ldo].  Exact fp32
+ * (v_mfma_f32_32x32x2_f32 + libm expf); the [HW][HW] score matrix never leaves the CU.  (HW, C) in {(256, 256), (64, 512), (64, 256)}
+ * (VF_ERR_UNSUPPORTED otherwise: batched vf_igemm_f32 + vf_softmax_rows_f32). */
+int vf_attn_spatial_f32(const float* qkv, float* out, int n_img, int HW, int C, int64_t ld, int64_t ldo, float scale, void* stream);
 /* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
 int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
 

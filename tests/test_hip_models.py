@@ -400,3 +400,28 @@ def test_evaluators_resize_frames_of_another_size(dev, tiny_vq):
     ref = codebook_batch_predictions(m, torch.from_numpy(small))
     assert torch.equal(out['codes'], ref['codes']) and torch.equal(out['generated_images'], ref['generated_images'])
     assert out['ground_truth_images'].shape == (3, 80, 80, 3)             # the ground truth is returned as given (:75)
+
+
+@pytest.mark.parametrize('HW,C,n', [(256, 256, 5), (64, 512, 3), (64, 256, 2)])
+def test_fused_spatial_attention_matches_fp64_and_batched_form(dev, HW, C, n):
+    """vf_attn_spatial_f32 (AttnBlock core in one kernel, scores on chip) against fp64 softmax(q k^T C^-0.5) v and against the batched
+    igemm + row-softmax path it replaces (vqgan_th.py:124-141)"""
+    from viewformer_amd import ops
+    g = np.random.Generator(np.random.PCG64(HW + C))
+    qkv = torch.from_numpy((g.standard_normal((n * HW, 3 * C)) * 0.7).astype(np.float32)).to(dev)
+    scale = float(int(C) ** (-0.5))
+    got = ops.attn_spatial(qkv, n, HW, C, scale)
+    q, k, v = [t.double().cpu().view(n, HW, C) for t in (qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:])]
+    ref = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
+    err = (got.cpu().double().view(n, HW, C) - ref).abs().max().item()
+    assert err < 5e-6 * max(1.0, ref.abs().max().item()), err
+    # the unfused product path
+    kp = ops.pack(qkv[:, C:2 * C], C, HW, 1, sk=1, sn=3 * C, st=0, batch=n, src_bstride=HW * 3 * C)
+    S = torch.empty((n, HW, HW), dtype=torch.float32, device=dev)
+    ops.igemm(qkv[:, :C], kp, HW, C, HW, S, lda=3 * C, batch=n, stride_x=HW * 3 * C, stride_w=ops.packed_floats(C, HW), stride_out=HW * HW)
+    ops.softmax_rows_(S, n * HW, HW, scale)
+    vp = ops.pack(qkv[:, 2 * C:], HW, C, 1, sk=3 * C, sn=1, st=0, batch=n, src_bstride=HW * 3 * C)
+    a = torch.empty((n * HW, C), dtype=torch.float32, device=dev)
+    ops.igemm(S, vp, HW, HW, C, a, lda=HW, batch=n, stride_x=HW * HW, stride_w=ops.packed_floats(HW, C), stride_out=HW * C)
+    assert (got - a).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+    assert not ops.attn_spatial_supported(128, 256)

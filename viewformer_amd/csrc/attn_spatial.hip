@@ -1,0 +1,204 @@
+// Single-head spatial self-attention of the VQGAN AttnBlock, fused and exact fp32, gfx950.
+//
+// Replaces AttnBlock.forward's core (viewformer/models/vqgan_th.py:124-141): w = q^T k * C^-0.5, softmax over the keys, h = v w^T —
+// per image, HW tokens of C channels, (HW, C) in {(256, 256), (64, 512)} for the 128-px model — given the fused q|k|v projection
+// [n*HW][3C] (q at column 0, k at C, v at 2C).  The [HW][HW] score matrix stays on chip: the first version ran
+// pack(K) -> batched igemm -> softmax -> pack(V) -> batched igemm with the scores and two re-packed operands through HBM (5 launches,
+// 4 % of the inference step).
+//
+// One workgroup = 64 queries of one image against ALL its keys (HW <= 256 keys = at most 8 key tiles of 32, spread over the 4 waves):
+//   1. S^T = K . Q^T on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain).  Transposed, so that a query is a lane and its
+//      keys are that lane's accumulator registers.  Both operands come straight from the qkv rows as float4 along the channel axis.
+//   2. softmax over ALL keys at once (no online rescaling): per-wave partial max / sum in registers, combined across the 4 waves through
+//      LDS; precise expf, then the normalised probabilities P^T[key][query] are parked in LDS (<= 64 KiB).
+//   3. O^T = V^T . P^T: every wave takes C/4 output channels; V rows from global (128-byte rows per half-wave), P^T from LDS; the MFMA's
+//      two k slots are the keys kappa and kappa + 4 of the accumulator layout, so P needs no permutation.
+// Arithmetic: the same as the batched f32 igemm path it replaces up to summation order (scores: k ascending inside 8-channel groups;
+// outputs: keys in accumulator-row order), all fp32.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+template <int HW, int C>
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const float* __restrict__ qkv, float* __restrict__ out, long long ld,
+                                                              long long ldo, float scale) {
+    constexpr int NKT = HW / 32;                  // key tiles
+    constexpr int TPW = NKT * 2 / 4;              // (key tile, query tile) pairs per wave: 4 (HW = 256) or 1 (HW = 64)
+    constexpr int CT = C / 4 / 32;                // output-channel tiles per wave
+    constexpr int P_LD = 64;                      // P^T row: 64 queries
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Pt = smem_f;                           // [HW][P_LD]
+    float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem_f + HW * P_LD);      // [max | sum][wave][query]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const long long img = blockIdx.y;
+    const int q0 = blockIdx.x * 64;
+    const float* __restrict__ base = qkv + img * HW * ld;
+
+    // ---- 1. scores: acc[i] = S^T tile (32 keys x 32 queries) for this wave's pair i = (kt, u)
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    constexpr int NK = TPW >= 2 ? TPW / 2 : 1;    // distinct key tiles of the wave
+    constexpr int NU = TPW >= 2 ? 2 : 1;          // distinct query tiles of the wave
+    const int kt0 = TPW >= 2 ? wave * NK : (wave >> 1);
+    const int u0 = TPW >= 2 ? 0 : (wave & 1);
+    const float* krow[NK];
+    const float* qrow[NU];
+#pragma unroll
+    for (int a = 0; a < NK; ++a) krow[a] = base + (size_t)((kt0 + a) * 32 + l31) * ld + C + 4 * half;
+#pragma unroll
+    for (int b = 0; b < NU; ++b) qrow[b] = base + (size_t)(q0 + (u0 + b) * 32 + l31) * ld + 4 * half;
+#pragma unroll 4
+    for (int g = 0; g < C / 8; ++g) {
+        f32x4 ka[NK], qb[NU];
+#pragma unroll
+        for (int a = 0; a < NK; ++a) ka[a] = *reinterpret_cast<const f32x4*>(krow[a] + 8 * g);
+#pragma unroll
+        for (int b = 0; b < NU; ++b) qb[b] = *reinterpret_cast<const f32x4*>(qrow[b] + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < NK; ++a)
+#pragma unroll
+                for (int b = 0; b < NU; ++b)
+                    acc[a * NU + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[a][e], qb[b][e], acc[a * NU + b], 0, 0, 0);
+    }
+
+    // ---- 2. softmax over all keys.  Lane (l31, half) of pair (a, b): query (u0 + b) * 32 + l31, keys (kt0 + a) * 32 + rowmap(r, half)
+    // (statistics are kept per query tile b of THIS wave; a wave that owns no key tile of query tile u contributes -inf / 0 for it)
+    float mxl[NU];
+#pragma unroll
+    for (int b = 0; b < NU; ++b) mxl[b] = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < NK; ++a)
+#pragma unroll
+        for (int b = 0; b < NU; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = acc[a * NU + b][r] * scale;
+                acc[a * NU + b][r] = s;
+                mxl[b] = fmaxf(mxl[b], s);
+            }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float v = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < NU; ++b) v = (u0 + b == u) ? mxl[b] : v;
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        if (half == 0) red[0][wave][u * 32 + l31] = v;
+    }
+    __syncthreads();
+    float ml[NU], suml[NU];
+#pragma unroll
+    for (int b = 0; b < NU; ++b) {
+        const int qi = (u0 + b) * 32 + l31;
+        ml[b] = fmaxf(fmaxf(red[0][0][qi], red[0][1][qi]), fmaxf(red[0][2][qi], red[0][3][qi]));
+        suml[b] = 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < NK; ++a)
+#pragma unroll
+        for (int b = 0; b < NU; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(acc[a * NU + b][r] - ml[b]);
+                acc[a * NU + b][r] = p;
+                suml[b] += p;
+            }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float v = 0.f;
+#pragma unroll
+        for (int b = 0; b < NU; ++b) v = (u0 + b == u) ? suml[b] : v;
+        v += __shfl_xor(v, 32, 64);
+        if (half == 0) red[1][wave][u * 32 + l31] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NU; ++b) {
+        const int qi = (u0 + b) * 32 + l31;
+        const float l = (red[1][0][qi] + red[1][1][qi]) + (red[1][2][qi] + red[1][3][qi]);
+#pragma unroll
+        for (int a = 0; a < NK; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (kt0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                Pt[key * P_LD + qi] = acc[a * NU + b][r] / l;
+            }
+    }
+    __syncthreads();
+
+    // ---- 3. O^T[channel][query] = sum_key V[key][channel] * P^T[key][query]; this wave's channels: [wave * C/4, +C/4)
+    f32x16 o[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][u][r] = 0.f;
+    const int c0 = wave * (C / 4);
+    const float* __restrict__ vbase = base + 2 * C + c0 + l31;
+#pragma unroll 2
+    for (int kk = 0; kk < NKT; ++kk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // the MFMA's k slot `half` carries this key
+            float va[CT], pb[2];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) va[ct] = vbase[(size_t)key * ld + ct * 32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) pb[u] = Pt[key * P_LD + u * 32 + l31];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) o[ct][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[ct], pb[u], o[ct][u], 0, 0, 0);
+        }
+    }
+    // lane = query; accumulator rows 4j .. 4j+3 = 4 consecutive channels (+ 4 half, + 8 j)
+    float* __restrict__ obase = out + (img * HW + q0) * ldo + c0 + 4 * half;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[ct][u][4 * j + e];
+                *reinterpret_cast<f32x4*>(obase + (size_t)(u * 32 + l31) * ldo + ct * 32 + 8 * j) = v;
+            }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_attn_spatial_f32(const float* qkv, float* out, int n_img, int HW, int C, int64_t ld, int64_t ldo, float scale, void* stream) {
+    if (n_img == 0) return VF_OK;
+    if (!qkv || !out || n_img < 0 || ld < 3 * (int64_t)C || ldo < C || (ld & 3) || (ldo & 3)) return VF_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = ((size_t)HW * 64 + 2 * 4 * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_spatial_kernel<256, 256>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((256 * 64 + 512) * sizeof(float)));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (HW == 256 && C == 256)
+        hipLaunchKernelGGL((attn_spatial_kernel<256, 256>), dim3(4, (unsigned)n_img), dim3(256), smem, s, qkv, out, (long long)ld, (long long)ldo, scale);
+    else if (HW == 64 && C == 512)
+        hipLaunchKernelGGL((attn_spatial_kernel<64, 512>), dim3(1, (unsigned)n_img), dim3(256), smem, s, qkv, out, (long long)ld, (long long)ldo, scale);
+    else if (HW == 64 && C == 256)
+        hipLaunchKernelGGL((attn_spatial_kernel<64, 256>), dim3(1, (unsigned)n_img), dim3(256), smem, s, qkv, out, (long long)ld, (long long)ldo, scale);
+    else
+        return VF_ERR_UNSUPPORTED;
+    return vf_last_status();
+}
+
+}  // extern "C"

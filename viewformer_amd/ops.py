@@ -450,6 +450,19 @@ def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, sk
     return out
 
 
+def attn_spatial_supported(HW, C):
+    return (HW, C) in ((256, 256), (64, 512), (64, 256))
+
+
+def attn_spatial(qkv, n_img, HW, C, scale, out=None):
+    """fused single-head attention of the VQGAN AttnBlock: qkv [n_img*HW][3C] (q|k|v) -> [n_img*HW][C]; scores stay on chip"""
+    if out is None:
+        out = torch.empty((n_img * HW, C), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().vf_attn_spatial_f32(_p(_f32(qkv)), _p(_f32(out)), n_img, HW, C, qkv.stride(0), out.stride(0), scale, _stream()),
+          'vf_attn_spatial_f32')
+    return out
+
+
 def softmax_rows_(x, rows, n, scale=1.0):
     check(_lib.load().vf_softmax_rows_f32(_p(_f32(x)), rows, n, scale, _stream()), 'vf_softmax_rows_f32')
     return x

@@ -227,6 +227,7 @@ class VQGAN:
 
     _stats_of = None          # (tensor, partials) of the most recent halo-conv output
     fuse_gn_stats = True
+    fused_attention = True    # AttnBlock core in one kernel where the shape allows (False: batched GEMMs + row softmax, kept for A/B)
 
     def _res(self, x, name, n, H, W, cin, cout):
         """ResnetBlock.forward, vqgan_th.py:78-90"""
@@ -245,6 +246,10 @@ class VQGAN:
         wp, b = self._qkv[name]
         qkv = torch.empty((M, 3 * C), dtype=torch.float32, device=x.device)
         ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW, x6=wp.dtype == torch.bfloat16)
+        if self.fused_attention and ops.attn_spatial_supported(HW, C):
+            # scores, softmax and p.v in one kernel: the [HW][HW] matrix never leaves the CU (csrc/attn_spatial.hip)
+            a = ops.attn_spatial(qkv, n, HW, C, float(int(C) ** (-0.5)))
+            return self._conv1(a, name + '.proj_out', M, res=x)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         # scores[b] = q_b @ k_b^T : B[kk=c][nn=key] = k[key][c]
         kp = ops.pack(k, C, HW, 1, sk=1, sn=3 * C, st=0, batch=n, src_bstride=HW * 3 * C)
