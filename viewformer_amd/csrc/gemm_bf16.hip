@@ -20,6 +20,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VF_GEMM_BF16_TALL
+#define VF_GEMM_BF16_TALL 0     // 1: 128 x 32 wave tile (see gemm_bf16_direct_kernel) — measured SLOWER here (599 -> 507 TF at K = 3072), kept for A/B
+#endif
+
 constexpr int CK = 64;
 constexpr int BM = 128, BN = 128;
 constexpr int A_LDB = 144;                  // bytes per A row in LDS (128 data + 16 pad)
@@ -165,7 +169,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    // wave tile: TALL = 128 rows x 32 columns (4 x 1 MFMA tiles): a stage needs 4 weight fragments through the L1 -> VGPR return path
+    // instead of 8 and 16 activation fragments from LDS instead of 8.  Unlike the x3h convolution (+3 %) this loses 10-15 % here:
+    // one MFMA per fragment pair leaves the doubled LDS reads exposed.  Default off.
+    constexpr bool TALL = VF_GEMM_BF16_TALL != 0;
+    constexpr int MI = TALL ? 4 : 2, NJ = TALL ? 1 : 2;
+    const int wave_m = TALL ? 0 : wave >> 1, wave_n = TALL ? wave : wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
@@ -205,21 +214,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
             *reinterpret_cast<bf16x4*>(As + buf * A_BYTES + (a_r0 + RSTEP * q) * A_LDB + a_c4 * 8) = v;
         }
     };
-    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
-    bf16x8 bring[2][4][2];             // [stage parity][ks][j]
-    auto b_load = [&](bf16x8 (&dst)[4][2], int s) {
+    const int b_lane = (half * BN + wave_n * (32 * NJ) + l31) * 16;
+    bf16x8 bring[2][4][NJ];            // [stage parity][ks][j]
+    auto b_load = [&](bf16x8 (&dst)[4][NJ], int s) {
         const unsigned char* src = Wp + (size_t)min(s, nstages - 1) * stage_stride + b_lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) dst[ks][j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16);
+            for (int j = 0; j < NJ; ++j) dst[ks][j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -229,21 +238,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     for (int q = 0; q < NQ; ++q) a_park(0, q);
     __syncthreads();
 
-    auto stage_body = [&](int s, bf16x8 (&bcur)[4][2], bf16x8 (&bnext)[4][2]) {
+    auto stage_body = [&](int s, bf16x8 (&bcur)[4][NJ], bf16x8 (&bnext)[4][NJ]) {
         const unsigned char* a_src = As + (s & 1) * A_BYTES + (wave_m * 64 + l31) * A_LDB + half * 16;
         a_fetch(min(s + 1, nstages - 1));
         b_load(bnext, s + 1);
-        bf16x8 a[4][2];
+        bf16x8 a[4][MI];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(a_src + i * 32 * A_LDB + ks * 32);
+            for (int i = 0; i < MI; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(a_src + i * 32 * A_LDB + ks * 32);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], bcur[ks][j], acc[i][j], 0, 0, 0);
             if (A16) a_park((s + 1) & 1, ks);
             else { a_park((s + 1) & 1, ks * 2); a_park((s + 1) & 1, ks * 2 + 1); }
@@ -266,11 +275,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
         const bool pairs = (p.ldc & 1) == 0 && (p.Cout & 1) == 0;
         const int odd = l31 & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nblk * BN + wave_n * (32 * NJ) + j * 32 + l31;
             const float bias = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
                 float t[16];
 #pragma unroll
@@ -308,12 +317,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
     const long long ldc = p.ldc, ldr = p.ldr;
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nblk * BN + wave_n * (32 * NJ) + j * 32 + l31;
         const bool nok = n < p.Cout;
         const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
             const int nn = nok ? n : 0;
             float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
