@@ -236,6 +236,34 @@ def test_bf16_activation_chain_is_bit_identical(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize('M,K,N', [(512, 128, 256), (1000, 768, 768), (2048, 768, 2304), (1290, 3072, 768), (4096, 768, 3072)])
+def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N, monkeypatch):
+    """the 256 x 256 LDS-DMA kernel (gemm_bf16_g256.hip, taken for bf16 activations and 256-aligned widths) against the 128 x 128 kernel
+    (VF_GEMM_G256=0): same MFMA, same k order, fp32 epilogue -> the same bits; ragged last row tile, residual, GELU, bf16 output;
+    and against the fp64 reference on the bf16-rounded operands"""
+    from viewformer_amd import ops
+    x = _rand((M, K), 71).to(dev).to(torch.bfloat16)
+    w, b, r = _rand((K, N), 72, 0.05).to(dev), _rand((N,), 73).to(dev), _rand((M, N), 74).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    ref64 = x.double().cpu() @ _bf(w.cpu()) + b.double().cpu()
+
+    def run(epi, res, o16):
+        out = torch.full((M, N), float('nan'), dtype=torch.bfloat16 if o16 else torch.float32, device=dev)
+        ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi, res=res, bf16=True, a16=True, o16=o16)
+        return out
+    for epi, res, o16 in ((ops.EPI_NONE, None, False), (ops.EPI_NONE, r, False), (ops.EPI_GELU, None, True), (ops.EPI_NONE, None, True),
+                          (ops.EPI_GELU, r, False)):
+        monkeypatch.setenv('VF_GEMM_G256', '1')
+        new = run(epi, res, o16)
+        monkeypatch.setenv('VF_GEMM_G256', '0')
+        old = run(epi, res, o16)
+        assert not torch.isnan(new.float()).any()
+        assert torch.equal(new, old), (epi, res is not None, o16, (new.float() - old.float()).abs().max().item())
+    monkeypatch.setenv('VF_GEMM_G256', '1')
+    plain = run(ops.EPI_NONE, None, False)
+    assert _rel(plain, ref64) < 2e-6
+
+
 @pytest.mark.parametrize('M,K,N', [(8192, 768, 1024), (1000, 768, 1024), (77, 128, 256)])
 def test_fused_lmhead_argmax_equals_argmax_of_the_gemm_logits(dev, M, K, N):
     """vf_lmhead_argmax_bf16 (arg-max in the LM head's epilogue, logits never written) == vf_argmax_rows_f32(vf_gemm_bf16 logits), bit

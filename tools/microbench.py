@@ -70,6 +70,25 @@ def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
     print(f'gemm[{arith}] {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
 
 
+def gemm_tf(M=65536):
+    """the four dense layers of one transformer block at the bench's size (128 scenes x 8 views x 64 tokens), bf16 arm with bf16
+    activations: c_attn (fp32 or bf16 qkv out), attn.c_proj (+ residual), mlp.c_fc (GELU, bf16 out), mlp.c_proj (+ residual)"""
+    d = 768
+    for name, K, N, epi, o16, res in (('c_attn', d, 3 * d, 0, False, False), ('c_attn/o16', d, 3 * d, 0, True, False),
+                                      ('attn.c_proj', d, d, 0, False, True), ('mlp.c_fc', d, 4 * d, 1, True, False),
+                                      ('mlp.c_proj', 4 * d, d, 0, False, True)):
+        x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+        w = torch.randn(K, N, device=dev) * 0.02
+        wp = ops.pack_dense_kn_bf16(w)
+        b = torch.randn(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)
+        r = torch.randn(M, N, device=dev) if res else None
+        ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=epi, res=r, bf16=True, a16=True, o16=o16), iters=20)
+        by = M * K * 2 + K * N * 2 + M * N * (2 if o16 else 4) * (2 if res else 1)
+        print(f'gemm_bf16 {name:12s} {M}x{K}x{N}: {ms * 1e3:7.1f} us  {2.0 * M * K * N / ms / 1e9:6.1f} TF = {2.0 * M * K * N / ms / 1e9 / 25:.1f} % of 2500;'
+              f'  {by / 1e6:.0f} MB -> {by / ms / 1e6:.0f} GB/s')
+
+
 def vq(M=64 * 448):
     z = torch.randn(M, 256, device=dev) * 0.2
     E = torch.randn(256, 1024, device=dev) * 0.05
@@ -185,7 +204,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

@@ -223,10 +223,16 @@ __global__ __launch_bounds__(256, 2) void attn_lp_kernel(const float* __restrict
 
     prefetch(0);
     for (int kt = 0; kt < ntiles; ++kt) {
+#ifdef ATT_X_NOSTAGE
+        if (kt == 0) { stage(); __syncthreads(); }
+#else
         __syncthreads();                                             // previous tile fully consumed
         stage();
         __syncthreads();
+#ifndef ATT_X_NOGLOBAL
         if (kt + 1 < ntiles) prefetch(kt + 1);
+#endif
+#endif
         if (kt >= ntiles_w) continue;                                // beyond this wave's last visible view
         const bool tile_vis = uniform_views && visible(qview_w, (kt * KT) / L);
         if (skip_masked && uniform_views && !tile_vis) continue;     // every key masked for all 64 queries: contributes exactly 0.0f
@@ -245,7 +251,13 @@ __global__ __launch_bounds__(256, 2) void attn_lp_kernel(const float* __restrict
             for (int t2 = 0; t2 < 2; ++t2) {
                 const frag a = *reinterpret_cast<const frag*>(Ks + (t2 * 32 + l31) * F::K_LDB + (ks * 16 + half * 8) * F::EB);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) st[u][t2] = F::mfma(a, qb[u][ks], st[u][t2]);
+                for (int u = 0; u < 2; ++u) {
+#ifdef ATT_X_NOMFMA
+                    st[u][t2][ks] += (float)(*reinterpret_cast<const int*>(&a)) * (float)(*reinterpret_cast<const int*>(&qb[u][ks]));
+#else
+                    st[u][t2] = F::mfma(a, qb[u][ks], st[u][t2]);
+#endif
+                }
             }
 
         // ---- mask + online softmax (lane = one query of each tile; its 32 keys of this key tile) ------------------------
@@ -283,7 +295,11 @@ __global__ __launch_bounds__(256, 2) void attn_lp_kernel(const float* __restrict
                     float pv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
+#ifdef ATT_X_NOSOFTMAX
+                        const float p = st[u][t2][ks2 * 8 + e];
+#else
                         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t2][ks2 * 8 + e], c2, -mc));
+#endif
                         psum += p;
                         pv[e] = MODE == 1 ? p * pscale : p;
                     }
@@ -319,7 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_lp_kernel(const float* __restrict
                         va = (long)(((unsigned long long)hi << 32) | lo);
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) ot[u][d] = F::mfma(va, pb[u][t2][ks2], ot[u][d]);
+                    for (int u = 0; u < 2; ++u) {
+#ifdef ATT_X_NOMFMA
+                        ot[u][d][t2 * 2 + ks2] += (float)(*reinterpret_cast<const int*>(&va)) * (float)(*reinterpret_cast<const int*>(&pb[u][t2][ks2]));
+#else
+                        ot[u][d] = F::mfma(va, pb[u][t2][ks2], ot[u][d]);
+#endif
+                    }
                 }
     }
 

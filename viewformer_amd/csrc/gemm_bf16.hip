@@ -512,6 +512,8 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 
 }  // namespace
 
+int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream);      // gemm_bf16_g256.hip: 256 x 256 tile, LDS-DMA operands
+
 extern "C" {
 
 size_t vf_gemm_bf16_packed_elems(int K, int N) {
@@ -562,6 +564,13 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if (a16 || o16) {
         if (a.Cin % (2 * CK) != 0 || a.batch > 1) return VF_ERR_UNSUPPORTED;
         if ((a16 && (a.lda & 7)) || (o16 && a.res)) return VF_ERR_BAD_ARG;
+        // large token matrices with 256-aligned widths: the 256 x 256 LDS-DMA kernel (bit-identical results; VF_GEMM_G256=0 keeps
+        // the 128 x 128 kernel for A/B runs)
+        const char* g256_env = getenv("VF_GEMM_G256");          // (read per call: the parity test flips it in-process)
+        if (!(g256_env && g256_env[0] == '0')) {
+            const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
+            if (rc != VF_ERR_UNSUPPORTED) return rc;
+        }
         const dim3 g((unsigned)(mt * nb));
         hipStream_t st = (hipStream_t)stream;
         if (a16 && o16) hipLaunchKernelGGL((gemm_bf16_direct_kernel<true, true>), g, dim3(256), (size_t)2 * A_BYTES, st, a);

@@ -1,0 +1,243 @@
+// bf16 dense GEMM for the transformer's token matrix (M = scenes x views x 64 tokens, tens of thousands of rows), gfx950:
+// 256 x 256 workgroup tile, both operands through LDS by LDS-DMA.
+//
+//   out[m][n] = epi( sum_k A[m][k] * W[k][n] + bias[n] ) (+ res[m][n])       A bf16 in HBM (LayerNorm / GELU / attention outputs),
+//                                                                             W packed bf16 (vf_gemm_bf16_pack), fp32 sums
+//
+// Why a second kernel (gemm_bf16.hip keeps the 128 x 128 one for ragged / small shapes): at 128 x 128 x 64 per stage a workgroup moves
+// 32-48 KB through the L1 -> VGPR/LDS path for 2 MFLOP, i.e. the 64 B/clk/CU of that path are needed in full at the matrix pipe's
+// peak rate, and the kernel sat at 25-31 % of the bf16 peak on the four dense layers of a block (tools/microbench.py gemm_tf).  A
+// 256 x 256 tile halves the operand bytes per flop:
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_bf16 tiles (128 accumulator registers), 32 MFMAs per
+//     64-deep stage per wave against 24 ds_read_b128;
+//   * a stage = 32 KB of A (256 rows x 128 B) + 32 KB of W, double buffered = 128 KB of the CU's 160 KB LDS, one workgroup per CU;
+//   * both arrive by global_load_lds_dwordx4 (1 KB per wave instruction, no VGPR round trip, no ds_write pass): W's packed layout
+//     [ks][half][n][16 B] already is the fragment order (a lane's B fragment = one conflict-free ds_read_b128); A rows are 128 B with
+//     the 16-byte chunk index XORed by bits 1..3 of the row — applied on the GLOBAL source address, the LDS image stays lane-linear
+//     as the DMA requires — so that the 16 rows a ds_read_b128 lane group touches hit 16 distinct 16-byte bank slots;
+//   * stage s + 1 is in flight while stage s is multiplied: one "s_waitcnt vmcnt(0) lgkmcnt(0)" + raw s_barrier per stage.
+// Same arithmetic as gemm_bf16.hip (same MFMA, same k order, bias / GELU / residual in fp32): results are bit-identical to it.
+#include "vf_common.h"
+#include "epilogue.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int GM = 256, GN = 256, GK = 64;
+constexpr int GA_BYTES = GM * GK * 2;        // 32768
+constexpr int GB_BYTES = GN * GK * 2;        // 32768 = two 128-column packed blocks
+constexpr int GSTAGE = GA_BYTES + GB_BYTES;  // 65536
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// fp32 output: bias, optional GELU, optional residual.  One code path with wave-uniform flags (eight template instantiations of the
+// unrolled 8-tile store made the compiler hoist every tile's addresses and spill 350 registers around the 128 accumulators); a tile is
+// still handled as ONE block of 16 back-to-back loads / stores (epilogue.h).
+__device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
+                                               int wave_n, int half, int l31, bool full, bool gelu) {
+    const long long ldc = p.ldc, ldr = p.ldr;
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+            const int rows_left = p.M - m0;
+            float* o = p.out + (size_t)(rows_left > 0 ? m0 : 0) * ldc + n;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bias;
+            if (gelu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = vf_gelu_erf_fast(v[r]);
+            }
+            if (has_res) {
+                const float* rs = p.res + (size_t)(rows_left > 0 ? m0 : 0) * ldr + n;
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    rr[r] = rs[(long long)(full || row < rows_left ? row : 0) * ldr];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rr[r];
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+            } else if (rows_left > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    if (row < rows_left) o[(long long)row * ldc] = v[r];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // one tile at a time
+        }
+    }
+}
+
+// bf16 output (bias + optional GELU, no residual): neighbouring lanes hold neighbouring columns, so each lane pair swaps half of its
+// rows and every lane stores two adjacent columns of one row (4 bytes) — same scheme as gemm_bf16_direct_kernel
+template <bool GELU, bool FULL>
+__device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
+                                                int wave_n, int half, int l31) {
+    __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
+    const int odd = l31 & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[r] = acc[i][j][r] + bias;
+                if (GELU) t[r] = vf_gelu_erf_fast(t[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float give = odd ? t[r] : t[r + 1];
+                const float got = __shfl_xor(give, 1, 64);
+                const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
+                bf16x2_t v;
+                v[0] = (__bf16)(odd ? got : t[r]);
+                v[1] = (__bf16)(odd ? t[r + 1] : got);
+                if (FULL || m < p.M) *reinterpret_cast<bf16x2_t*>(O + (size_t)m * p.ldc + (n - odd)) = v;
+            }
+        }
+    }
+}
+
+template <bool O16>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nb = p.Cout / GN;
+    const unsigned lbid = vf_xcd_bid();                 // XCD-contiguous logical workgroup id: the column tiles of one row block share an L2
+    const int nblk = lbid % nb;
+    const int mtile = lbid / nb;
+    const int m_tile0 = mtile * GM, n_tile0 = nblk * GN;
+    const int nstages = p.Cin / GK;
+
+    // ---- LDS-DMA sources.  A: wave w moves rows [32 w, 32 w + 32) of the tile, 8 rows (1 KB) per instruction; lane -> row (lane >> 3),
+    // LDS chunk c' = lane & 7, global chunk c = c' ^ ((row >> 1) & 7).  W: the 32 KB of the stage are contiguous, wave w moves 4 KB.
+    const unsigned char* asrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 32 + q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int m = m_tile0 + r;
+        m = m < p.M ? m : p.M - 1;
+        asrc[q] = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)m * p.lda) * 2 + c * 16;
+    }
+    const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * GB_BYTES + wave * 4096 + lane * 16;
+    auto issue = [&](int s) {
+        unsigned char* dst = smem_b + (s & 1) * GSTAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(asrc[q] + (size_t)s * (GK * 2), dst + (wave * 32 + q * 8) * 128);
+        const unsigned char* ws = wsrc + (size_t)s * w_stage_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(ws + q * 1024, dst + GA_BYTES + wave * 4096 + q * 1024);
+    };
+
+    // ---- fragment addresses: A row = wave_m * 128 + i * 32 + l31, chunk (ks * 2 + half) ^ ((l31 >> 1) & 7)
+    const unsigned a_row_off = (unsigned)((wave_m * 128 + l31) * 128);
+    const unsigned a_swz = (unsigned)((l31 >> 1) & 7);
+    unsigned a_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a_off[ks] = a_row_off + ((((unsigned)(ks * 2 + half)) ^ a_swz) << 4);
+    // W image: [block (2)][ks][half][n (128)][16 B]; this wave's columns: block wave_n >> 1, n = (wave_n & 1) * 64 + j * 32 + l31
+    const unsigned b_off = (unsigned)(GA_BYTES + (wave_n >> 1) * (GK * 128 * 2) + ((half * 128) + (wave_n & 1) * 64 + l31) * 16);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0);
+    for (int s = 0; s < nstages; ++s) {
+        // stage s has landed (this wave's pieces: vmcnt; everyone's: the barrier); every wave has finished reading stage s - 1
+        // (lgkmcnt: the compiler may leave the last ds_reads in flight up to their MFMA), whose buffer the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nstages) issue(s + 1);
+        const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
+        // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks run (two register sets)
+        bf16x8 a[2][4], b[2][2];
+        auto frags = [&](int ks, bf16x8 (&af)[4], bf16x8 (&bf)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (ks * 2 * 128 + j * 32) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
+        };
+        frags(0, a[0], b[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);            // keep the reads ahead of the MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const bool full = m_tile0 + GM <= p.M;
+    const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
+    if (O16) {
+        if (full) {
+            if (gelu) g256_store_bf16<true, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else g256_store_bf16<false, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+        } else {
+            if (gelu) g256_store_bf16<true, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else g256_store_bf16<false, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+        }
+        return;
+    }
+    g256_store_f32(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
+}
+
+}  // namespace
+
+// Launcher used by vf_gemm_bf16 (gemm_bf16.hip).  Returns VF_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the
+// 128 x 128 kernel): bf16 A, Cout % 256 == 0, Cin % 64 == 0, no batch, at least one full row tile.
+int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
+    const bool a16 = a.reserved0 & 1, o16 = a.reserved0 & 2;
+    if (!a16 || a.batch > 1 || a.Cout % GN != 0 || a.Cin % GK != 0 || a.M < GM || (a.lda & 7)) return VF_ERR_UNSUPPORTED;
+    if (o16 && (a.res || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
+    if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;     // (no layer has both; the 128-tile kernel contracts gelu * + res)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
+    const dim3 g((unsigned)(mt * nb));
+    if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
+    else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
+    return vf_last_status();
+}
