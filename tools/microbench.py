@@ -70,13 +70,15 @@ def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
     print(f'gemm[{arith}] {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
 
 
-def gemm_tf(M=65536):
+def gemm_tf(M=65536, only=None):
     """the four dense layers of one transformer block at the bench's size (128 scenes x 8 views x 64 tokens), bf16 arm with bf16
     activations: c_attn (fp32 or bf16 qkv out), attn.c_proj (+ residual), mlp.c_fc (GELU, bf16 out), mlp.c_proj (+ residual)"""
     d = 768
     for name, K, N, epi, o16, res in (('c_attn', d, 3 * d, 0, False, False), ('c_attn/o16', d, 3 * d, 0, True, False),
                                       ('attn.c_proj', d, d, 0, False, True), ('mlp.c_fc', d, 4 * d, 1, True, False),
                                       ('mlp.c_proj', 4 * d, d, 0, False, True)):
+        if only and name != only:
+            continue
         x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
         w = torch.randn(K, N, device=dev) * 0.02
         wp = ops.pack_dense_kn_bf16(w)
@@ -87,6 +89,32 @@ def gemm_tf(M=65536):
         by = M * K * 2 + K * N * 2 + M * N * (2 if o16 else 4) * (2 if res else 1)
         print(f'gemm_bf16 {name:12s} {M}x{K}x{N}: {ms * 1e3:7.1f} us  {2.0 * M * K * N / ms / 1e9:6.1f} TF = {2.0 * M * K * N / ms / 1e9 / 25:.1f} % of 2500;'
               f'  {by / 1e6:.0f} MB -> {by / ms / 1e6:.0f} GB/s')
+
+
+def g256_stamps(M=65536, K=3072, N=768):
+    """phase timeline of the 256-tile bf16 GEMM (library built with -DG256_STAMPS): per wave, cycles summed over the stages"""
+    import ctypes
+    import numpy as np
+    from viewformer_amd import _lib
+    x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    wp = ops.pack_dense_kn_bf16(torch.randn(K, N, device=dev) * 0.02)
+    out = torch.empty(M, N, device=dev)
+    nwg = (M // 256) * (N // 256)
+    st = torch.zeros(nwg * 8 * 8, dtype=torch.int32, device=dev)
+    a = ops.VfIgemmArgs()
+    a.x, a.w_packed, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+    a.pro_beta = st.data_ptr()
+    a.mode, a.epilogue, a.M, a.Cin, a.Cout, a.lda, a.ldc, a.ldr, a.batch, a.reserved0 = ops.MODE_GEMM, 0, M, K, N, K, N, N, 1, 1
+    for _ in range(3):
+        _lib.check(_lib.load().vf_gemm_bf16(ctypes.byref(a), ops._stream()), 'vf_gemm_bf16')
+    torch.cuda.synchronize()
+    t = st.cpu().numpy().view(np.uint32).reshape(nwg, 8, 8).astype(np.float64)
+    ns = K // 64
+    print(f'g256 {M}x{K}x{N}: {nwg} workgroups, {ns} stages; cycles per stage per wave (mean over waves; [wave_m 0 | wave_m 1])')
+    for i, name in enumerate(('dma issue', 'first frags', 'mfma phase', 'dma wait', 'barrier wait')):
+        v = t[:, :, i] / ns
+        print('  %-12s mean %7.0f   [%7.0f | %7.0f]   p10 %7.0f p90 %7.0f' % (name, v.mean(), v[:, :4].mean(), v[:, 4:].mean(), np.percentile(v, 10), np.percentile(v, 90)))
+    print('  main loop total per wave: mean %.0f cycles = %.0f per stage' % (t[:, :, 5].mean(), t[:, :, 5].mean() / ns))
 
 
 def vq(M=64 * 448):
@@ -204,7 +232,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),
