@@ -185,6 +185,33 @@ def test_attention_bf16_all_mask_modes(dev, B, H, S, L, mode):
     print(f'bf16 attention {mode} B={B} H={H} S={S} L={L}: rel err {err:.2e}')
 
 
+@pytest.mark.parametrize('B,H,S,mode', [(1, 12, 7, 'causal'), (2, 3, 8, 'twin'), (1, 2, 3, 'streams'), (3, 2, 1, 'causal'), (2, 2, 5, 'twin'),
+                                        (1, 2, 21, 'twin')])
+def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev, B, H, S, mode, monkeypatch):
+    """bf16 q/k/v in, bf16 out, 64-token views: the LDS-DMA ring kernel (attention_dma.hip) against attention_lp.hip on the same
+    inputs (VF_ATTN_DMA=0) — same MFMAs in the same key order, same softmax: identical bits; and within ATTN_TOL of the exact fp32
+    kernel.  Covers one-view sequences, sequences that do not fill the last 4-view workgroup, and 21-view sequences (S = 20 + twin)."""
+    from viewformer_amd import ops
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    qkv = _rand((B * T, 3 * d), 91, 0.35).to(dev)
+    q16 = qkv.to(torch.bfloat16)
+    ref = torch.empty((B * T, d), device=dev)
+    ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], ref, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VF_ATTN_DMA', flag)
+        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
+        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        outs[flag] = out
+    assert not torch.isnan(outs['1'].float()).any()
+    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
+    err = ((outs['1'].float() - ref).abs().max() / ref.abs().max()).item()
+    assert err < ATTN_TOL, err
+
+
 def test_bf16_activation_chain_is_bit_identical(dev):
     """LayerNorm / GELU / attention outputs written as bf16 by their producers and read as bf16 by the GEMMs (a16 / o16): the same
     rounding the GEMM applies to an fp32 operand on load, so everything downstream is bit-identical — kernel by kernel and for the

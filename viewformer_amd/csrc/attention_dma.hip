@@ -1,0 +1,276 @@
+// Block-causal attention of the bf16 transformer arm for bf16 q / k / v in HBM (the c_attn GEMM's bf16 output) and 64-token views, gfx950.
+//
+// Same semantics and arithmetic as attention_lp.hip MODE 0 (S^T = K.Q^T on v_mfma_f32_32x32x16_bf16, fp32 online softmax with the
+// scale folded into exp2, probabilities rounded to bf16, O^T += V^T.P^T; viewformer/models/branching_attention.py:5-18,41-61,82-126),
+// but the operands never pass through VGPRs on their way in.  attention_lp.hip at the bench shape (128 scenes x 12 heads x 512
+// tokens) spends its time waiting for memory, not computing: removing its MFMAs or its softmax changes nothing (239 -> 224 us),
+// removing the K / V tile loads gives 155 us (ablation builds, tools/variants.sh).  Per CU the deliverable load bandwidth is set by
+// the bytes in flight (L2 latency x ~16 B/clk), so this kernel keeps THREE key tiles in flight per workgroup and halves the bytes:
+//   * a workgroup = 4 waves = 4 consecutive query views (a wave = one view = 64 queries as two 32-query MFMA tiles);
+//   * K / V tiles (one key view: 64 keys x 64 features, 8 KB each in bf16) arrive by global_load_lds_dwordx4 into a 4-slot ring
+//     (64 KB -> 2 workgroups per CU), issued three tiles ahead behind counted vmcnt waits and one raw s_barrier per tile;
+//   * K image: 128-byte rows, 16-byte chunk index XORed with bits 1..3 of the row (on the global source address — the LDS side of the
+//     DMA is lane-linear) -> conflict-free ds_read_b128 A fragments;
+//   * V image: [feature half][key][32 features], read with ds_read_b64_tr_b16: a 16-lane group fetches a [4 keys][16 features]
+//     block and every lane receives 4 consecutive keys of ITS feature — the V^T A-fragment of the P.V MFMA straight from a
+//     row-major V tile (no transposing write pass, no padded image);
+//   * Q (64 rows x 128 B per wave) also comes by DMA into ring slots 2-3 before they are needed for tiles, then lives in registers;
+//   * with 64-token views every (query wave, key tile) pair is entirely visible or entirely masked: no per-element mask, masked
+//     tiles are skipped (their weights are exactly 0.0f);
+//   * O is normalised, rounded to bf16, transposed through the wave's now idle ring slot and stored as whole 128-byte rows.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DH = 64, KT = 64, QT = 256, RING = 4;
+constexpr int K_BYTES = KT * DH * 2;         // 8192
+constexpr int TILE_BYTES = 2 * K_BYTES;      // K image then V image
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(p)));
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                          const __bf16* __restrict__ v, __bf16* __restrict__ out, int T, int ldq, int ldk,
+                                                          int ldv, int ldo, float scale, int twin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING x (K image | V image)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * QT;
+    const int qw0 = q0 + wave * 64;
+    const int nviews = T / KT;
+    const int qview = qw0 / KT;                            // this wave's view (>= nviews: the wave only helps moving tiles)
+    const bool active = qview < nviews;
+
+    const unsigned char* qb8 = reinterpret_cast<const unsigned char*>(q + b * (size_t)T * ldq + h * DH);
+    const unsigned char* kb8 = reinterpret_cast<const unsigned char*>(k + b * (size_t)T * ldk + h * DH);
+    const unsigned char* vb8 = reinterpret_cast<const unsigned char*>(v + b * (size_t)T * ldv + h * DH);
+
+    // visibility of key view kv from query view qv (attention_f32.hip): plain block-causal kv <= qv; twin = Vc >= 0: views Vc, Vc+1, ...
+    // are alternative endings (each sees the prefix and itself); twin <= -2: STREAMS with Sv = -twin views per stream
+    const int Vc = twin >= 0 ? twin : 0x3fffffff;
+    const int Sv = twin <= -2 ? -twin : 0;
+    auto visible = [&](int qv, int kv) {
+        if (Sv > 0) {
+            const int qs = qv / Sv, qi = qv - qs * Sv;
+            const int ks = kv / Sv, ki = kv - ks * Sv;
+            return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+        }
+        return kv == qv || min(kv, Vc) < min(qv, Vc);
+    };
+    // in every mask mode a query sees no view index above its own: the workgroup walks key tiles 0 .. its last view
+    const int ntiles = min(nviews, q0 / KT + QT / KT);
+
+    // ---- DMA.  Every 1 KB piece = 64 lanes x 16 B, lane-linear in LDS.
+    // K piece (8 rows x 128 B): lane -> row (lane >> 3), LDS chunk c' = lane & 7 holds global chunk c' ^ ((row >> 1) & 7).
+    // V piece (16 keys x 64 B of one feature half): lane -> key (lane >> 2), 16-byte chunk lane & 3.
+    const int pr = lane >> 3, pc = lane & 7;
+    auto issue_tile = [&](int t) {
+        unsigned char* dst = smem + (t % RING) * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave * 2 + j;
+            const int r = pi * 8 + pr;
+            glds16(kb8 + ((size_t)(t * KT + r) * ldk) * 2 + ((pc ^ ((r >> 1) & 7)) << 4), dst + pi * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave * 2 + j;
+            const int key = (pi & 3) * 16 + (lane >> 2);
+            glds16(vb8 + ((size_t)(t * KT + key) * ldv) * 2 + (pi >> 2) * 64 + (lane & 3) * 16, dst + K_BYTES + pi * 1024);
+        }
+    };
+    // Q: the wave's 64 rows -> its private 8 KB of ring slots 2-3 (same swizzled row image as K)
+    unsigned char* Qs = smem + 2 * TILE_BYTES + wave * K_BYTES;
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi) {
+        const int r = pi * 8 + pr;
+        const int row = min(qw0 + r, T - 1);
+        glds16(qb8 + ((size_t)row * ldq) * 2 + ((pc ^ ((r >> 1) & 7)) << 4), Qs + pi * 1024);
+    }
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // Q fragments (B operand of S^T = K.Q^T): qb[u][ks] = Q[32 u + l31][16 ks + 8 half + 0..7]
+    const unsigned swz = (unsigned)((l31 >> 1) & 7);
+    bf16x8 qb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qb[u][ks] = *reinterpret_cast<const bf16x8*>(Qs + (u * 32 + l31) * 128 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4));
+
+    f32x16 ot[2][2];                                                 // [query tile][feature half]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[u][d][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = scale * LOG2E;                                  // softmax weight = exp2(score * c2 - max * c2)
+
+    // fragment addresses inside a tile
+    const unsigned k_off = (unsigned)(l31 * 128);                    // + t2 * 4096 + (((ks * 2 + half) ^ swz) << 4)
+    // V^T fragment of (t2, ks2, d): 16-lane group g = lane >> 4: keys 32 t2 + 16 ks2 + 4 half + (i >> 2) (+ 8), features
+    // 32 d + 16 (g & 1) + 4 (i & 3) .. + 3 with i = lane & 15  ->  lane receives keys .. + 0..3 of feature 32 d + l31
+    const unsigned v_off = (unsigned)(K_BYTES + (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
+        // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
+        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
+        if (last_issued - kt >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (last_issued - kt == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0) {
+            if (ntiles > 2) issue_tile(2);
+            if (ntiles > 3) issue_tile(3);
+        } else if (kt + 3 < ntiles) {
+            issue_tile(kt + 3);
+        }
+        if (!active || !visible(qview, kt)) continue;                // masked for all 64 queries: contributes exactly 0.0f
+        const unsigned char* tile = smem + (kt % RING) * TILE_BYTES;
+
+        // ---- S^T = K . Q^T: each K fragment feeds both query tiles
+        f32x16 st[2][2];                                             // [query tile][key half]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][t2][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + k_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[u][ks], st[u][t2], 0, 0, 0);
+            }
+
+        // ---- online softmax (lane = one query of each tile; its 32 keys of this key tile per half-wave)
+        bf16x8 pb[2][2][2];                                          // [query tile][key half][k-step]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[u][t2][r]), st[u][t2][r + 1]);   // v_max3_f32
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx * scale);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * LOG2E);       // 0 on the first tile (m_run = -inf)
+            const float mc = m_new * LOG2E;
+            float psum = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t2][ks2 * 8 + e], c2, -mc));
+                        psum += p;
+                        pk[e] = (__bf16)p;
+                    }
+                    pb[u][t2][ks2] = pk;
+                }
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {        // the maximum moved for some query of the wave: rescale
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[u][d][r] *= alpha;
+            }
+        }
+
+        // ---- O^T += V^T . P^T: k-step (t2, ks2) = keys 32 t2 + 16 ks2 + 8 (e >> 2) + 4 half + (e & 3); each V^T fragment feeds both tiles
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned char* vp = tile + v_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64;
+                    const bf16x4 v0 = tr_read(vp);
+                    const bf16x4 v1 = tr_read(vp + 8 * 64);
+                    bf16x8 va;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = v0[e]; va[4 + e] = v1[e]; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) ot[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[u][t2][ks2], ot[u][d], 0, 0, 0);
+                }
+    }
+
+    // ---- normalise, round, transpose through the wave's slice of the (now idle) ring, store whole rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+    if (!active) return;
+    unsigned char* Os = smem + wave * K_BYTES;                       // [64 queries][128 B], chunk c stored at c ^ ((row >> 1) & 7)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        const int row = u * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (__bf16)(ot[u][d][4 * j + e] / l_tot);      // (a division, as attention_lp.hip: same bits)
+                *reinterpret_cast<bf16x4*>(Os + row * 128 + ((((unsigned)(d * 4 + j)) ^ swz) << 4) + 8 * half) = o4;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __bf16* __restrict__ ob = out + (b * (size_t)T + qw0) * ldo + h * DH;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + pr;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(Os + row * 128 + pc * 16);
+        const int c = pc ^ ((row >> 1) & 7);
+        *reinterpret_cast<f32x4*>(ob + (size_t)row * ldo + c * 8) = val;
+    }
+}
+
+}  // namespace
+
+// Launcher used by vf_attn_blockcausal_bf16_v2 (attention_lp.hip).  VF_ERR_UNSUPPORTED when the call does not qualify (the caller then
+// takes the register-staged kernel): bf16 q / k / v / out, 64-token views, T a multiple of 64, 16-byte aligned rows.
+int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
+                       float scale, int twin_view, hipStream_t stream) {
+    if (L != KT || T % KT != 0 || ((ldq | ldk | ldv | ldo) & 7)) return VF_ERR_UNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return VF_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
+    hipLaunchKernelGGL(attn_dma_kernel, grid, dim3(256), (size_t)RING * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), T, ldq, ldk, ldv,
+                       ldo, scale, twin_view);
+    return vf_last_status();
+}
