@@ -134,7 +134,11 @@ class OpTimer:
             else:
                 pairs = S * (S + 1) // 2
             arm = 'fp8' if kw.get('fp8') else 'bf16' if kw.get('bf16') else 'x6' if kw.get('x6') else 'f32'
-            t.attn.append((e0, e1, 4.0 * H * 64 * L * L * pairs * B, arm, (B, H, T, L, twin_view)))
+            io16 = q.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+            dma = (arm == 'bf16' and io16 and L == 64 and T % 64 == 0 and os.environ.get('VF_ATTN_DMA', '1') != '0'
+                   and os.environ.get('VF_ATTN_BF16_V1') != '1')
+            by = B * T * H * 64 * (3 * q.element_size() + out.element_size())             # q, k, v read once, o written once
+            t.attn.append((e0, e1, 4.0 * H * 64 * L * L * pairs * B, arm, (B, H, T, L, twin_view), dma, by))
             return r
         ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal = igemm, vqf, vqe, attn
 
@@ -172,13 +176,20 @@ class OpTimer:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in self.attn)
         fl = sum(r[2] for r in self.attn)
-        arm, shape = self.attn[0][3], self.attn[0][4]
+        arm, shape, dma = self.attn[0][3], self.attn[0][4], self.attn[0][5]
+        by = sum(r[6] for r in self.attn)
         peak = {'fp8': BF16_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS, 'x6': BF16_MFMA_PEAK_TFLOPS / 6, 'f32': F32_MFMA_PEAK_TFLOPS}[arm]
-        return {'kernel': {'fp8': 'attn_lp_kernel<fp8 e4m3>', 'bf16': 'attn_lp_kernel<bf16>', 'x6': 'attn_blockcausal_x6_kernel',
-                           'f32': 'attn_blockcausal_kernel'}[arm], 'bound': 'mfma', 'launches': len(self.attn),
+        name = {'fp8': 'attn_lp_kernel<fp8 e4m3>', 'bf16': 'attn_lp_kernel<bf16>', 'x6': 'attn_blockcausal_x6_kernel',
+                'f32': 'attn_blockcausal_kernel'}[arm]
+        if dma:
+            name = 'attn_dma_kernel (bf16 q/k/v tiles by LDS-DMA, 3 in flight)'
+        return {'kernel': name, 'bound': 'mfma', 'launches': len(self.attn),
                 'B_H_T_L_twin': list(shape), 'avg_launch_us': round(ms / len(self.attn) * 1e3, 1),
                 'achieved': round(fl / ms / 1e9, 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s (useful: visible tile pairs only)',
                 'frac': round(fl / ms / 1e9 / peak, 4),
+                # the other roof: q, k, v read once + o written once (this shape: 140 FLOP/B -> the HBM roof sits at 45 % of the bf16 peak)
+                'hbm': {'algorithmic_bytes_per_launch': by // len(self.attn), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4)},
                 'peak_note': ('non-scaled fp8 MFMA runs at the bf16 rate' if arm == 'fp8' else
                               'x6 executes 6 bf16 MFMA flops per fp32 flop: peak = 2500 / 6' if arm == 'x6' else '')}
 

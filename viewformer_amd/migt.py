@@ -215,9 +215,10 @@ class MIGT:
                  and all(self._dense[f'h.{i}.{n}'].wp16 is not None for i in range(c.n_layer)
                          for n in ('attn.c_attn', 'attn.c_proj', 'mlp.c_fc', 'mlp.c_proj')))
         att = torch.empty((M, d), dtype=torch.bfloat16 if act16 else torch.float32, device=dev)
-        # the fused c_attn output could be bf16 too (the attention kernel takes bf16 q/k/v, bit-identical), but A/B on MI355X it is
-        # 1.3 % slower end to end (938 vs 925 views/s: the 2-byte strided stores of the GEMM epilogue cost more than the bytes saved)
-        qkv16 = act16 and os.environ.get('VF_QKV16', '0') == '1'
+        # the fused c_attn output is bf16 too (bit-identical downstream: the attention kernel rounds fp32 q/k/v to bf16 on load): half
+        # the bytes written by the GEMM and read by the attention, whose LDS-DMA kernel (attention_dma.hip) takes bf16 tiles straight
+        # into LDS.  VF_QKV16=0 keeps fp32 q/k/v (A/B runs).
+        qkv16 = act16 and os.environ.get('VF_QKV16', '1') != '0'
         qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if qkv16 else torch.float32, device=dev)
         for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
             p = f'h.{i}'
