@@ -14,6 +14,8 @@ device allocations, views and the stream only.
 import re
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 
@@ -141,6 +143,8 @@ class VQGAN:
                     c.wp3h = ops.pack_conv3_x3h(w)
             elif split and c.k == 1 and c.cin % 64 == 0 and c.cout >= 64:
                 c.wp6 = ops.pack_dense_nk_x6(w.reshape(c.cout, c.cin))
+                if self.conv_arith == 'x3h' and self.dense_x3h:       # 1x1 convolutions on the 3-product GEMM too (csrc/gemm_x3h.hip)
+                    c.wp3h = ops.pack_dense_nk_x3h(w.reshape(c.cout, c.cin))
             if self.decoder_precision == 'bf16' and (name.startswith('decoder.') or name == 'post_quant_conv'):
                 if c.k == 3 and c.cin % 32 == 0 and c.cout % 128 == 0:
                     c.wp16 = ops.pack_conv3_bf16(w)
@@ -164,7 +168,10 @@ class VQGAN:
                 # fused q|k|v projection: one [C][3C] GEMM
                 w = torch.cat([dev_t(f'{name}.{p}.weight').reshape(c, c) for p in ('q', 'k', 'v')], 0)   # [3C][C] (out,in)
                 b = torch.cat([dev_t(f'{name}.{p}.bias') for p in ('q', 'k', 'v')], 0)
-                self._qkv[name] = (ops.pack_dense_nk_x6(w) if self.conv_arith in ('x6', 'x3h') and c % 64 == 0 else ops.pack_dense_nk(w), b)
+                if self.conv_arith == 'x3h' and self.dense_x3h and c % 64 == 0:
+                    self._qkv[name] = (ops.pack_dense_nk_x3h(w), b)
+                else:
+                    self._qkv[name] = (ops.pack_dense_nk_x6(w) if self.conv_arith in ('x6', 'x3h') and c % 64 == 0 else ops.pack_dense_nk(w), b)
                 conv(name + '.proj_out')
             elif kind == 'norm_swish':
                 norm(name)
@@ -212,9 +219,10 @@ class VQGAN:
         c = self._conv[name]
         out = torch.empty((M, c.cout), dtype=torch.float32, device=x.device)
         bf16 = c.wp16 is not None and pro is None
-        x6 = not bf16 and c.wp6 is not None
-        ops.igemm(x, c.wp16 if bf16 else c.wp6 if x6 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro,
-                  pro_swish=pro_swish, pro_rows_per_img=rows_per_img, bf16=bf16, x6=x6)
+        x3h = not bf16 and c.k == 1 and c.wp3h is not None
+        x6 = not bf16 and not x3h and c.wp6 is not None
+        ops.igemm(x, c.wp16 if bf16 else c.wp3h if x3h else c.wp6 if x6 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro,
+                  pro_swish=pro_swish, pro_rows_per_img=rows_per_img, bf16=bf16, x6=x6, x3h=x3h)
         return out
 
     def _gn(self, x, name, n, HW, C):
@@ -227,6 +235,7 @@ class VQGAN:
 
     _stats_of = None          # (tensor, partials) of the most recent halo-conv output
     fuse_gn_stats = True
+    dense_x3h = os.environ.get('VF_VQ_DENSE_X3H', '1') != '0'     # conv_arith='x3h': 1x1 convolutions / q|k|v projections on the 3-product split-fp16 GEMM (False: 6-product x6)
     fused_attention = True    # AttnBlock core in one kernel where the shape allows (False: batched GEMMs + row softmax, kept for A/B)
 
     def _res(self, x, name, n, H, W, cin, cout):
@@ -245,7 +254,8 @@ class VQGAN:
         pro = self._gn(x, name + '.norm', n, HW, C)
         wp, b = self._qkv[name]
         qkv = torch.empty((M, 3 * C), dtype=torch.float32, device=x.device)
-        ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW, x6=wp.dtype == torch.bfloat16)
+        ops.igemm(x, wp, M, C, 3 * C, qkv, bias=b, pro=pro, pro_swish=False, pro_rows_per_img=HW, x6=wp.dtype == torch.bfloat16,
+                  x3h=wp.dtype == torch.float16)
         if self.fused_attention and ops.attn_spatial_supported(HW, C):
             # scores, softmax and p.v in one kernel: the [HW][HW] matrix never leaves the CU (csrc/attn_spatial.hip)
             a = ops.attn_spatial(qkv, n, HW, C, float(int(C) ** (-0.5)))
