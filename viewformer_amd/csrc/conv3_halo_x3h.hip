@@ -32,6 +32,9 @@
 #ifndef VF_X3H_SB
 #define VF_X3H_SB 1       // sched_barrier(0) at every stage boundary (pins the prefetch distance)
 #endif
+#ifndef VF_X3H_S2_TALL
+#define VF_X3H_S2_TALL 1  // the stride-2 kernel's wave tile (see conv3_s2_x3h_kernel)
+#endif
 #ifndef VF_X3H_TALL
 #define VF_X3H_TALL 1     // wave tile = all 128 pixels x 32 channels (4 x 1 MFMA tiles) instead of 64 pixels x 64 channels (2 x 2): a stage
 #endif                    // then needs 2 weight fragments through the L1 -> VGPR return path instead of 4 (and 8 activation fragments
@@ -279,7 +282,12 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    // wave tile: S2 TALL = all 128 output pixels x 32 channels (4 x 1 MFMA tiles): every weight fragment streamed L2 -> VGPR feeds 4
+    // pixel tiles and no two waves load the same fragment — the 2 x 2 form moved 147 KB of weights + 36 KB of patch per 16-channel
+    // chunk through the CU's L1 path for 14 MFLOP (77 FLOP/B: a 30 % matrix-pipe ceiling at ~16 B/clk/CU; it measured 28 %)
+    constexpr bool TALL = VF_X3H_S2_TALL != 0;
+    constexpr int MI = TALL ? 4 : 2, NJ = TALL ? 1 : 2;
+    const int wave_m = TALL ? 0 : wave >> 1, wave_n = TALL ? wave : wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = p.Cout / BN;
@@ -331,45 +339,46 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     };
 
     const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
-    int a_base[2];
+    int a_base[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) a_base[mi] = (2 * (wave_m * 4 + mi * 2 + trow) * S2_PW + tpx) * S2_LDB + half * 16;
+    for (int mi = 0; mi < MI; ++mi) a_base[mi] = (2 * (wave_m * 4 + mi * 2 + trow) * S2_PW + tpx) * S2_LDB + half * 16;
 
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
-    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    const int b_lane = (half * BN + wave_n * (32 * NJ) + l31) * 16;
     const int last_g = nchunks * 9 - 1;
-    f16x8 bring[3][2][2];
-    f16x8 aring[2][2][2];
-    auto b_load = [&](f16x8 (&dst)[2][2], int g) {            // g = chunk16 * 9 + tap
+    constexpr int S2_BR = 3;                         // weight-fragment ring depth: must divide the 9 taps (the slot is indexed by the tap)
+    f16x8 bring[S2_BR][2][NJ];
+    f16x8 aring[2][MI][2];
+    auto b_load = [&](f16x8 (&dst)[2][NJ], int g) {            // g = chunk16 * 9 + tap
         g = min(g, last_g);
         const int c = g / 9, tap = g - c * 9;
         const unsigned char* src = Wb + (size_t)((c >> 1) * 9 + tap) * tap_stride + (c & 1) * KS_BYTES + b_lane;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+            for (int j = 0; j < NJ; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
     };
-    auto a_load = [&](f16x8 (&dst)[2][2], int tap) {
+    auto a_load = [&](f16x8 (&dst)[MI][2], int tap) {
         const int dy = tap / 3, dx = tap % 3;
         const int off = (dy * S2_PW + (dx & 1) * (TW + 1) + (dx >> 1)) * S2_LDB;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(smem_h + a_base[mi] + off + pl * 32);
     };
 
-    f32x16 acc[2][2], accx[2][2];
+    f32x16 acc[MI][NJ], accx[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
     patch_load(0);
     b_load(bring[0], 0);
-    b_load(bring[1], 1);
+    if (S2_BR > 2) b_load(bring[1], 1);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();                                        // every wave is done reading the previous chunk
         patch_park();
@@ -378,31 +387,31 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
         a_load(aring[0], 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            b_load(bring[(t + 2) % 3], chunk * 9 + t + 2);
+            b_load(bring[(t + S2_BR - 1) % S2_BR], chunk * 9 + t + S2_BR - 1);
             if (t + 1 < 9) a_load(aring[(t + 1) & 1], t + 1);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][1], bring[t % 3][0][j], accx[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][1], bring[t % S2_BR][0][j], accx[mi][j], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % 3][1][j], accx[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % S2_BR][1][j], accx[mi][j], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % 3][0][j], acc[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % S2_BR][0][j], acc[mi][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)(p.Cin / CK) * 9 * nb * TAP_BYTES);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
-    vf_halo_epilogue<false>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+    vf_halo_epilogue_t<false, MI, NJ>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
 
