@@ -45,6 +45,8 @@ def conv_s2(n_img=224, C=128, H=128, x6=True, x3h=False):
 def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
+    if os.environ.get('VF_MB_ZERO') == '1':           # zero operands: no datapath toggling -> how much of the time is power (DVFS)?
+        x.zero_(); w.zero_(); w[0, 0, 0, 0] = 1.0
     wp = ops.pack_conv3_x3h(w) if x3h else ops.pack_conv3_x6(w) if x6 else ops.pack_conv3_bf16(w) if bf16 else ops.pack_conv_oihw(w)
     b = torch.randn(C, device=dev)
     out = torch.empty_like(x)
@@ -223,7 +225,7 @@ def clockprobe(n_img=56, C=128, H=128):
 
 ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
-           convbf16_256=lambda: conv(32, 256, 32, bf16=True),
+           convbf16_256=lambda: conv(32, 256, 32, bf16=True), convbf16_dec=lambda: conv(128, 128, 128, bf16=True), convbf16_dec512=lambda: conv(128, 512, 16, bf16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True),
            attnbf16_s20=lambda: attn(B=12, S=21, twin=19, bf16=True), attnfp8_s20=lambda: attn(B=12, S=21, twin=19, fp8=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),

@@ -13,6 +13,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VF_BF16_CONV_TALL
+#define VF_BF16_CONV_TALL 0     // A/B on MI355X: 694 vs 702 TF (128 ch @128^2), 994 vs 1004 (512 ch @16^2) — the weight stream is not this kernel's bound
+#endif
+
 constexpr int CK = 32;
 constexpr int P_LDB = 80;           // bytes per patch pixel in LDS
 constexpr int TH = 8, TW = 16;
@@ -42,7 +46,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    // wave tile: TALL = all 128 pixels x 32 channels (4 x 1 MFMA tiles, half the weight bytes per wave) instead of 64 pixels x 64
+    // channels (2 x 2).  Unlike the x3h kernels it buys nothing here (see VF_BF16_CONV_TALL): at one MFMA per product the fp32
+    // GroupNorm + swish prologue of the patch (two transcendentals per element) costs about as much as the MFMAs.
+    constexpr bool TALL = VF_BF16_CONV_TALL != 0;
+    constexpr int MI = TALL ? 4 : 2, NJ = TALL ? 1 : 2;
+    const int wave_m = TALL ? 0 : wave >> 1, wave_n = TALL ? wave : wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = p.Cout / BN;
@@ -117,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     };
 
     const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
-    int a_base[2], a_r[2];
+    int a_base[MI], a_r[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int a0 = wave_m * 4 + mi * 2 + trow;
         a_r[mi] = a0;
         const int tcol = PAIR ? (tpx >> 3) * 10 + (tpx & 7) : tpx;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     // packed weights [chunk][tap][nblk][ks(2)][half(2)][n(128)][8 bf16]
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
-    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
+    const int b_lane = (half * BN + wave_n * (32 * NJ) + l31) * 16;
     // software pipeline over taps (g = chunk*9 + tap): weight fragments BD taps ahead in a register ring, LDS fragments one
     // tap ahead; sched_barrier pins the distances (the scheduler otherwise sinks the loads next to their uses)
 #ifndef VF_BF16_BD
@@ -137,21 +146,21 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
 #endif
     constexpr int BD = VF_BF16_BD, RING = BD + 1;
     static_assert(9 % RING == 0, "ring indices must repeat per chunk");
-    bf16x8 bring[RING][4];
-    bf16x8 aring[2][2][2];
+    bf16x8 bring[RING][2 * NJ];
+    bf16x8 aring[2][MI][2];
     const int last_g = nchunks * 9 - 1;
-    auto b_load = [&](bf16x8 (&dst)[4], int g) {
+    auto b_load = [&](bf16x8 (&dst)[2 * NJ], int g) {
         const unsigned char* src = Wb + (size_t)min(g, last_g) * tap_stride;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                dst[ks * 2 + j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16 + b_lane);
+            for (int j = 0; j < NJ; ++j)
+                dst[ks * NJ + j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16 + b_lane);
     };
-    auto a_load = [&](bf16x8 (&dst)[2][2], const unsigned char* patch, int tap) {
+    auto a_load = [&](bf16x8 (&dst)[MI][2], const unsigned char* patch, int tap) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             int aoff;
             if (UP2) {
                 const int pr = (a_r[mi] + dy + 1) >> 1, pc = (tpx + dx + 1) >> 1;
@@ -164,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -190,17 +199,17 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[tap & 1][mi][ks], bring[tap % RING][ks * 2 + j], acc[mi][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j)
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[tap & 1][mi][ks], bring[tap % RING][ks * NJ + j], acc[mi][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (tap >= 1 && tap <= G::SLOTS) patch_store_slot((chunk + 1) & 1, tap - 1);
         }
         __syncthreads();
     }
 
-    vf_halo_epilogue<PAIR>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+    vf_halo_epilogue_t<PAIR, MI, NJ>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 }
 
 __global__ void pack_conv_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cin, int Cout, int nb, int nchunks) {
