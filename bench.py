@@ -155,7 +155,7 @@ class OpTimer:
             tot_fl += fl
             k = by.setdefault(key, [0.0, 0.0, 0])
             k[0] += ms; k[1] += fl; k[2] += 1
-        top = sorted(by.items(), key=lambda kv: -kv[1][0])[:5]
+        top = sorted(by.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get('VF_BENCH_TOP_SHAPES', '5'))]
         return tot_ms, tot_fl, len(self.gemm), top
 
     def vq_entry(self):
