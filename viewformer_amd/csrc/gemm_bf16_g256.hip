@@ -186,13 +186,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef G256_STAMPS       // phase timeline (tools/microbench.py g256_stamps): per wave, cycles summed over the stages
+    unsigned long long tt[6];
+    unsigned acc_t[6] = {0, 0, 0, 0, 0, 0};
+#define G256_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt[i]) :: "memory")
+    G256_STAMP(5);
+#else
+#define G256_STAMP(i)
+#endif
     issue(0);
     for (int s = 0; s < nstages; ++s) {
         // stage s has landed (this wave's pieces: vmcnt; everyone's: the barrier); every wave has finished reading stage s - 1
         // (lgkmcnt: the compiler may leave the last ds_reads in flight up to their MFMA), whose buffer the next DMA overwrites
+        G256_STAMP(3);                                     // MFMAs issued (fragments all consumed)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        G256_STAMP(4);                                     // own DMA pieces landed
         __builtin_amdgcn_s_barrier();
+        G256_STAMP(0);                                     // barrier passed
+#ifdef G256_STAMPS
+        acc_t[3] += (unsigned)(tt[4] - tt[3]);             // wait for the DMA
+        acc_t[4] += (unsigned)(tt[0] - tt[4]);             // wait at the barrier
+        if (s > 0) acc_t[2] += (unsigned)(tt[3] - tt[2]);  // MFMA phase of the previous stage
+#endif
         if (s + 1 < nstages) issue(s + 1);
+        G256_STAMP(1);                                     // DMA issued
         const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
         // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks run (two register sets)
         bf16x8 a[2][4], b[2][2];
@@ -203,6 +220,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
         };
         frags(0, a[0], b[0]);
+#ifdef G256_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G256_STAMP(2);                                     // first fragments in registers
+        acc_t[0] += (unsigned)(tt[1] - tt[0]);
+        acc_t[1] += (unsigned)(tt[2] - tt[1]);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
@@ -216,6 +239,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         }
     }
 
+#ifdef G256_STAMPS
+    G256_STAMP(3);
+    acc_t[2] += (unsigned)(tt[3] - tt[2]);
+    if (p.pro_beta && lane == 0) {                         // (the GEMM has no prologue: the pointer carries the stamp buffer)
+        unsigned* o = reinterpret_cast<unsigned*>(const_cast<float*>(p.pro_beta)) + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = acc_t[i];
+        o[5] = (unsigned)(tt[3] - tt[5]);                  // kernel entry -> end of the main loop
+    }
+#endif
     const bool full = m_tile0 + GM <= p.M;
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
     if (O16) {
