@@ -218,7 +218,8 @@ class MIGT:
         # the fused c_attn output is bf16 too (bit-identical downstream: the attention kernel rounds fp32 q/k/v to bf16 on load): half
         # the bytes written by the GEMM and read by the attention, whose LDS-DMA kernel (attention_dma.hip) takes bf16 tiles straight
         # into LDS.  VF_QKV16=0 keeps fp32 q/k/v (A/B runs).
-        qkv16 = act16 and os.environ.get('VF_QKV16', '1') != '0'
+        # (the fp8 arm's kernel stages its tiles through registers and takes fp32 q/k/v at full speed: no bf16 there)
+        qkv16 = act16 and self.attention != 'fp8' and os.environ.get('VF_QKV16', '1') != '0'
         qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if qkv16 else torch.float32, device=dev)
         for i in range(c.n_layer):                                           # Block.call, migt.py:230-238
             p = f'h.{i}'
