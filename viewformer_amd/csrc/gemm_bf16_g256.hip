@@ -26,6 +26,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef G256_A_VIA_REGS
+#define G256_A_VIA_REGS 0
+#endif
 #ifndef G256_PANEL
 #define G256_PANEL 4          // column tiles per panel (0: all column tiles of a row block together)
 #endif
@@ -34,8 +37,15 @@ constexpr int GA_BYTES = GM * GK * 2;        // 32768
 constexpr int GB_BYTES = GN * GK * 2;        // 32768 = two 128-column packed blocks
 constexpr int GSTAGE = GA_BYTES + GB_BYTES;  // 65536
 
+#ifndef G256_AUX_A
+#define G256_AUX_A 0        // cache-policy bits of the A pieces' DMA (2 = nt)
+#endif
+#ifndef G256_AUX_W
+#define G256_AUX_W 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
 // fp32 output: bias, optional GELU, optional residual.  One code path with wave-uniform flags (eight template instantiations of the
@@ -160,13 +170,27 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     }
     const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * GB_BYTES + wave * 4096 + lane * 16;
-    auto issue = [&](int s) {
+#if G256_A_VIA_REGS      // experiment: the A tile through VGPRs (global_load_dwordx4 + ds_write_b128 into the same swizzled image), W by DMA
+    f32x4 areg[4];
+    auto a_fetch = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) areg[q] = *reinterpret_cast<const f32x4*>(asrc[q] + (size_t)s * (GK * 2));
+    };
+    auto a_park = [&](int s) {
         unsigned char* dst = smem_b + (s & 1) * GSTAGE;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(asrc[q] + (size_t)s * (GK * 2), dst + (wave * 32 + q * 8) * 128);
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + (wave * 32 + q * 8) * 128 + lane * 16) = areg[q];
+    };
+#endif
+    auto issue = [&](int s) {
+        unsigned char* dst = smem_b + (s & 1) * GSTAGE;
+#if !G256_A_VIA_REGS
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16<G256_AUX_A>(asrc[q] + (size_t)s * (GK * 2), dst + (wave * 32 + q * 8) * 128);
+#endif
         const unsigned char* ws = wsrc + (size_t)s * w_stage_stride;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(ws + q * 1024, dst + GA_BYTES + wave * 4096 + q * 1024);
+        for (int q = 0; q < 4; ++q) glds16<G256_AUX_W>(ws + q * 1024, dst + GA_BYTES + wave * 4096 + q * 1024);
     };
 
     // ---- fragment addresses: A row = wave_m * 128 + i * 32 + l31, chunk (ks * 2 + half) ^ ((l31 >> 1) & 7)
@@ -195,6 +219,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #define G256_STAMP(i)
 #endif
     issue(0);
+#if G256_A_VIA_REGS
+    a_fetch(0);
+    a_park(0);
+#endif
     for (int s = 0; s < nstages; ++s) {
         // stage s has landed (this wave's pieces: vmcnt; everyone's: the barrier); every wave has finished reading stage s - 1
         // (lgkmcnt: the compiler may leave the last ds_reads in flight up to their MFMA), whose buffer the next DMA overwrites
@@ -209,6 +237,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         if (s > 0) acc_t[2] += (unsigned)(tt[3] - tt[2]);  // MFMA phase of the previous stage
 #endif
         if (s + 1 < nstages) issue(s + 1);
+#if G256_A_VIA_REGS
+        if (s + 1 < nstages) a_fetch(s + 1);
+#endif
         G256_STAMP(1);                                     // DMA issued
         const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
         // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks run (two register sets)
@@ -237,6 +268,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if G256_A_VIA_REGS
+        if (s + 1 < nstages) a_park(s + 1);                // the idle buffer: last read in stage s - 1
+#endif
     }
 
 #ifdef G256_STAMPS
