@@ -72,6 +72,23 @@ def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
     print(f'gemm[{arith}] {M}x{K}x{N} epi={epi}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TF')
 
 
+def gemm_1x1(M=229376, K=256, N=768, HW=256, pro=True):
+    """the encoder's 1x1 convolutions on the x3h GEMM: the fused q|k|v projection of an AttnBlock (GroupNorm prologue) at the bench's size"""
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    wp = ops.pack_dense_nk_x3h(w)
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    prol = None
+    if pro:
+        n_img = M // HW
+        m, s = ops.groupnorm_stats(x, torch.ones(K, device=dev), n_img, HW, K)
+        prol = (m, s, torch.zeros(K, device=dev))
+    ms = timeit(lambda: ops.igemm(x, wp, M, K, N, out, bias=b, pro=prol, pro_rows_per_img=HW if pro else 0, x3h=True), iters=20)
+    by = M * K * 4 + M * N * 4
+    print(f'gemm_x3h 1x1 {M}x{K}x{N} pro={pro}: {ms * 1e3:.1f} us  {2.0 * M * K * N / ms / 1e9:.1f} TF  {by / ms / 1e6:.0f} GB/s')
+
+
 def gemm_tf(M=65536, only=None):
     """the four dense layers of one transformer block at the bench's size (128 scenes x 8 views x 64 tokens), bf16 arm with bf16
     activations: c_attn (fp32 or bf16 qkv out), attn.c_proj (+ residual), mlp.c_fc (GELU, bf16 out), mlp.c_proj (+ residual)"""
@@ -225,7 +242,7 @@ def clockprobe(n_img=56, C=128, H=128):
 
 ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
-           convbf16_256=lambda: conv(32, 256, 32, bf16=True), convbf16_dec=lambda: conv(128, 128, 128, bf16=True), convbf16_dec512=lambda: conv(128, 512, 16, bf16=True),
+           convbf16_256=lambda: conv(32, 256, 32, bf16=True), convbf16_dec=lambda: conv(128, 128, 128, bf16=True), convbf16_dec_nopro=lambda: conv(128, 128, 128, bf16=True, pro=False), convbf16_dec512=lambda: conv(128, 512, 16, bf16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True),
            attnbf16_s20=lambda: attn(B=12, S=21, twin=19, bf16=True), attnfp8_s20=lambda: attn(B=12, S=21, twin=19, fp8=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),
@@ -236,7 +253,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

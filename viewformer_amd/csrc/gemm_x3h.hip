@@ -16,6 +16,10 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VF_GEMM_X3H_TALL
+#define VF_GEMM_X3H_TALL 0     // A/B on the encoder's 1x1 shapes (tools/microbench.py gemm_1x1*): 143 vs 137, 164 vs 172, 180 vs 181 TF — a tie
+#endif
+
 constexpr int CK = 32;
 constexpr int BM = 128, BN = 128;
 constexpr int A_LDB = 144;                        // bytes per A row in LDS: 2 planes x 64 B + 16 B pad
@@ -37,7 +41,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    // wave tile: TALL = all 128 rows x 32 columns (4 x 1 MFMA tiles) instead of 64 x 64 (2 x 2): no two waves stream the same weight
+    // fragment (half the weight bytes through the CU's vector-memory path; twice the A fragments from LDS, which has headroom)
+    constexpr bool TALL = VF_GEMM_X3H_TALL != 0;
+    constexpr int MI = TALL ? 4 : 2, NJ = TALL ? 1 : 2;
+    const int wave_m = TALL ? 0 : wave >> 1, wave_n = TALL ? wave : wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = (p.Cout + BN - 1) / BN;
@@ -99,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
         *reinterpret_cast<f16x4*>(dst + 64) = ol;
     };
 
-    const int b_lane = (half * BN + wave_n * 64 + l31) * 16;
-    f16x8 bring[2][2][2][2];          // [chunk parity][ks][plane][j]
-    auto b_load = [&](f16x8 (&dst)[2][2][2], int chunk) {
+    const int b_lane = (half * BN + wave_n * (32 * NJ) + l31) * 16;
+    f16x8 bring[2][2][2][NJ];         // [chunk parity][ks][plane][j]
+    auto b_load = [&](f16x8 (&dst)[2][2][NJ], int chunk) {
         chunk = min(chunk, nchunks - 1);
         const unsigned char* src = Wb + (size_t)chunk * chunk_stride + b_lane;
 #pragma unroll
@@ -109,16 +117,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     dst[ks][pl][j] = *reinterpret_cast<const f16x8*>(src + ks * KS_BYTES + pl * PLANE_BYTES + j * 32 * 16);
     };
     const int a_lane = (wave_m * 64 + l31) * A_LDB + half * 16;
 
-    f32x16 acc[2][2], accx[2][2];          // main products ah*bh; cross products (al*2^11)*bh + ah*(bl*2^11)
+    f32x16 acc[MI][NJ], accx[MI][NJ];      // main products ah*bh; cross products (al*2^11)*bh + ah*(bl*2^11)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
@@ -128,32 +136,32 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     for (int q = 0; q < 4; ++q) a_park(0, q);
     __syncthreads();
 
-    auto chunk_body = [&](int chunk, f16x8 (&bcur)[2][2][2], f16x8 (&bnext)[2][2][2]) {
+    auto chunk_body = [&](int chunk, f16x8 (&bcur)[2][2][NJ], f16x8 (&bnext)[2][2][NJ]) {
         const unsigned char* a_src = smem_g + ((chunk - c0) & 1) * A_BYTES + a_lane;
         a_fetch(min(chunk + 1, nchunks - 1));
         b_load(bnext, chunk + 1);
-        f16x8 a[2][2][2];             // [ks][mi][plane]
+        f16x8 a[2][MI][2];            // [ks][mi][plane]
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     a[ks][mi][pl] = *reinterpret_cast<const f16x8*>(a_src + mi * 32 * A_LDB + pl * 64 + ks * 32);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][1], bcur[ks][0][j], accx[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][1], bcur[ks][0][j], accx[mi][j], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][0], bcur[ks][1][j], accx[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][0], bcur[ks][1][j], accx[mi][j], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][0], bcur[ks][0][j], acc[mi][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][mi][0], bcur[ks][0][j], acc[mi][j], 0, 0, 0);
             a_park((chunk - c0 + 1) & 1, ks * 2);
             a_park((chunk - c0 + 1) & 1, ks * 2 + 1);
         }
@@ -168,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     // out = (acc + accx * 2^-11) / S, S = the power-of-two weight scale stored behind the packed planes
     const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)total_chunks * chunk_stride);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
     float* __restrict__ Out = p.out + (size_t)blockIdx.y * p.stride_out;
@@ -179,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     const long long ldc = p.ldc, ldr = p.ldr;
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nblk * BN + wave_n * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nblk * BN + wave_n * (32 * NJ) + j * 32 + l31;
         const bool nok = n < p.Cout;
         const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
             const int nn = nok ? n : 0;
             float* o = Out + (size_t)(m0 < p.M ? m0 : 0) * ldc + nn;
