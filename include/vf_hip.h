@@ -206,6 +206,9 @@ int vf_attn_blockcausal_x6(const float* q, const float* k, const float* v, float
  * (v_mfma_f32_32x32x2_f32 + libm expf); the [HW][HW] score matrix never leaves the CU.  (HW, C) in {(256, 256), (64, 512), (64, 256)}
  * (VF_ERR_UNSUPPORTED otherwise: batched vf_igemm_f32 + vf_softmax_rows_f32). */
 int vf_attn_spatial_f32(const float* qkv, float* out, int n_img, int HW, int C, int64_t ld, int64_t ldo, float scale, void* stream);
+/* The same contract in fp32-EQUIVALENT "x3h" arithmetic on the fp16 matrix pipe (two fp16 pieces per operand, three exact products; see
+ * vf_conv3_halo_x3h): what the encoder's AttnBlocks run under conv_arith = 'x3h'.  Error against fp64 not above vf_attn_spatial_f32's. */
+int vf_attn_spatial_x3h(const float* qkv, float* out, int n_img, int HW, int C, int64_t ld, int64_t ldo, float scale, void* stream);
 /* row softmax with scale (VQGAN AttnBlock, vqgan_th.py:132-134): x[r][0:n] in place */
 int vf_softmax_rows_f32(float* x, int64_t rows, int n, float scale, void* stream);
 

@@ -425,3 +425,14 @@ def test_fused_spatial_attention_matches_fp64_and_batched_form(dev, HW, C, n):
     ops.igemm(S, vp, HW, HW, C, a, lda=HW, batch=n, stride_x=HW * HW, stride_w=ops.packed_floats(HW, C), stride_out=HW * C)
     assert (got - a).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
     assert not ops.attn_spatial_supported(128, 256)
+    # the x3h form (fp16 matrix pipe, three exact products per fp32 product): fp32-equivalent — its error against fp64 is not above the
+    # native kernel's (+ the representation floor), on unit-scale inputs and on inputs whose softmax is peaked (tiny probabilities)
+    for mul in (1.0, 4.0):
+        qk = qkv.clone()
+        qk[:, :2 * C] *= mul ** 0.5
+        q, k, v = [t.double().cpu().view(n, HW, C) for t in (qk[:, :C], qk[:, C:2 * C], qk[:, 2 * C:])]
+        ref2 = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
+        e32 = (ops.attn_spatial(qk, n, HW, C, scale).cpu().double().view(n, HW, C) - ref2).abs().max().item()
+        e3h = (ops.attn_spatial(qk, n, HW, C, scale, x3h=True).cpu().double().view(n, HW, C) - ref2).abs().max().item()
+        print(f'attn_spatial HW={HW} C={C} x{mul}: f32 err {e32:.2e}  x3h err {e3h:.2e}')
+        assert e3h < 1.25 * e32 + 2e-7 * max(1.0, ref2.abs().max().item()), (e3h, e32)

@@ -87,6 +87,7 @@ EXPORTS = {
     'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_attn_spatial_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
+    'vf_attn_spatial_x3h': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
     'vf_layernorm_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_layernorm_bf16out_f32': (c_int, [P, P, P, P, c_int64, c_int, c_float, P]),

@@ -454,12 +454,14 @@ def attn_spatial_supported(HW, C):
     return (HW, C) in ((256, 256), (64, 512), (64, 256))
 
 
-def attn_spatial(qkv, n_img, HW, C, scale, out=None):
-    """fused single-head attention of the VQGAN AttnBlock: qkv [n_img*HW][3C] (q|k|v) -> [n_img*HW][C]; scores stay on chip"""
+def attn_spatial(qkv, n_img, HW, C, scale, out=None, x3h=False):
+    """fused single-head attention of the VQGAN AttnBlock: qkv [n_img*HW][3C] (q|k|v) -> [n_img*HW][C]; scores stay on chip.
+    ``x3h``: the fp32-equivalent three-product fp16 form (vf_attn_spatial_x3h) instead of the native f32 MFMA"""
     if out is None:
         out = torch.empty((n_img * HW, C), dtype=torch.float32, device=qkv.device)
-    check(_lib.load().vf_attn_spatial_f32(_p(_f32(qkv)), _p(_f32(out)), n_img, HW, C, qkv.stride(0), out.stride(0), scale, _stream()),
-          'vf_attn_spatial_f32')
+    fn = _lib.load().vf_attn_spatial_x3h if x3h else _lib.load().vf_attn_spatial_f32
+    check(fn(_p(_f32(qkv)), _p(_f32(out)), n_img, HW, C, qkv.stride(0), out.stride(0), scale, _stream()),
+          'vf_attn_spatial_x3h' if x3h else 'vf_attn_spatial_f32')
     return out
 
 

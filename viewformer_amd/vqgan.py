@@ -258,7 +258,7 @@ class VQGAN:
                   x3h=wp.dtype == torch.float16)
         if self.fused_attention and ops.attn_spatial_supported(HW, C):
             # scores, softmax and p.v in one kernel: the [HW][HW] matrix never leaves the CU (csrc/attn_spatial.hip)
-            a = ops.attn_spatial(qkv, n, HW, C, float(int(C) ** (-0.5)))
+            a = ops.attn_spatial(qkv, n, HW, C, float(int(C) ** (-0.5)), x3h=self.conv_arith == 'x3h' and self.dense_x3h)
             return self._conv1(a, name + '.proj_out', M, res=x)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         # scores[b] = q_b @ k_b^T : B[kk=c][nn=key] = k[key][c]
