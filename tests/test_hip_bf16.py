@@ -263,7 +263,8 @@ def test_bf16_activation_chain_is_bit_identical(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize('M,K,N', [(512, 128, 256), (1000, 768, 768), (2048, 768, 2304), (1290, 3072, 768), (4096, 768, 3072)])
+@pytest.mark.parametrize('M,K,N', [(512, 128, 256), (1000, 768, 768), (2048, 768, 2304), (1290, 3072, 768), (4096, 768, 3072), (770, 256, 1280),
+                                   (1536, 256, 512), (2048, 128, 2048)])
 def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N, monkeypatch):
     """the 256 x 256 LDS-DMA kernel (gemm_bf16_g256.hip, taken for bf16 activations and 256-aligned widths) against the 128 x 128 kernel
     (VF_GEMM_G256=0): same MFMA, same k order, fp32 epilogue -> the same bits; ragged last row tile, residual, GELU, bf16 output;
