@@ -31,6 +31,12 @@ constexpr int DH = 64, KT = 64, QT = 256, RING = 4;
 constexpr int K_BYTES = KT * DH * 2;         // 8192
 constexpr int TILE_BYTES = 2 * K_BYTES;      // K image then V image
 
+#ifndef ADMA_BUFFER
+#define ADMA_BUFFER 1       // buffer_load ... lds with an SGPR resource per (scene, head) and 32-bit lane offsets instead of 64-bit lane addresses
+#endif
+__device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
@@ -68,6 +74,12 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     const unsigned char* qb8 = reinterpret_cast<const unsigned char*>(q + b * (size_t)T * ldq + h * DH);
     const unsigned char* kb8 = reinterpret_cast<const unsigned char*>(k + b * (size_t)T * ldk + h * DH);
     const unsigned char* vb8 = reinterpret_cast<const unsigned char*>(v + b * (size_t)T * ldv + h * DH);
+#if ADMA_BUFFER
+    // one resource per operand, based at this (scene, head): lane offsets stay below T * ld * 2 bytes
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(qb8), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(kb8), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(vb8), 0, 0x7fffffff, 0x00020000);
+#endif
 
     // visibility of key view kv from query view qv (attention_f32.hip): plain block-causal kv <= qv; twin = Vc >= 0: views Vc, Vc+1, ...
     // are alternative endings (each sees the prefix and itself); twin <= -2: STREAMS with Sv = -twin views per stream
@@ -94,13 +106,21 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
             const int r = pi * 8 + pr;
+#if ADMA_BUFFER
+            bufds16(k_rs, dst + pi * 1024, (unsigned)(r * ldk * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), (unsigned)(t * KT * ldk * 2));
+#else
             glds16(kb8 + ((size_t)(t * KT + r) * ldk) * 2 + ((pc ^ ((r >> 1) & 7)) << 4), dst + pi * 1024);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
             const int key = (pi & 3) * 16 + (lane >> 2);
+#if ADMA_BUFFER
+            bufds16(v_rs, dst + K_BYTES + pi * 1024, (unsigned)(key * ldv * 2 + (pi >> 2) * 64 + (lane & 3) * 16), (unsigned)(t * KT * ldv * 2));
+#else
             glds16(vb8 + ((size_t)(t * KT + key) * ldv) * 2 + (pi >> 2) * 64 + (lane & 3) * 16, dst + K_BYTES + pi * 1024);
+#endif
         }
     };
     // Q: the wave's 64 rows -> its private 8 KB of ring slots 2-3 (same swizzled row image as K)
@@ -109,7 +129,11 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     for (int pi = 0; pi < 8; ++pi) {
         const int r = pi * 8 + pr;
         const int row = min(qw0 + r, T - 1);
+#if ADMA_BUFFER
+        bufds16(q_rs, Qs + pi * 1024, (unsigned)(row * ldq * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), 0u);
+#else
         glds16(qb8 + ((size_t)row * ldq) * 2 + ((pc ^ ((r >> 1) & 7)) << 4), Qs + pi * 1024);
+#endif
     }
     issue_tile(0);
     if (ntiles > 1) issue_tile(1);
@@ -282,6 +306,7 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
                        float scale, int twin_view, hipStream_t stream) {
     if (L != KT || T % KT != 0 || ((ldq | ldk | ldv | ldo) & 7)) return VF_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return VF_ERR_UNSUPPORTED;
+    if ((size_t)T * (size_t)(ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv)) * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit offsets per (scene, head)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);

@@ -43,6 +43,13 @@ constexpr int GSTAGE = GA_BYTES + GB_BYTES;  // 65536
 #ifndef G256_AUX_W
 #define G256_AUX_W 0
 #endif
+#ifndef G256_BUFFER
+#define G256_BUFFER 1       // buffer_load_dwordx4 ... lds (SGPR resource + 32-bit lane offsets) instead of global_load_lds_dwordx4 (64-bit lane
+                            // addresses): the address path is part of what a piece costs — mlp.c_proj 325 -> 304 us, c_attn 261 -> 244 us
+#endif
+__device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
 template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
@@ -168,6 +175,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         m = m < p.M ? m : p.M - 1;
         asrc[q] = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)m * p.lda) * 2 + c * 16;
     }
+#if G256_BUFFER
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_packed), 0, 0x7fffffff, 0x00020000);
+    unsigned avoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) avoff[q] = (unsigned)(asrc[q] - reinterpret_cast<const unsigned char*>(p.x));
+    const unsigned wvoff = (unsigned)((size_t)nblk * GB_BYTES + wave * 4096 + lane * 16);
+#endif
     const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * GB_BYTES + wave * 4096 + lane * 16;
 #if G256_A_VIA_REGS      // experiment: the A tile through VGPRs (global_load_dwordx4 + ds_write_b128 into the same swizzled image), W by DMA
@@ -184,6 +199,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #endif
     auto issue = [&](int s) {
         unsigned char* dst = smem_b + (s & 1) * GSTAGE;
+#if G256_BUFFER
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bufds16(a_rsrc, dst + (wave * 32 + q * 8) * 128, avoff[q], (unsigned)(s * (GK * 2)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bufds16(w_rsrc, dst + GA_BYTES + wave * 4096 + q * 1024, wvoff + q * 1024, (unsigned)((size_t)s * w_stage_stride));
+#else
 #if !G256_A_VIA_REGS
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16<G256_AUX_A>(asrc[q] + (size_t)s * (GK * 2), dst + (wave * 32 + q * 8) * 128);
@@ -191,6 +212,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         const unsigned char* ws = wsrc + (size_t)s * w_stage_stride;
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16<G256_AUX_W>(ws + q * 1024, dst + GA_BYTES + wave * 4096 + q * 1024);
+#endif
     };
 
     // ---- fragment addresses: A row = wave_m * 128 + i * 32 + l31, chunk (ks * 2 + half) ^ ((l31 >> 1) & 7)
@@ -305,7 +327,8 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     const bool a16 = a.reserved0 & 1, o16 = a.reserved0 & 2;
     if (!a16 || a.batch > 1 || a.Cout % GN != 0 || a.Cin % GK != 0 || a.M < GM || (a.lda & 7)) return VF_ERR_UNSUPPORTED;
     if (o16 && (a.res || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
-    if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;     // (no layer has both; the 128-tile kernel contracts gelu * + res)
+    if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
+    if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
