@@ -49,6 +49,20 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VF_X3H_XBUF
+#define VF_X3H_XBUF 1       // patch loads of the stride-1 kernel through a per-image buffer resource
+#endif
+#ifndef VF_X3H_S2_WBUF
+#define VF_X3H_S2_WBUF 0    // the stride-2 kernel measured slower with buffer loads (240 vs 245 TF, 277 vs 296)
+#endif
+#ifndef VF_X3H_WBUF
+#define VF_X3H_WBUF 1       // weight fragments by buffer_load_dwordx4 (SGPR resource + scalar stage offset + 32-bit lane offset) instead of 64-bit lane addresses
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 wbuf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 constexpr int CK = 32;
 constexpr int P_LDB = 144;          // bytes per patch pixel in LDS: 2 planes x 64 B + 16 B pad
 constexpr int TH = 8, TW = 16;
@@ -125,10 +139,20 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 
     f32x4 preg[G::SLOTS];
     f32x4 pmean, pscale, pbeta, pmean1, pscale1;
+#if VF_X3H_XBUF
+    // the image's activations as a buffer resource (an image is < 2 GB; the whole tensor is not): 32-bit lane offsets + a scalar chunk offset
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+#endif
     auto patch_load = [&](int chunk) {
+#if VF_X3H_XBUF
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q)
+            preg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (unsigned)s_off[q] * 4u, (unsigned)(chunk * CK * 4), 0));
+#else
         const float* xc = X + chunk * CK;
 #pragma unroll
         for (int q = 0; q < G::SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+#endif
         if (PRO) {
             pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
             pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
@@ -180,13 +204,24 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     f16x8 bring[RING][2][NJ];
     f16x8 aring[2][MI][2];
     const int last_g = nchunks * 18 - 1;
+#if VF_X3H_WBUF
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
+#endif
     auto b_load = [&](f16x8 (&dst)[2][NJ], int g) {
         g = min(g, last_g);
+#if VF_X3H_WBUF
+        const unsigned soff = (unsigned)((size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dst[pl][j] = wbuf_load(w_rs, (unsigned)(b_lane + pl * PLANE_BYTES + j * 32 * 16), soff);
+#else
         const unsigned char* src = Wb + (size_t)(g >> 1) * tap_stride + (g & 1) * KS_BYTES + b_lane;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+#endif
     };
     auto a_load = [&](f16x8 (&dst)[MI][2], const unsigned char* patch, int s) {
         const int tap = s >> 1, ks = s & 1;
@@ -350,14 +385,25 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     constexpr int S2_BR = 3;                         // weight-fragment ring depth: must divide the 9 taps (the slot is indexed by the tap)
     f16x8 bring[S2_BR][2][NJ];
     f16x8 aring[2][MI][2];
+#if VF_X3H_S2_WBUF
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
+#endif
     auto b_load = [&](f16x8 (&dst)[2][NJ], int g) {            // g = chunk16 * 9 + tap
         g = min(g, last_g);
         const int c = g / 9, tap = g - c * 9;
+#if VF_X3H_S2_WBUF
+        const unsigned soff = (unsigned)((size_t)((c >> 1) * 9 + tap) * tap_stride + (c & 1) * KS_BYTES);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dst[pl][j] = wbuf_load(w_rs, (unsigned)(b_lane + pl * PLANE_BYTES + j * 32 * 16), soff);
+#else
         const unsigned char* src = Wb + (size_t)((c >> 1) * 9 + tap) * tap_stride + (c & 1) * KS_BYTES + b_lane;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) dst[pl][j] = *reinterpret_cast<const f16x8*>(src + pl * PLANE_BYTES + j * 32 * 16);
+#endif
     };
     auto a_load = [&](f16x8 (&dst)[MI][2], int tap) {
         const int dy = tap / 3, dx = tap % 3;
