@@ -13,6 +13,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VF_BF16_CONV_BUF
+#define VF_BF16_CONV_BUF 1
+#endif
 #ifndef VF_BF16_CONV_TALL
 #define VF_BF16_CONV_TALL 0     // A/B on MI355X: 694 vs 702 TF (128 ch @128^2), 994 vs 1004 (512 ch @16^2) — the weight stream is not this kernel's bound
 #endif
@@ -94,10 +97,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
 
     f32x4 preg[G::SLOTS];
     f32x4 pmean, pscale, pbeta, pmean1, pscale1;
+#if VF_BF16_CONV_BUF      // buffer resources (SGPR base, scalar chunk / tap offset, 32-bit lane offsets) for the patch and the weight stream
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+#endif
     auto patch_load = [&](int chunk) {
+#if VF_BF16_CONV_BUF
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q)
+            preg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (unsigned)s_off[q] * 4u, (unsigned)(chunk * CK * 4), 0));
+#else
         const float* xc = X + chunk * CK;
 #pragma unroll
         for (int q = 0; q < G::SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(xc + s_off[q]);
+#endif
         if (PRO) {
             pmean = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)img * p.Cin + chunk * CK + c4 * 4);
             pscale = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)img * p.Cin + chunk * CK + c4 * 4);
@@ -149,13 +161,25 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_bf16_kernel(vf_igemm_args p
     bf16x8 bring[RING][2 * NJ];
     bf16x8 aring[2][MI][2];
     const int last_g = nchunks * 9 - 1;
+#if VF_BF16_CONV_BUF
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
+#endif
     auto b_load = [&](bf16x8 (&dst)[2 * NJ], int g) {
+#if VF_BF16_CONV_BUF
+        const unsigned soff = (unsigned)((size_t)min(g, last_g) * tap_stride);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                dst[ks * NJ + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (unsigned)((ks * 2 * BN + j * 32) * 16 + b_lane), soff, 0));
+#else
         const unsigned char* src = Wb + (size_t)min(g, last_g) * tap_stride;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 dst[ks * NJ + j] = *reinterpret_cast<const bf16x8*>(src + (ks * 2 * BN + j * 32) * 16 + b_lane);
+#endif
     };
     auto a_load = [&](bf16x8 (&dst)[MI][2], const unsigned char* patch, int tap) {
         const int dy = tap / 3, dx = tap % 3;
