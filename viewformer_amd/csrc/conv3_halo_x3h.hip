@@ -52,6 +52,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef VF_X3H_XBUF
 #define VF_X3H_XBUF 1       // patch loads of the stride-1 kernel through a per-image buffer resource
 #endif
+#ifndef VF_X3H_WFIRST
+#define VF_X3H_WFIRST 1
+#endif
+#ifndef VF_X3H_S2_WFIRST
+#define VF_X3H_S2_WFIRST 1
+#endif
 #ifndef VF_X3H_S2_WBUF
 #define VF_X3H_S2_WBUF 0    // the stride-2 kernel measured slower with buffer loads (240 vs 245 TF, 277 vs 296)
 #endif
@@ -257,11 +263,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
+        // (vmcnt retires in issue order: stage BD's weight fragments go out BEFORE the patch loads, so that no fragment needed within the
+        // next BD stages is queued behind HBM latency — see the stride-2 kernel, where this order is worth 20 %)
+#if VF_X3H_WFIRST
+        b_load(bring[BD % RING], chunk * 18 + BD);
+#endif
+#ifdef VF_X3H_X_NOPATCH      // ablation: what do the next chunk's patch loads (HBM latency in front of the in-order vmcnt queue) cost?
+        if (chunk == 0)
+#endif
         patch_load(min(chunk + 1, nchunks - 1));
         if (AD) a_load(aring[0], patch, 0);
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
-            b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
+            if (!VF_X3H_WFIRST || s > 0) b_load(bring[(s + BD) % RING], chunk * 18 + s + BD);
             if (AD == 0) a_load(aring[s & 1], patch, s);
             else if (VF_X3H_SB != 3 && s + 1 < 18) a_load(aring[(s + 1) & 1], patch, s + 1);
             if (VF_X3H_SB == 2) __builtin_amdgcn_sched_barrier(0);      // loads are issued before this stage's MFMAs
@@ -428,12 +442,21 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();                                        // every wave is done reading the previous chunk
         patch_park();
+        // vmcnt retires loads in issue order: a weight fragment issued AFTER the next chunk's patch loads (HBM latency) cannot be consumed
+        // before they have landed.  So tap 2's fragments go out first — the patch then has until tap 3 instead of tap 2 (without the
+        // patch loads at all the kernel runs 354 instead of 240 TF: that wait is its bound).
+#if VF_X3H_S2_WFIRST
+        b_load(bring[(S2_BR - 1) % S2_BR], chunk * 9 + S2_BR - 1);
+#endif
+#ifdef VF_X3H_X_NOPATCH
+        if (chunk == 0)
+#endif
         patch_load(min(chunk + 1, nchunks - 1));
         __syncthreads();
         a_load(aring[0], 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            b_load(bring[(t + S2_BR - 1) % S2_BR], chunk * 9 + t + S2_BR - 1);
+            if (!VF_X3H_S2_WFIRST || t > 0) b_load(bring[(t + S2_BR - 1) % S2_BR], chunk * 9 + t + S2_BR - 1);
             if (t + 1 < 9) a_load(aring[(t + 1) & 1], t + 1);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
