@@ -34,7 +34,10 @@ __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
     l = (_Float16)((x - (float)h) * 2048.f);
 }
 
-template <bool PRO, bool SWISH>
+// PIMG: distinct images among the 4 rows a thread stages (rows r0 + 32 q of a 128-row tile): 1 when an image has a multiple of 128 rows,
+// 2 for a multiple of 64, else 4 — the per-image GroupNorm mean / scale registers of the prologue shrink with it (32 -> 8 / 16 registers:
+// the 4-image form spilled 54 registers into the staging path of every chunk)
+template <bool PRO, bool SWISH, int PIMG = 4>
 __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];   // [2][A_BYTES]
 
@@ -76,16 +79,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
     }
     f32x4 areg[4];
     f32x4 pbeta;
-    f32x4 pmean[4], pscale[4];
+    f32x4 pmean[PIMG], pscale[PIMG];
     auto a_fetch = [&](int chunk) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) areg[q] = *reinterpret_cast<const f32x4*>(arow[q] + chunk * CK);
         if (PRO) {
             pbeta = *reinterpret_cast<const f32x4*>(p.pro_beta + chunk * CK + c4 * 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pmean[q] = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)aimg[q] * p.Cin + chunk * CK + c4 * 4);
-                pscale[q] = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)aimg[q] * p.Cin + chunk * CK + c4 * 4);
+            for (int i = 0; i < PIMG; ++i) {
+                pmean[i] = *reinterpret_cast<const f32x4*>(p.pro_mean + (size_t)aimg[i * (4 / PIMG)] * p.Cin + chunk * CK + c4 * 4);
+                pscale[i] = *reinterpret_cast<const f32x4*>(p.pro_scale + (size_t)aimg[i * (4 / PIMG)] * p.Cin + chunk * CK + c4 * 4);
             }
         }
     };
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(vf_igemm_args p) {
         for (int e = 0; e < 4; ++e) {
             float t = areg[q][e];
             if (PRO) {
-                t = (t - pmean[q][e]) * pscale[q][e] + pbeta[e];
+                t = (t - pmean[q * PIMG / 4][e]) * pscale[q * PIMG / 4][e] + pbeta[e];
                 if (SWISH) t = vf_swish_1ulp(t);
             }
             _Float16 h, l;
@@ -257,12 +260,12 @@ __global__ void pack_gemm_x3h_kernel(const float* __restrict__ src, _Float16* __
     }
 }
 
-template <bool PRO, bool SWISH>
+template <bool PRO, bool SWISH, int PIMG = 4>
 int launch(const vf_igemm_args& a, hipStream_t stream) {
     const size_t smem = (size_t)2 * A_BYTES;
     const int nb = (a.Cout + BN - 1) / BN, mt = (a.M + BM - 1) / BM;
     const int nsplit = a.reserved0 > 1 ? a.reserved0 : 1;
-    hipLaunchKernelGGL((gemm_x3h_kernel<PRO, SWISH>), dim3((unsigned)(mt * nb), (unsigned)nsplit), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_x3h_kernel<PRO, SWISH, PIMG>), dim3((unsigned)(mt * nb), (unsigned)nsplit), dim3(256), smem, stream, a);
     return vf_last_status();
 }
 
@@ -305,6 +308,9 @@ int vf_gemm_x3h(const vf_igemm_args* args, void* stream) {
         return VF_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (!a.pro_mean) return launch<false, false>(a, s);
+    // (a clamped tail row of the last tile may belong to a later image than its group's first row; it is never stored)
+    if (a.pro_rows_per_img % 128 == 0) return a.pro_swish ? launch<true, true, 1>(a, s) : launch<true, false, 1>(a, s);
+    if (a.pro_rows_per_img % 64 == 0) return a.pro_swish ? launch<true, true, 2>(a, s) : launch<true, false, 2>(a, s);
     return a.pro_swish ? launch<true, true>(a, s) : launch<true, false>(a, s);
 }
 
