@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 
     const int c4 = tid & 7;
     int s_off[G::SLOTS];
-    bool s_ok[G::SLOTS];
-    int s_sel[G::SLOTS];
-    int s_lds[G::SLOTS];
+    unsigned ok_mask = 0, sel_mask = 0;            // bit q: slot q is inside the image / belongs to the pair's second image (two registers
+                                                   // instead of 2 x SLOTS: the pair form spilled 10)
+    // LDS slot of staging slot q: pixel (tid >> 3) + 32 q — only the LAST slot can run past the patch (-> the dummy pixel), the others are
+    // one base register + a compile-time offset
+    const int lds0 = (tid >> 3) * P_LDB + c4 * 8;
+    int lds_last = 0;
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) {
         const int pix = (tid >> 3) + 32 * q;
@@ -135,12 +138,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
         const int pr = pixc / G::PW, pc0 = pixc - pr * G::PW;
         const int sel = PAIR ? (pc0 >= 10) : 0;
         const int pc = pc0 - 10 * sel;
-        s_sel[q] = sel;
+        sel_mask |= (unsigned)sel << q;
         const int sy = sy0 + pr, sx = sx0 + pc;
         const bool ok = pix < G::NPIX && sy >= 0 && sy < p.Hin && sx >= 0 && sx < p.Win;
-        s_ok[q] = ok;
+        ok_mask |= (unsigned)ok << q;
         s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
-        s_lds[q] = pixc * P_LDB + c4 * 8;
+        if (q == G::SLOTS - 1) lds_last = pixc * P_LDB + c4 * 8;
     }
 
     f32x4 preg[G::SLOTS];
@@ -170,19 +173,19 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
         }
     };
     auto patch_store_slot = [&](int buf, int q) {
-        unsigned char* dst = smem_h + buf * G::BUF + s_lds[q];
+        unsigned char* dst = smem_h + buf * G::BUF + (q == G::SLOTS - 1 ? lds_last : lds0 + q * 32 * P_LDB);
         f16x4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = preg[q][e];
             if (PRO) {
-                const float mu = (PAIR && s_sel[q]) ? pmean1[e] : pmean[e];
-                const float sc = (PAIR && s_sel[q]) ? pscale1[e] : pscale[e];
+                const float mu = (PAIR && ((sel_mask >> q) & 1u)) ? pmean1[e] : pmean[e];
+                const float sc = (PAIR && ((sel_mask >> q) & 1u)) ? pscale1[e] : pscale[e];
                 t = (t - mu) * sc + pbeta[e];
                 if (SWISH) t = VF_X3H_PRECISE_SWISH ? vf_swish(t) : vf_swish_1ulp(t);
             }
             _Float16 h, l;
-            split2(s_ok[q] ? t : 0.f, h, l);
+            split2(((ok_mask >> q) & 1u) ? t : 0.f, h, l);
             oh[e] = h; ol[e] = l;
         }
         *reinterpret_cast<f16x4*>(dst) = oh;
