@@ -97,6 +97,17 @@ def attnsp(n=896, HW=256, C=256):
         print(f'attn_spatial{" x3h" if x3h else " f32"} {n}x{HW}x{C}: {ms * 1e3:.1f} us  {4.0 * n * HW * HW * C / ms / 1e9:.1f} TF')
 
 
+def convout(n_img=128, C=128, H=128):
+    """the decoder's conv_out (128 -> 3, norm_out + swish fused) at the bench's size"""
+    x = torch.randn(n_img * H * H, C, device=dev)
+    w = torch.randn(3, C, 3, 3, device=dev) * 0.05
+    b = torch.randn(3, device=dev)
+    m, s = ops.groupnorm_stats(x, torch.ones(C, device=dev), n_img, H * H, C)
+    pro = (m, s, torch.zeros(C, device=dev))
+    ms = timeit(lambda: ops.conv3_small_cout(x, w, b, n_img, H, H, C, 3, pro=pro, pro_swish=True), iters=20)
+    print(f'conv_out {C}->3 @{H}^2 x{n_img}: {ms * 1e3:.1f} us  {x.numel() * 4 / ms / 1e6:.0f} GB/s read')
+
+
 def gemm_tf(M=65536, only=None):
     """the four dense layers of one transformer block at the bench's size (128 scenes x 8 views x 64 tokens), bf16 arm with bf16
     activations: c_attn (fp32 or bf16 qkv out), attn.c_proj (+ residual), mlp.c_fc (GELU, bf16 out), mlp.c_proj (+ residual)"""
@@ -261,7 +272,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, convout=convout, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

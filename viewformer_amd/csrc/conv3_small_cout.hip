@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
                                                                const float* __restrict__ pro_beta, float* __restrict__ out,
                                                                int H, int W, int Cin, int Cout) {
     __shared__ __attribute__((aligned(16))) float patch[NPIX * P_LD];
-    __shared__ __attribute__((aligned(16))) float wl[9 * CK * MAXCO];
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // ALL weights, once: [chunk][tap][c][MAXCO] (Cin / 32 x 4.6 KB)
     const int tid = threadIdx.x;
     const int tilesX = W / TW, tilesY = H / TH;
     int bid = blockIdx.x;
@@ -34,13 +34,40 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
     const float* __restrict__ X = x + (size_t)img * H * W * Cin;
     const int c4 = tid & 7;
     const int px = tid & 31, py = tid >> 5;
+    const int nchunks = Cin / CK;
 
     float acc[MAXCO];
 #pragma unroll
     for (int co = 0; co < MAXCO; ++co) acc[co] = (co < Cout && bias) ? bias[co] : 0.f;
 
-    for (int chunk = 0; chunk < Cin / CK; ++chunk) {
-        __syncthreads();                                   // the previous chunk's readers are done
+    // weights: wl[chunk][tap][c][co] from OIHW w[co][Cin][3][3] (the first version re-gathered a chunk's 1152 values from global per chunk)
+    for (int i = tid; i < nchunks * 9 * CK * MAXCO; i += 256) {
+        const int co = i & (MAXCO - 1), c = (i >> 2) & (CK - 1), tap = (i / (CK * MAXCO)) % 9, chunk = i / (9 * CK * MAXCO);
+        wl[i] = co < Cout ? w[((size_t)co * Cin + chunk * CK + c) * 9 + tap] : 0.f;
+    }
+    // patch slots of this thread (the next chunk's raw values are fetched one chunk ahead: the first version loaded and used them in
+    // the same chunk, exposing the HBM latency four times per workgroup)
+    int s_off[SLOTS];
+    unsigned ok_mask = 0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int pixc = pix < NPIX ? pix : 0;
+        const int pr = pixc / PW, pc = pixc - pr * PW;
+        const int sy = y0 - 1 + pr, sx = x0 - 1 + pc;
+        const bool ok = pix < NPIX && sy >= 0 && sy < H && sx >= 0 && sx < W;
+        ok_mask |= (unsigned)ok << q;
+        s_off[q] = ok ? (sy * W + sx) * Cin + c4 * 4 : c4 * 4;
+    }
+    f32x4 preg[SLOTS];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + s_off[q] + chunk * CK);
+    };
+    fetch(0);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();                                   // the previous chunk's readers are done (chunk 0: the weights are in place)
         f32x4 pm = {0.f, 0.f, 0.f, 0.f}, ps = pm, pb = pm;
         if (PRO) {
             pm = *reinterpret_cast<const f32x4*>(pro_mean + (size_t)img * Cin + chunk * CK + c4 * 4);
@@ -51,12 +78,9 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
         for (int q = 0; q < SLOTS; ++q) {
             const int pix = (tid >> 3) + 32 * q;
             if (pix < NPIX) {
-                const int pr = pix / PW, pc = pix - pr * PW;
-                const int sy = y0 - 1 + pr, sx = x0 - 1 + pc;
-                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    v = *reinterpret_cast<const f32x4*>(X + ((size_t)sy * W + sx) * Cin + chunk * CK + c4 * 4);
+                if ((ok_mask >> q) & 1u) {
+                    v = preg[q];
                     if (PRO) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -69,16 +93,12 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
                 *reinterpret_cast<f32x4*>(patch + pix * P_LD + c4 * 4) = v;
             }
         }
-        // weights of this chunk: wl[tap][c][co] from OIHW w[co][Cin][3][3]
-        for (int i = tid; i < 9 * CK * MAXCO; i += 256) {
-            const int co = i & (MAXCO - 1), c = (i >> 2) & (CK - 1), tap = i / (CK * MAXCO);
-            wl[i] = co < Cout ? w[((size_t)co * Cin + chunk * CK + c) * 9 + tap] : 0.f;
-        }
+        if (chunk + 1 < nchunks) fetch(chunk + 1);
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float* a = patch + ((py + tap / 3) * PW + px + tap % 3) * P_LD;
-            const float* wt = wl + tap * CK * MAXCO;
+            const float* wt = wl + (chunk * 9 + tap) * CK * MAXCO;
 #pragma unroll
             for (int k4 = 0; k4 < CK / 4; ++k4) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(a + k4 * 4);
@@ -107,14 +127,24 @@ int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bi
     if ((pro_mean || pro_scale || pro_beta) && !(pro_mean && pro_scale && pro_beta)) return VF_ERR_BAD_ARG;
     const dim3 grid((unsigned)((long long)n_img * (H / TH) * (W / TW)));
     hipStream_t s = (hipStream_t)stream;
+    const size_t wsm = (size_t)(Cin / CK) * 9 * CK * MAXCO * sizeof(float);
+    if (wsm > 96 * 1024) return VF_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {                                        // static patch (49 KB) + dynamic weights exceed the default 64 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     if (!pro_mean)
-        hipLaunchKernelGGL((conv3_small_cout_kernel<false, false>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+        hipLaunchKernelGGL((conv3_small_cout_kernel<false, false>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
                            pro_beta, out, H, W, Cin, Cout);
     else if (pro_swish)
-        hipLaunchKernelGGL((conv3_small_cout_kernel<true, true>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+        hipLaunchKernelGGL((conv3_small_cout_kernel<true, true>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
                            pro_beta, out, H, W, Cin, Cout);
     else
-        hipLaunchKernelGGL((conv3_small_cout_kernel<true, false>), grid, dim3(256), 0, s, x, w_oihw, bias, pro_mean, pro_scale,
+        hipLaunchKernelGGL((conv3_small_cout_kernel<true, false>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
                            pro_beta, out, H, W, Cin, Cout);
     return vf_last_status();
 }
