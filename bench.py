@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0
 
 # HBM traffic of the dominant launch: NOT measured in this run (PMC counters need rocprofv3) — taken from the committed PMC pass of a
 # 56-image launch of the same kernel and shape (2 * FETCH_SIZE with the gfx950 unit correction + WRITE_SIZE) and scaled by pixels
-PMC_SOURCE = {'x3h': ('profiles/r1_conv_x3h_pmc.txt', 532920e3, 501760e3), 'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
+PMC_SOURCE = {'x3h': ('profiles/r2_new_kernels_pmc.txt', 466930e3, 458750e3),      # the round-2 kernel (tall tile, buffer loads) 'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
               'f32': ('profiles/r1_conv_halo_pmc.txt', 497520e3, 458750e3)}
 
 
