@@ -108,6 +108,32 @@ def convout(n_img=128, C=128, H=128):
     print(f'conv_out {C}->3 @{H}^2 x{n_img}: {ms * 1e3:.1f} us  {x.numel() * 4 / ms / 1e6:.0f} GB/s read')
 
 
+def x3h_stamps(n_img=56, C=128, H=128):
+    """stage-loop time vs chunk-barrier wait of the x3h 3x3 convolution (library built with -DVF_X3H_STAMPS), cycles per chunk per wave"""
+    import numpy as np
+    x = torch.randn(n_img * H * H, C, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.03
+    wp = ops.pack_conv3_x3h(w)
+    b = torch.randn(C, device=dev)
+    out = torch.empty_like(x)
+    g = torch.ones(C, device=dev)
+    m, s = ops.groupnorm_stats(x, g, n_img, H * H, C)
+    slots = ops.halo_gn_slots(H, H) if hasattr(ops, 'halo_gn_slots') else (H // 8) * (H // 16) * 2
+    nwg = n_img * (H // 8) * (H // 16) * (C // 128)
+    extra = (nwg * 8 + slots * 64 - 1) // (slots * 64)
+    part = torch.zeros(n_img + extra, slots, 32, 2, device=dev)
+    M = n_img * H * H
+    for _ in range(3):
+        ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=(m, s, torch.zeros(C, device=dev)), pro_swish=True,
+                  Hin=H, Win=H, Hout=H, Wout=H, x3h=True, gn_part=part)
+    torch.cuda.synchronize()
+    t = part.view(-1)[n_img * slots * 64:].view(torch.int32)[:nwg * 8].cpu().numpy().view(np.uint32).reshape(nwg, 4, 2).astype(np.float64)
+    nch = C // 32
+    print(f'x3h conv {C}->{C} @{H}^2 x{n_img}: {nwg} workgroups, {nch} chunks of 18 stages (216 MFMAs = 6912 pipe cycles per wave per chunk)')
+    print('  stage loop   per chunk: mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 0].mean() / nch, np.percentile(t[:, :, 0], 10) / nch, np.percentile(t[:, :, 0], 90) / nch))
+    print('  barrier wait per chunk: mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 1].mean() / nch, np.percentile(t[:, :, 1], 10) / nch, np.percentile(t[:, :, 1], 90) / nch))
+
+
 def gemm_tf(M=65536, only=None):
     """the four dense layers of one transformer block at the bench's size (128 scenes x 8 views x 64 tokens), bf16 arm with bf16
     activations: c_attn (fp32 or bf16 qkv out), attn.c_proj (+ residual), mlp.c_fc (GELU, bf16 out), mlp.c_proj (+ residual)"""
@@ -272,7 +298,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, convout=convout, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, x3h_stamps=x3h_stamps, convout=convout, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

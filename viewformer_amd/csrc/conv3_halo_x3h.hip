@@ -264,7 +264,15 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
     for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
     __syncthreads();
 
+#ifdef VF_X3H_STAMPS      // per-wave cycle sums (tools/microbench.py x3h_stamps): stage loop vs the wait at the chunk barrier
+    unsigned long long st_t[3];
+    unsigned st_acc[2] = {0, 0};
+#define X3H_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t[i]) :: "memory")
+#else
+#define X3H_STAMP(i)
+#endif
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        X3H_STAMP(0);
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
         // (vmcnt retires in issue order: stage BD's weight fragments go out BEFORE the patch loads, so that no fragment needed within the
         // next BD stages is queued behind HBM latency — see the stride-2 kernel, where this order is worth 20 %)
@@ -303,7 +311,13 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
             if ((s & 1) && (s >> 1) >= VF_X3H_STORE && (s >> 1) - VF_X3H_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X3H_STORE);
             if (VF_X3H_SB == 2) __builtin_amdgcn_sched_barrier(0);
         }
+        X3H_STAMP(1);
         __syncthreads();
+#ifdef VF_X3H_STAMPS
+        X3H_STAMP(2);
+        st_acc[0] += (unsigned)(st_t[1] - st_t[0]);
+        st_acc[1] += (unsigned)(st_t[2] - st_t[1]);
+#endif
     }
 
     // out = (acc + accx * 2^-11) / S with S the power-of-two weight scale stored behind the packed planes
@@ -315,6 +329,13 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
     vf_halo_epilogue_t<PAIR, MI, NJ>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+#ifdef VF_X3H_STAMPS      // behind the GroupNorm partials of the launch (the caller sizes gn_part for it)
+    if (p.gn_part && lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(p.gn_part + (size_t)n_img_total * p.gn_slots * 64) + ((size_t)blockIdx.x * 4 + wave) * 2;
+        o[0] = st_acc[0];
+        o[1] = st_acc[1];
+    }
+#endif
 }
 
 
