@@ -43,6 +43,10 @@ constexpr int GSTAGE = GA_BYTES + GB_BYTES;  // 65536
 #ifndef G256_AUX_W
 #define G256_AUX_W 0
 #endif
+#ifndef G256_PERSIST
+#define G256_PERSIST 0       // workgroups of the persistent form (256 = one per CU).  A/B at M = 65 536: c_attn 241 vs 247 us, c_fc 391 vs 381,
+                             // mlp.c_proj 312 vs 308 — a wash: the hidden first-stage flight is paid back by the lost overlap of tile tails -> off
+#endif
 #ifndef G256_BUFFER
 #define G256_BUFFER 1       // buffer_load_dwordx4 ... lds (SGPR resource + 32-bit lane offsets) instead of global_load_lds_dwordx4 (64-bit lane
                             // addresses): the address path is part of what a piece costs — mlp.c_proj 325 -> 304 us, c_attn 261 -> 244 us
@@ -319,6 +323,125 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     g256_store_f32(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
 }
 
+// ---- persistent form: one workgroup per CU walks the tiles (tile = blockIdx.x + k * gridDim.x, same XCD / panel order) and issues the
+// NEXT tile's first stage before its epilogue: the DMA's flight (~3500 cycles, a whole stage-time for which a fresh workgroup sits idle)
+// passes under the bias / GELU / store work of the tile that just finished.  Buffer-resource DMA only; needs an even stage count (the
+// last stage then reads buffer 1 and buffer 0 is free for the prefetch).
+template <bool O16>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nb = p.Cout / GN;
+    const int mt = (p.M + GM - 1) / GM;
+    constexpr int PANEL = G256_PANEL;
+    const int sn = PANEL <= 0 || nb <= PANEL ? nb : nb % PANEL == 0 ? PANEL : (PANEL >= 3 && nb % 3 == 0) ? 3 : (PANEL >= 2 && nb % 2 == 0) ? 2 : 1;
+    const int per_panel = mt * sn;
+    const int nstages = p.Cin / GK;
+    const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_packed), 0, 0x7fffffff, 0x00020000);
+
+    // tile id -> (row block, column tile): XCD-contiguous ids (vf_xcd_bid's map for an arbitrary id), then column panels
+    auto tile_of = [&](unsigned t, int& m_tile0, int& n_tile0) {
+        const unsigned n = (unsigned)ntiles, q = n >> 3, r = n & 7u, x = t & 7u, i = t >> 3;
+        const unsigned lbid = x * q + (x < r ? x : r) + i;
+        const int panel = (int)(lbid / (unsigned)per_panel);
+        const int in_panel = (int)(lbid - (unsigned)panel * per_panel);
+        n_tile0 = (panel * sn + in_panel % sn) * GN;
+        m_tile0 = (in_panel / sn) * GM;
+    };
+    unsigned avoff[4], wvoff = 0;
+    auto sources = [&](int m_tile0, int n_tile0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 32 + q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int m = m_tile0 + r;
+            m = m < p.M ? m : p.M - 1;
+            avoff[q] = (unsigned)(((size_t)m * p.lda) * 2 + c * 16);
+        }
+        wvoff = (unsigned)((size_t)(n_tile0 / GN) * GB_BYTES + wave * 4096 + lane * 16);
+    };
+    auto issue = [&](int s) {
+        unsigned char* dst = smem_b + (s & 1) * GSTAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bufds16(a_rsrc, dst + (wave * 32 + q * 8) * 128, avoff[q], (unsigned)(s * (GK * 2)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bufds16(w_rsrc, dst + GA_BYTES + wave * 4096 + q * 1024, wvoff + q * 1024, (unsigned)((size_t)s * w_stage_stride));
+    };
+    const unsigned a_row_off = (unsigned)((wave_m * 128 + l31) * 128);
+    const unsigned a_swz = (unsigned)((l31 >> 1) & 7);
+    unsigned a_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a_off[ks] = a_row_off + ((((unsigned)(ks * 2 + half)) ^ a_swz) << 4);
+    const unsigned b_off = (unsigned)(GA_BYTES + (wave_n >> 1) * (GK * 128 * 2) + ((half * 128) + (wave_n & 1) * 64 + l31) * 16);
+
+    int m_tile0, n_tile0;
+    tile_of(blockIdx.x, m_tile0, n_tile0);
+    sources(m_tile0, n_tile0);
+    issue(0);
+    for (unsigned t = blockIdx.x; t < (unsigned)ntiles; t += gridDim.x) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int s = 0; s < nstages; ++s) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < nstages) issue(s + 1);
+            const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
+            bf16x8 a[2][4], b[2][2];
+            auto frags = [&](int ks, bf16x8 (&af)[4], bf16x8 (&bf)[2]) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (ks * 2 * 128 + j * 32) * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
+            };
+            frags(0, a[0], b[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next tile's first stage goes out now (buffer 0: last read in stage nstages - 2, which every wave has left)
+        const int em = m_tile0, en = n_tile0;
+        const unsigned tn = t + gridDim.x;
+        if (tn < (unsigned)ntiles) {
+            tile_of(tn, m_tile0, n_tile0);
+            sources(m_tile0, n_tile0);
+            issue(0);
+        }
+        const bool full = em + GM <= p.M;
+        const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
+        if (O16) {
+            if (full) {
+                if (gelu) g256_store_bf16<true, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else g256_store_bf16<false, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+            } else {
+                if (gelu) g256_store_bf16<true, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else g256_store_bf16<false, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+            }
+        } else {
+            g256_store_f32(p, acc, em, en, wave_m, wave_n, half, l31, full, gelu);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 // Launcher used by vf_gemm_bf16 (gemm_bf16.hip).  Returns VF_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the
@@ -338,6 +461,21 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     }
     const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
     const dim3 g((unsigned)(mt * nb));
+    // persistent form (G256_PERSIST): 256 workgroups (one per CU; a multiple of the 8 XCDs) walk the tiles; VF_GEMM_G256P=0 keeps one tile per workgroup
+    const char* pe = getenv("VF_GEMM_G256P");
+    if (G256_PERSIST && G256_BUFFER && !(pe && pe[0] == '0') && (a.Cin / GK) % 2 == 0 && mt * nb > G256_PERSIST) {
+        static bool attr_p = false;
+        if (!attr_p) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+            if (e != hipSuccess) return (int)e;
+            attr_p = true;
+        }
+        const dim3 gp((unsigned)G256_PERSIST);
+        if (o16) hipLaunchKernelGGL((gemm_bf16_g256p_kernel<true>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);
+        else hipLaunchKernelGGL((gemm_bf16_g256p_kernel<false>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);
+        return vf_last_status();
+    }
     if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
     else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
     return vf_last_status();
