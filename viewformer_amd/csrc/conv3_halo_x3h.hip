@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
-    vf_halo_epilogue_t<false, MI, NJ>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
+    vf_halo_epilogue_t<false, MI, NJ, false>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);   // (no room for 64 preloaded values)
 }
 
 

@@ -70,10 +70,12 @@ __device__ __forceinline__ void vf_store_tile_ragged(const f32x16& acc, float bi
 // Same tile store as vf_store_tile<0, HAS_RES>, additionally accumulating the sum and the sum of squares of the values it
 // stores into s[sel(r)] / q[sel(r)] (sel(r) in {0, 1}: which of the two images of a pair tile row r belongs to; always 0
 // for ordinary tiles).
-template <bool HAS_RES, typename OffOut, typename OffRes, typename Sel>
+// The sums are carried in the accumulator type S of the caller: double (halo_common.h) makes a tile's partial sums independent of the
+// order in which a lane and the shuffle tree meet the values — a pair tile's left and right half group an image's pixels differently.
+template <bool HAS_RES, typename OffOut, typename OffRes, typename Sel, typename S>
 __device__ __forceinline__ void vf_store_tile_stats(const f32x16& acc, float bias, float* __restrict__ out,
                                                     const float* __restrict__ res, OffOut off_out, OffRes off_res, Sel sel,
-                                                    float (&s)[2], float (&q)[2]) {
+                                                    S (&s)[2], S (&q)[2]) {
     float v[16];
     if (HAS_RES) {
         float rr[16];
@@ -88,8 +90,34 @@ __device__ __forceinline__ void vf_store_tile_stats(const f32x16& acc, float bia
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k = sel(r);
-        s[k] += v[r];
-        q[k] += v[r] * v[r];
+        s[k] += (S)v[r];
+        q[k] += (S)v[r] * (S)v[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[off_out(r)] = v[r];
+}
+
+// The same two stores with the residual values already in registers (halo_common.h loads them for ALL tiles of the wave up front: the
+// per-tile form pays one memory round trip per tile, four in a row for the tall halo tile).
+template <typename OffOut>
+__device__ __forceinline__ void vf_store_tile_pre(const f32x16& acc, float bias, float* __restrict__ out, const float (&rr)[16], OffOut off_out) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias + rr[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[off_out(r)] = v[r];
+}
+template <typename OffOut, typename Sel, typename S>
+__device__ __forceinline__ void vf_store_tile_stats_pre(const f32x16& acc, float bias, float* __restrict__ out, const float (&rr)[16], OffOut off_out,
+                                                        Sel sel, S (&s)[2], S (&q)[2]) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias + rr[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = sel(r);
+        s[k] += (S)v[r];
+        q[k] += (S)v[r] * (S)v[r];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[off_out(r)] = v[r];
@@ -98,7 +126,8 @@ __device__ __forceinline__ void vf_store_tile_stats(const f32x16& acc, float bia
 // Reduce a lane's per-column (s, q) over the cg adjacent columns of a GroupNorm group (cg = C/32 in {4, 8, 16, 32},
 // columns = the 32 lanes of a half-wave) and over the two half-waves (the other 16 rows of the tile); the first lane of each
 // group then owns the group's partial of this wave's 64 x 32 sub-tile.  Fixed shuffle tree -> deterministic.
-__device__ __forceinline__ void vf_gn_group_reduce(float& s, float& q, int cg) {
+template <typename S>
+__device__ __forceinline__ void vf_gn_group_reduce(S& s, S& q, int cg) {
     s += __shfl_xor(s, 32, 64);
     q += __shfl_xor(q, 32, 64);
     for (int o = 1; o < cg; o <<= 1) {
