@@ -44,10 +44,10 @@ static inline int vf_halo_gn_check(const vf_igemm_args& a) {
 // channels [wave_n * 32 NJ + 32 j, +32).  (MI, NJ) = (2, 2): the 2 x 2 wave grid of the original kernels (wave_m in {0, 1} = rows
 // 0-3 / 4-7); (4, 1): the "tall" form, every wave covers all 8 rows and 32 channels (wave_m = 0, wave_n = wave).  The fused GroupNorm
 // partial statistics keep their layout either way: slot tile_slot + (row >> 2) holds the sums over rows 4 (row >> 2) .. +3.
-// PAIR: the tile is two 8x8 images (img, img1) side by side.  (A lane then sums a different subset of an image's pixels in the left and
-// in the right half, so an image's partial sums — exact to fp32 rounding either way — can differ in the last bit with its position in the
-// batch; tests/test_hip_models.py::test_vqgan_batch_and_chunk_invariance holds on its data, an epilogue variant that only changed the
-// compiler's fma contraction of the sum of squares did not: tools/debug_invariance.py.)
+// PAIR: the tile is two 8x8 images (img, img1) side by side.  A lane then sums a different subset of an image's pixels in the left and in
+// the right half; with fp32 sums that made an image's GroupNorm statistics depend, in the last bit, on its position in the batch (the batch
+// invariance test held on its data until an unrelated epilogue change altered the compiler's fma contraction — tools/debug_invariance.py
+// found the layer).  The partial sums are therefore carried in fp64 (vf_gn_acc_t) and rounded once.
 template <bool PAIR, int MI, int NJ, bool PRELOAD = (VF_HALO_RES_PRELOAD != 0)>
 __device__ __forceinline__ void vf_halo_epilogue_t(const vf_igemm_args& p, const f32x16 (&acc)[MI][NJ], int img, int img1, int y0,
                                                    int x0, int tile_slot, int nblk, int wave_m, int wave_n, int half, int l31) {
