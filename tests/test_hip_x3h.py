@@ -63,10 +63,17 @@ def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
     return _err(o3, ref, mag), _err(o32, ref, mag)
 
 
+def test_conv3_s2_x3h_pair_form_odd_image_count(dev):
+    """16x16 -> 8x8 Downsample: two images per tile; an odd image count processes the last image twice (same values rewritten)"""
+    (mx3, rms3), (mx32, rms32) = _run(dev, 's2', 128, 128, 16, False, n=3)
+    assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9, (mx3, rms3, rms32)
+
+
 @pytest.mark.parametrize('mode,cin,cout,H,pro', [('s1', 128, 128, 16, True), ('s1', 64, 256, 32, False), ('up', 128, 128, 8, False),
                                                   ('up', 32, 128, 16, True), ('s1', 128, 128, 64, True),
                                                   ('s1', 128, 128, 8, True), ('s1', 512, 512, 8, False), ('s1', 256, 256, 16, True),
-                                                  ('s2', 128, 128, 32, False), ('s2', 64, 256, 64, False), ('s2', 32, 128, 32, False)])
+                                                  ('s2', 128, 128, 32, False), ('s2', 64, 256, 64, False), ('s2', 32, 128, 32, False),
+                                                      ('s2', 256, 256, 16, False), ('s2', 64, 128, 16, False)])
 def test_conv3_halo_x3h_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
     (mx3, rms3), (mx32, rms32) = _run(dev, mode, cin, cout, H, pro)
     print(f'{mode} {cin}->{cout} @{H} pro={pro}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
@@ -109,7 +116,8 @@ def test_x3h_fused_groupnorm_partials(dev):
 
 def test_x3h_refuses_unsupported_shapes(dev):
     from viewformer_amd import ops
-    assert not ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 8, 8)       # 16x16 -> 8x8 stays on the generic kernel
+    assert ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 8, 8)           # 16x16 -> 8x8: the pair form (two images per tile)
+    assert not ops.conv3_x3h_supported(ops.MODE_CONV3_S2PAD, 128, 128, 4, 4)       # smaller maps stay on the generic kernel
     x = torch.zeros((2 * 16 * 12, 64), device=dev)
     out = torch.empty((2 * 16 * 12, 128), device=dev)
     with pytest.raises(ops._lib.VfError):        # W % 16 != 0: refused, never rerouted

@@ -350,8 +350,14 @@ constexpr int S2_LDB = 80;                                   // 2 planes x 32 B 
 constexpr int S2_SLOTS = (S2_NPIX * 4 + 255) / 256;          // float4 staging slots per thread (9)
 constexpr int S2_BUF = (S2_NPIX + 1) * S2_LDB;
 
+// P8: the 16x16 -> 8x8 Downsample (the encoder's last): the 8x16 output tile is TWO images side by side (img, img1), each with its own
+// 17x17 input patch; a patch row is [even cols of A (9) | even cols of B (9) | odd cols of A (8) | odd cols of B (8)] = 34 pixels.
+template <bool P8>
 __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [S2_BUF]
+    constexpr int PW = P8 ? 34 : S2_PW;
+    constexpr int NPIX = S2_PH * PW;
+    constexpr int SLOTS = (NPIX * 4 + 255) / 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,40 +370,47 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nb = p.Cout / BN;
-    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    const int tilesX = P8 ? 1 : p.Wout / TW, tilesY = P8 ? 1 : p.Hout / TH;
     int bid = (int)vf_xcd_bid();                        // XCD-contiguous logical workgroup id (vf_common.h)
     const int nblk = bid % nb; bid /= nb;
     const int tx = bid % tilesX; bid /= tilesX;
     const int ty = bid % tilesY;
-    const int img = bid / tilesY;
+    const int img = P8 ? (bid / tilesY) * 2 : bid / tilesY;
+    const int n_img_total = p.M / (p.Hout * p.Wout);
+    const int img1 = P8 ? min(img + 1, n_img_total - 1) : img;    // (odd image count: the last image twice, same values rewritten)
+    const int pair_pix = (img1 - img) * p.Hin * p.Win;
     const int y0 = ty * TH, x0 = tx * TW;
     const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
     const int nchunks = p.Cin / 16;
 
     // staging slots: thread -> (patch pixel, float4 column of the 16-channel chunk)
     const int c4 = tid & 3;
-    int s_off[S2_SLOTS], s_lds[S2_SLOTS];
-    bool s_ok[S2_SLOTS];
+    int s_off[SLOTS], s_lds[SLOTS];
+    bool s_ok[SLOTS];
 #pragma unroll
-    for (int q = 0; q < S2_SLOTS; ++q) {
+    for (int q = 0; q < SLOTS; ++q) {
         const int pix = (tid >> 2) + 64 * q;
-        const int pixc = pix < S2_NPIX ? pix : 0;
-        const int pr = pixc / S2_PW, pc = pixc - pr * S2_PW;
+        const int pixc = pix < NPIX ? pix : 0;
+        const int pr = pixc / PW, pc0 = pixc - pr * PW;
+        const int sel = P8 ? (pc0 >= 17) : 0;           // which image of the pair
+        const int pc = pc0 - 17 * sel;
         const int sy = 2 * y0 + pr, sx = 2 * x0 + pc;
-        const bool ok = pix < S2_NPIX && sy < p.Hin && sx < p.Win;            // right / bottom zero padding
+        const bool ok = pix < NPIX && sy < p.Hin && sx < p.Win;               // right / bottom zero padding
         s_ok[q] = ok;
-        s_off[q] = ok ? (sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
-        const int slot = pix < S2_NPIX ? pr * S2_PW + (pc & 1) * (TW + 1) + (pc >> 1) : S2_NPIX;   // parity-major row
-        s_lds[q] = slot * S2_LDB + c4 * 8;
+        s_off[q] = ok ? (sel * pair_pix + sy * p.Win + sx) * p.Cin + c4 * 4 : c4 * 4;
+        int slot;
+        if (P8) slot = pr * PW + ((pc & 1) ? 18 + sel * 8 + (pc >> 1) : sel * 9 + (pc >> 1));
+        else slot = pr * PW + (pc & 1) * (TW + 1) + (pc >> 1);                // parity-major row
+        s_lds[q] = (pix < NPIX ? slot : NPIX) * S2_LDB + c4 * 8;
     }
-    f32x4 preg[S2_SLOTS];
+    f32x4 preg[SLOTS];
     auto patch_load = [&](int chunk) {
 #pragma unroll
-        for (int q = 0; q < S2_SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + chunk * 16 + s_off[q]);
+        for (int q = 0; q < SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + chunk * 16 + s_off[q]);
     };
     auto patch_park = [&]() {
 #pragma unroll
-        for (int q = 0; q < S2_SLOTS; ++q) {
+        for (int q = 0; q < SLOTS; ++q) {
             f16x4 oh, ol;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -411,10 +424,21 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
         }
     };
 
+    // fragment bases: even input columns (taps dx = 0, 2) and odd ones (dx = 1) — in the pair form the two sections of a patch row
+    // are offset by the image, so they get separate bases; otherwise the odd section simply starts TW + 1 pixels later
     const int trow = vf_perm_row(l31), tpx = vf_perm_px(l31);
-    int a_base[MI];
+    int a_base[MI], a_base_o[MI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a_base[mi] = (2 * (wave_m * 4 + mi * 2 + trow) * S2_PW + tpx) * S2_LDB + half * 16;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row2 = 2 * (wave_m * 4 + mi * 2 + trow) * PW;
+        if (P8) {
+            a_base[mi] = (row2 + (tpx >> 3) * 9 + (tpx & 7)) * S2_LDB + half * 16;
+            a_base_o[mi] = (row2 + 18 + (tpx >> 3) * 8 + (tpx & 7)) * S2_LDB + half * 16;
+        } else {
+            a_base[mi] = (row2 + tpx) * S2_LDB + half * 16;
+            a_base_o[mi] = a_base[mi] + (TW + 1) * S2_LDB;
+        }
+    }
 
     const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
     const size_t tap_stride = (size_t)nb * TAP_BYTES;
@@ -445,11 +469,11 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     };
     auto a_load = [&](f16x8 (&dst)[MI][2], int tap) {
         const int dy = tap / 3, dx = tap % 3;
-        const int off = (dy * S2_PW + (dx & 1) * (TW + 1) + (dx >> 1)) * S2_LDB;
+        const int off = (dy * PW + (dx >> 1)) * S2_LDB;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(smem_h + a_base[mi] + off + pl * 32);
+            for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(smem_h + ((dx & 1) ? a_base_o[mi] : a_base[mi]) + off + pl * 32);
     };
 
     f32x16 acc[MI][NJ], accx[MI][NJ];
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
-    vf_halo_epilogue_t<false, MI, NJ, false>(p, acc, img, img, y0, x0, (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);   // (no room for 64 preloaded values)
+    vf_halo_epilogue_t<P8, MI, NJ, false>(p, acc, img, img1, y0, x0, P8 ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);   // (no room for 64 preloaded values)
 }
 
 
@@ -591,13 +615,19 @@ int vf_conv3_halo_x3h(const vf_igemm_args* args, void* stream) {
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
     if (a.mode == VF_MODE_CONV3_S2PAD) {
-        if (a.Cout % BN != 0 || a.Cin % CK != 0 || a.Hout % TH != 0 || a.Wout % TW != 0 || a.pro_mean) return VF_ERR_UNSUPPORTED;
+        const bool p8 = a.Hout == 8 && a.Wout == 8;                      // two images per tile
+        if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!p8 && (a.Hout % TH != 0 || a.Wout % TW != 0)) || a.pro_mean) return VF_ERR_UNSUPPORTED;
         if (a.Hin != a.Hout * 2 || a.Win != a.Wout * 2 || a.M % (a.Hout * a.Wout) != 0) return VF_ERR_BAD_ARG;
         if (a.batch > 1 || a.epilogue != VF_EPI_NONE || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
         if ((long long)a.Hin * a.Win * a.Cin >= (1ll << 31)) return VF_ERR_UNSUPPORTED;
         if (int st = vf_halo_gn_check(a)) return st;
+        if (p8) {
+            const long long blocks = (long long)((a.M / 64 + 1) / 2) * (a.Cout / BN);
+            hipLaunchKernelGGL(conv3_s2_x3h_kernel<true>, dim3((unsigned)blocks), dim3(256), (size_t)(S2_PH * 34 + 1) * S2_LDB, (hipStream_t)stream, a);
+            return vf_last_status();
+        }
         const long long blocks = (long long)(a.M / (a.Hout * a.Wout)) * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
-        hipLaunchKernelGGL(conv3_s2_x3h_kernel, dim3((unsigned)blocks), dim3(256), (size_t)S2_BUF, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv3_s2_x3h_kernel<false>, dim3((unsigned)blocks), dim3(256), (size_t)S2_BUF, (hipStream_t)stream, a);
         return vf_last_status();
     }
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;

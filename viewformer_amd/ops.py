@@ -130,7 +130,9 @@ def pack_conv3_x3h(w_oihw):
 
 
 def conv3_x3h_supported(mode, Cin, Cout, Hout, Wout):
-    """shape rules of vf_conv3_halo_x3h (the same as the x6 kernel's)"""
+    """shape rules of vf_conv3_halo_x3h: the x6 kernel's, plus the 16x16 -> 8x8 stride-2 convolution (two images per tile)"""
+    if mode == MODE_CONV3_S2PAD and Hout == 8 and Wout == 8 and Cin % 32 == 0 and Cout % 128 == 0:
+        return True
     return conv3_x6_supported(mode, Cin, Cout, Hout, Wout)
 
 
