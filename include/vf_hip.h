@@ -17,8 +17,12 @@
  *     never throws across the ABI; thread-safe for distinct streams
  *   - activations are channels-last fp32 ("NHWC": [image][y][x][channel]); token rows are
  *     [row][feature] fp32; codes are int64 like the reference's Torch path
- *   - arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), so the
- *     only difference from the fp32 reference is summation order
+ *   - arithmetic: every entry point names its own.  The fp32-EQUIVALENT families are the
+ *     native f32 MFMA (*_f32: v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), x6 (*_x6:
+ *     three exact bf16 pieces, six products) and x3h (*_x3h: two exact fp16 pieces, three
+ *     products — the default of the inference encoder); they differ from the fp32
+ *     reference by summation order only.  *_bf16 / *_fp8 entry points round
+ *     their operands once and are the tolerance arms.
  */
 #ifndef VF_HIP_H
 #define VF_HIP_H
@@ -37,6 +41,10 @@ extern "C" {
 /* library / device introspection (host) */
 int vf_abi_version(void);                 /* bumps when a signature changes */
 const char* vf_build_arch(void);          /* "gfx950" */
+/* developer switches compiled into this library (ablation / cycle-stamp builds of the kernels, csrc/vf_common.h): the count and
+ * the i-th macro name.  A product build returns 0; tests/test_abi.py asserts it of the shipped library. */
+int vf_build_flags(void);
+const char* vf_build_flag_name(int i);
 
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM family: conv3x3 (stride 1 / stride-2 with (0,1,0,1) pad / nearest-x2

@@ -43,6 +43,23 @@ def test_host_queries(lib):
     assert lib.vf_groupnorm_workspace_bytes(4, 16384, 128) == 4 * 64 * 256 * 2 * 4
 
 
+def test_shipped_library_has_no_developer_switch_compiled_in(lib):
+    """The kernel sources keep ablation / cycle-stamp switches (-DADMA_X_NOCOMPUTE, -DATT_X_NOMFMA, -DG256_STAMPS, ...) for the
+    experiments under tools/; a translation unit built with one registers its name (csrc/vf_common.h).  The product library must
+    register none — and the registry itself must work (the variant builds under tools/ rely on it to label their output)."""
+    names = [lib.vf_build_flag_name(i) for i in range(lib.vf_build_flags())]
+    assert lib.vf_build_flags() == 0, f'libvf_hip.so was built with developer switches: {names}'
+    assert lib.vf_build_flag_name(0) is None
+    # every switch the sources test for is one the registry knows (a new ablation macro must be added to vf_common.h's list)
+    csrc = os.path.join(REPO, 'viewformer_amd', 'csrc')
+    known = set(re.findall(r'VF_REG_FLAG\((\w+)\)', open(os.path.join(csrc, 'vf_common.h')).read()))
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.h')):
+            used |= set(re.findall(r'#\s*if(?:def|ndef)?\s+(?:!\s*)?(?:defined\s*\(\s*)?(\w+_X_\w+|\w+_STAMPS|\w+_CLOCKPROBE|\w+_VIA_REGS)', open(os.path.join(csrc, f)).read()))
+    assert used <= known, used - known
+
+
 def test_argument_validation_without_gpu(lib):
     from viewformer_amd._lib import VfIgemmArgs
     P = ctypes.c_void_p

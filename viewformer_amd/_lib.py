@@ -32,6 +32,8 @@ P = c_void_p
 EXPORTS = {
     'vf_abi_version': (c_int, []),
     'vf_build_arch': (c_char_p, []),
+    'vf_build_flags': (c_int, []),
+    'vf_build_flag_name': (c_char_p, [c_int]),
     'vf_igemm_packed_floats': (c_size_t, [c_int, c_int, c_int]),
     'vf_igemm_pack_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int64, P]),
     'vf_igemm_f32': (c_int, [POINTER(VfIgemmArgs), P]),

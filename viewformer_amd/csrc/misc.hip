@@ -2,6 +2,7 @@
 // argmax / softmax, uint8 pre/post-processing and the 3-channel conv_in.  One wave per row where a
 // row reduction is needed (64-lane shuffle reductions), float4 accesses, grid-stride loops.
 #include "vf_common.h"
+#include <string.h>
 #include "../../include/vf_hip.h"
 
 namespace {
@@ -269,7 +270,25 @@ __global__ void resize_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __res
 
 }  // namespace
 
+// registry behind vf_build_flags(): filled by the static initialisers of translation units built with a developer switch (vf_common.h)
+namespace {
+constexpr int VF_MAX_FLAGS = 32;
+const char* g_flag_names[VF_MAX_FLAGS];
+int g_flag_count = 0;
+}
+
 extern "C" {
+
+int vf_register_build_flag(const char* name) {
+    for (int i = 0; i < g_flag_count; ++i)
+        if (strcmp(g_flag_names[i], name) == 0) return i;
+    if (g_flag_count < VF_MAX_FLAGS) g_flag_names[g_flag_count++] = name;
+    return g_flag_count - 1;
+}
+
+int vf_build_flags(void) { return g_flag_count; }
+
+const char* vf_build_flag_name(int i) { return (i >= 0 && i < g_flag_count) ? g_flag_names[i] : nullptr; }
 
 int vf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int d, float eps,
                      void* stream) {

@@ -122,6 +122,55 @@ __device__ __forceinline__ float vf_vq_sq4(const f32x4 v) {
     return __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
 }
 
+// ---- build-flag registry (vf_build_flags / vf_build_flag_name, include/vf_hip.h) -------------------------------------------------
+// Developer switches that change RESULTS (ablations: a phase of a kernel compiled out) or make a kernel write debug data (cycle
+// stamps) live in the product sources behind -D macros.  Every translation unit built with one of them registers its name at load
+// time; a product build registers nothing, vf_build_flags() returns 0, and tests/test_abi.py asserts that of the shipped .so.
+extern "C" int vf_register_build_flag(const char* name);
+#define VF_REG_FLAG(m) namespace { const int vf_flagreg_##m = vf_register_build_flag(#m); }
+#ifdef ADMA_X_NOCOMPUTE
+VF_REG_FLAG(ADMA_X_NOCOMPUTE)
+#endif
+#ifdef ADMA_X_NODMA
+VF_REG_FLAG(ADMA_X_NODMA)
+#endif
+#ifdef ADMA_X_NOSM
+VF_REG_FLAG(ADMA_X_NOSM)
+#endif
+#ifdef ATT_X_NOMFMA
+VF_REG_FLAG(ATT_X_NOMFMA)
+#endif
+#ifdef ATT_X_NOSTAGE
+VF_REG_FLAG(ATT_X_NOSTAGE)
+#endif
+#ifdef ATT_X_NOSOFTMAX
+VF_REG_FLAG(ATT_X_NOSOFTMAX)
+#endif
+#ifdef ATT_X_NOGLOBAL
+VF_REG_FLAG(ATT_X_NOGLOBAL)
+#endif
+#ifdef G256_A_VIA_REGS
+VF_REG_FLAG(G256_A_VIA_REGS)
+#endif
+#ifdef G256_STAMPS
+VF_REG_FLAG(G256_STAMPS)
+#endif
+#ifdef VQF_STAMPS
+VF_REG_FLAG(VQF_STAMPS)
+#endif
+#ifdef VQF_X_NORERANK
+VF_REG_FLAG(VQF_X_NORERANK)
+#endif
+#ifdef VF_X3H_STAMPS
+VF_REG_FLAG(VF_X3H_STAMPS)
+#endif
+#ifdef VF_X3H_X_NOPATCH
+VF_REG_FLAG(VF_X3H_X_NOPATCH)
+#endif
+#ifdef VF_X6_CLOCKPROBE
+VF_REG_FLAG(VF_X6_CLOCKPROBE)
+#endif
+
 // shared host helper (defined in igemm_f32.hip): pack [taps][K][N] into the fragment-major B layout
 int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long long sk, long long sn, long long st,
                    int BN, int batch, long long src_bstride, hipStream_t stream);
