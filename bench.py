@@ -201,19 +201,25 @@ def cpu_baseline(models_cfg, S, n_scenes, seed=123):
     vcfg, vsd, mcfg, msd = models_cfg
     # torch's CPU conv/matmul stop scaling (and regress badly) past a few dozen threads at these sizes:
     # a 256-thread run of this sample took 14 s/scene on the GPU box's host, so cap the pool.
-    cores = min(os.cpu_count() or 1, 32)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 32)
     torch.set_num_threads(cores)
     frames, cams = synthetic_scene_batch(max(n_scenes, 1), S, 128, seed=seed)
     t0 = time.time()
     po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames[:1], cams[:1])      # warm (also sizes the sample)
     warm = time.time() - t0
     n = max(1, min(n_scenes, int(20.0 / max(warm, 1e-3))))                         # bound the sample to ~20 s
+    stages = {}
     t0 = time.time()
-    po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames[:n], cams[:n])
+    po.generate_batch_predictions(msd, mcfg, vsd, vcfg, frames[:n], cams[:n], timings=stages)
     dt = time.time() - t0
-    return dict(value=round(n / dt, 4), unit='novel views/s', cores=cores, kind='port',
+    return dict(value=round(n / dt, 4), unit='novel views/s', cores=cores, host_cores=host_cores, kind='port',
+                stage_ms_per_view={k: round(v / n * 1e3, 1) for k, v in stages.items()},
+                stage_note=f'encode = {S} frames per view (target included), transformer = generation + localization passes, '
+                           'decode = 1 frame per view',
                 sample=f'{n} scenes x {S} views (same synthetic workload), fp32 torch-CPU restatement of the '
-                       f'reference path (oracle/), {cores} threads, {dt:.1f} s')
+                       f'reference path (oracle/), {cores} of the host\'s {host_cores} logical cores as torch threads '
+                       f'(the full pool measured 14x slower: torch CPU conv / matmul regress past a few dozen threads), {dt:.1f} s')
 
 
 def timed(step, steps, warmup, dev):
@@ -353,6 +359,9 @@ def main():
     ap.add_argument('--encoder-chunk', type=int, default=1024, help='images per encoder / decoder launch chunk (VQGAN max_images_per_call)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     ap.add_argument('--dropout', type=float, default=0.0, help='train: dropout rate (the reference default is 0.1)')
+    ap.add_argument('--batch-sweep', default=None,
+                    help='views workload: comma-separated scenes-per-step list (SURVEY 8d: 1,8,64,256,1024); prints ONE JSON line with the '
+                         'views/s of every batch size (same models, inputs resident in HBM, --steps timed steps each)')
     args = ap.parse_args()
     args.batch_set, args.views_set = args.batch is not None, args.views is not None
 
@@ -377,6 +386,35 @@ def main():
 
     vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith, not args.fp32_activations, args.encoder_chunk,
                                       attention=args.attention)
+    if args.batch_sweep:
+        sweep = []
+        for b in [int(x) for x in args.batch_sweep.split(',')]:
+            fr, cm = synthetic_scene_batch(b, S, 128, seed=rank)
+            fr_d, cm_d = torch.from_numpy(fr).to(dev), torch.from_numpy(cm).to(dev)
+
+            def step_b():
+                return generate_batch_predictions(tr, vq, fr_d, cm_d)
+            step_b()
+            torch.cuda.synchronize()
+            dt_b, _ = timed(step_b, args.steps, args.warmup, dev)
+            n_b = sharding.sum_over_ranks(b * args.steps, dev)
+            sweep.append({'scenes_per_gpu_per_step': b, 'images_encoded_per_step': b * S, 'value': round(n_b / dt_b, 2),
+                          'ms_per_step': round(dt_b / args.steps * 1e3, 3)})
+            del fr_d, cm_d
+            torch.cuda.empty_cache()
+        if rank == 0:
+            from viewformer_amd.evaluate import MAX_SCENES_PER_CALL
+            print(json.dumps({'metric': 'novel views/sec (encode->AR transformer->decode), 128px 6-ctx', 'unit': 'novel views/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak',
+                              'dtype': 'bf16' if args.precision == 'mixed' else 'f32', 'data': 'synthetic',
+                              'config': {'workload': 'batch sweep of BASELINE.json configs[1] (SURVEY 8d)', 'views_per_scene': S,
+                                         'localization_pass': localization, 'max_scenes_per_transformer_call': MAX_SCENES_PER_CALL,
+                                         'max_images_per_encoder_call': args.encoder_chunk},
+                              'batch_sweep': sweep}), flush=True)
+        sharding.barrier()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     frames, cams = synthetic_scene_batch(B, S, 128, seed=rank)             # this rank's shard of the global batch
     frames_d = torch.from_numpy(frames).to(dev)
     cams_d = torch.from_numpy(cams).to(dev)
@@ -416,7 +454,8 @@ def main():
                    'fp32_conv_arithmetic': {
                        'x3h': 'x3h: every fp32 product = 3 exact fp16 partial products (operands split h + l*2^-11 with l carried at '
                               '2^11, cross terms in their own fp32 accumulator, power-of-two pre-scaled weights) on the fp16 MFMA '
-                              'pipe; error vs fp64 <= native f32 MFMA (tests/test_hip_x3h.py); stride-2 and 1x1 convs: x6',
+                              'pipe; error vs fp64 <= native f32 MFMA (tests/test_hip_x3h.py); stride-1, stride-2, upsample and 1x1 convolutions and the '
+                              'AttnBlock core all run it (quant_conv too); x6 only for shapes it does not tile',
                        'x6': 'x6: every fp32 product = 6 exact bf16 partial products (operands split h+m+l) accumulated in fp32 on '
                              'the bf16 MFMA pipe; error vs fp64 <= native f32 MFMA (tests/test_hip_x6.py)',
                        'f32': 'native f32 MFMA'}[args.conv_arith],
@@ -427,19 +466,26 @@ def main():
                                                 'pass executes 8/14 of the transformer part, so this is equivalent work, not executed FLOPs'},
     }
     # ---- host round trip (the reference moves frames to the device and images back every batch, evaluate_transformer.py:18-19,222)
+    from viewformer_amd.evaluate import stream_batch_predictions
     fr_h = torch.from_numpy(frames).pin_memory()
     cm_h = torch.from_numpy(cams).pin_memory()
+    n_io = max(args.steps, 4)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for o in stream_batch_predictions(tr, vq, ((fr_h, cm_h) for _ in range(n_io))):
+        img_h = o['generated_images']                  # host tensors (pinned ring)
+    host_dt = (time.perf_counter() - t0) / n_io
     t0 = time.perf_counter()
     for _ in range(2):
         o = generate_batch_predictions(tr, vq, fr_h.to(dev, non_blocking=True), cm_h.to(dev, non_blocking=True))
-        img_h = o['generated_images'].cpu()
-        cam_h = o['generated_cameras'].cpu()
-    host_dt = (time.perf_counter() - t0) / 2
-    line['host_io'] = {'value': round(B / host_dt, 2), 'unit': 'novel views/s',
-                       'note': f'same step incl. host->device copy of {fr_h.numel() >> 20} MiB of frames and device->host copy of the {img_h.numel() >> 20} MiB '
-                               'of generated images per step (PCIe), 2 steps; never the headline value'}
-    del cam_h
+        img_s, cam_s = o['generated_images'].cpu(), o['generated_cameras'].cpu()
+    serial_dt = (time.perf_counter() - t0) / 2
+    line['host_io'] = {'value': round(B / host_dt, 2), 'unit': 'novel views/s', 'steps': n_io,
+                       'serial_value': round(B / serial_dt, 2),
+                       'note': f'the evaluator\'s outer loop with host tensors in and out (evaluate.stream_batch_predictions): {fr_h.numel() >> 20} MiB of frames up '
+                               f'and {img_h.numel() >> 20} MiB of generated images down per step on a second HIP stream, overlapped with the neighbouring '
+                               'steps\' kernels; serial_value = the same copies issued in line with the step (the reference\'s loop); never the headline value'}
+    del img_s, cam_s
     # ---- roofline section (rank 0): HIP events on the launch stream around every GEMM-family launch, the lookup and the attention
     # two instrumented passes, the one with the smaller total kept: the first launches after the timed loop occasionally run
     # at a lower clock (seen once: 5.5 ms instead of 3.7 ms for the dominant launch while the rocprofv3 trace said 3.75 ms)

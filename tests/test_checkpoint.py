@@ -101,6 +101,11 @@ def test_load_model_reads_config_overrides_and_refuses_missing_dirs(tmp_path):
     m = ck.load_model(str(d / 'model'), pose_multiplier=0.2)                 # evaluate_transformer.py:205-208
     assert m.config.pose_multiplier == 0.2 and m.config.n_layer == 1
     assert np.array_equal(np.asarray(m.state_dict()['wte.weight']), np.asarray(make_migt_weights(cfg, seed=1)['wte.weight']))
+    with pytest.raises(TypeError, match='pose_multipler'):                   # a mistyped override must not be dropped silently
+        ck.load_model(str(d / 'model'), pose_multipler=0.2)
+    cj2 = dict(cj, some_future_field=3)                                       # ... while unknown keys INSIDE config.json are ignored
+    json.dump(cj2, open(d / 'config.json', 'w'))                              # (models/__init__.py:63-74 walks the dataclass fields only)
+    assert ck.load_model(str(d / 'model')).config.n_layer == 1
     with pytest.raises(FileNotFoundError):
         ck.load_model('interiornet-transformer-tf')                          # named checkpoints need the network
     # a checkpoint with a missing tensor is refused by load_state_dict

@@ -127,3 +127,20 @@ def test_filtered_lookup_escape_paths(dev):
     assert not ops.vq_filter_supported(128, 1024) and not ops.vq_filter_supported(256, 2048) and not ops.vq_filter_supported(256, 1000)
     with pytest.raises(_lib.VfError):
         ops.vq_filter_pack(torch.zeros((128, 1024), device=dev))
+
+
+@pytest.mark.parametrize('kind', ['beyond_fp16', 'inf_entry'])
+def test_codebook_outside_fp16_range_takes_the_exact_scan(dev, kind):
+    """the fp16 tiles cannot carry a code entry >= 65504 (or a non-finite one); the pack step then leaves e_max = inf,
+    no row is certified and every row is scanned exactly — the same indices as vq_argmin instead of silently diverging."""
+    g = np.random.Generator(np.random.PCG64(5))
+    E = _codebook(seed=3)
+    if kind == 'beyond_fp16':
+        E[7, 100] = 1.0e5
+        E[9, 101] = -7.0e4
+    else:
+        E[3, 55] = float('inf')
+    z = torch.from_numpy(g.standard_normal((640, 256)).astype(np.float32))
+    exact, filt, st = _both(z, E, dev)
+    assert torch.equal(exact, filt)
+    assert st[3] == 640 and st[0] == 0 and st[1] == 0      # stats[3] = rows scanned exactly over the whole codebook

@@ -27,7 +27,7 @@ from typing import Dict
 import numpy as np
 
 from . import codes_dataset as _wire
-from .config import MIGTConfig, VQGANConfig, load_config
+from .config import MIGTConfig, VQGANConfig, config_field_names, load_config
 
 _TABLE_MAGIC = 0xdb4775248b80fb57
 _HEADER_KEY = b''
@@ -312,6 +312,11 @@ def load_model(checkpoint: str, device=None, **config_overrides):
         raise FileNotFoundError(f'{cfg_file} not found (downloading named checkpoints is not available offline)')
     with open(cfg_file) as f:
         cfg = json.load(f)
+    # unknown keys INSIDE config.json are ignored like the reference's _build_dataclass does; an unknown key the CALLER passes is a
+    # typo that would silently evaluate with the stored value (pose_multipler=...), so it raises
+    unknown = set(config_overrides) - config_field_names(cfg.get('model')) - {'model'}
+    if unknown:
+        raise TypeError(f'load_model: unknown config override(s) {sorted(unknown)} for model {cfg.get("model")!r}')
     cfg.update(config_overrides)
     config = load_config(cfg)
     is_th = ckpt.endswith('.pth') or ckpt.endswith('.ckpt')

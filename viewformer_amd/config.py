@@ -84,6 +84,13 @@ class MIGTConfig:
 _CONFIGS = {'vqgan': VQGANConfig, 'migt': MIGTConfig}
 
 
+def config_field_names(model_name: str):
+    """Field names of the config class a ``config.json`` with ``model == model_name`` builds."""
+    if model_name not in _CONFIGS:
+        raise ValueError(f'Model {model_name} is not supported')
+    return {f.name for f in fields(_CONFIGS[model_name])}
+
+
 def load_config(config: dict):
     """Build a config object from a ``config.json`` dict (reference:
     viewformer/models/__init__.py:62-78).  Unknown model names raise ``ValueError``; keys that are not fields of the

@@ -391,12 +391,12 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
     int st = vf_last_status();
     if (st) return st;
     const size_t smem = (size_t)(2 * TT * LD + 2 * DH * LD + 2 * TT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), smem, s, q, k, v, dout, lse, D, dk, dv, T, L, ldq, ldk, ldv, lddo,
                        lddk, lddv, scale, twin_view, thresh, dscale, drop_seed, drop_site);

@@ -307,11 +307,11 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     if (L != KT || T % KT != 0 || ((ldq | ldk | ldv | ldo) & 7)) return VF_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return VF_ERR_UNSUPPORTED;
     if ((size_t)T * (size_t)(ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv)) * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit offsets per (scene, head)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_dma_kernel, grid, dim3(256), (size_t)RING * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),

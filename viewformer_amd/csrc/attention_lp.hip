@@ -394,9 +394,10 @@ extern "C" {
 
 int vf_attn_blockcausal_bf16_v2(const void* q, const void* k, const void* v, int in_bf16, void* out, int out_bf16, int B, int H, int T, int L,
                                 int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view, void* stream) {
-    if (in_bf16 && out_bf16 && q && k && v && out && B > 0 && H > 0 && T > 0 && scale > 0.f && ldq >= H * DH && ldk >= H * DH && ldv >= H * DH &&
+    if (skip_masked && in_bf16 && out_bf16 && q && k && v && out && B > 0 && H > 0 && T > 0 && scale > 0.f && ldq >= H * DH && ldk >= H * DH && ldv >= H * DH &&
         ldo >= H * DH) {
-        // (masked tiles carry weights of exactly 0.0f, so the DMA kernel's unconditional skipping equals skip_masked = 0 bit for bit)
+        // the DMA kernel always skips masked tiles (their weights are exactly 0.0f, so the result equals the dense form bit for bit); a caller
+        // asking for skip_masked = 0 gets the dense register-staged kernel, so that A/B and parity runs measure what they ask for
         const char* e = getenv("VF_ATTN_DMA");                       // VF_ATTN_DMA=0: keep the register-staged kernel (A/B runs, parity test)
         if (!(e && e[0] == '0')) {
             const int rc = vf_attn_dma_launch(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale, twin_view, (hipStream_t)stream);

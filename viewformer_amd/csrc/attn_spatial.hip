@@ -400,12 +400,12 @@ int vf_attn_spatial_f32(const float* qkv, float* out, int n_img, int HW, int C, 
     if (!qkv || !out || n_img < 0 || ld < 3 * (int64_t)C || ldo < C || (ld & 3) || (ldo & 3)) return VF_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = ((size_t)HW * 64 + 2 * 4 * 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_spatial_kernel<256, 256>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((256 * 64 + 512) * sizeof(float)));
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     if (HW == 256 && C == 256)
         hipLaunchKernelGGL((attn_spatial_kernel<256, 256>), dim3(4, (unsigned)n_img), dim3(256), smem, s, qkv, out, (long long)ld, (long long)ldo, scale);
@@ -423,12 +423,12 @@ int vf_attn_spatial_x3h(const float* qkv, float* out, int n_img, int HW, int C, 
     if (!qkv || !out || n_img < 0 || ld < 3 * (int64_t)C || ldo < C || (ld & 3) || (ldo & 3)) return VF_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)2 * 64 * (HW * 2 + 16) + 2 * 4 * 64 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_spatial_x3h_kernel<256, 256>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (256 * 2 + 16) + 2048));
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     if (HW == 256 && C == 256)
         hipLaunchKernelGGL((attn_spatial_x3h_kernel<256, 256>), dim3(4, (unsigned)n_img), dim3(256), smem, s, qkv, out, (long long)ld, (long long)ldo, scale);

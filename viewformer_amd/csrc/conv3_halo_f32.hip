@@ -245,12 +245,12 @@ int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
     using G = Geo<UP2, PAIR>;
     const size_t smem = (size_t)2 * G::BUF * sizeof(float);
     auto kern = conv3_halo_kernel<UP2, PRO, SWISH, PAIR>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const int n_img = a.M / (a.Hout * a.Wout);
     const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)

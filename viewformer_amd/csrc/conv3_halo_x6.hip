@@ -646,15 +646,15 @@ int vf_conv3_halo_x6(const vf_igemm_args* args, void* stream) {
     if (VF_X6_BIG && a.mode == VF_MODE_CONV3_S1 && !pair && a.Hout % BTH == 0) {
         const long long blocks = (long long)(a.M / (a.Hout * a.Wout)) * (a.Hout / BTH) * (a.Wout / TW) * (a.Cout / BN);
         const size_t smem = (size_t)2 * B_BUF;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+        if (vf_attr_needed(&attr_devs)) {
             for (const void* f : {reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<false, false>),
                                   reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<true, false>),
                                   reinterpret_cast<const void*>(conv3_halo_x6_big_kernel<true, true>)}) {
                 hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
                 if (e != hipSuccess) return (int)e;
             }
-            attr_set = true;
+            vf_attr_done(&attr_devs);
         }
         if (!a.pro_mean) hipLaunchKernelGGL((conv3_halo_x6_big_kernel<false, false>), dim3((unsigned)blocks), dim3(256), smem, s, a);
         else if (a.pro_swish) hipLaunchKernelGGL((conv3_halo_x6_big_kernel<true, true>), dim3((unsigned)blocks), dim3(256), smem, s, a);

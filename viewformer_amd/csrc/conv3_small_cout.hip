@@ -129,13 +129,13 @@ int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bi
     hipStream_t s = (hipStream_t)stream;
     const size_t wsm = (size_t)(Cin / CK) * 9 * CK * MAXCO * sizeof(float);
     if (wsm > 96 * 1024) return VF_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {                                        // static patch (49 KB) + dynamic weights exceed the default 64 KB
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {                                        // static patch (49 KB) + dynamic weights exceed the default 64 KB
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     if (!pro_mean)
         hipLaunchKernelGGL((conv3_small_cout_kernel<false, false>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,

@@ -541,12 +541,12 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     const size_t smem = (size_t)2 * (A_BYTES + B_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const int nb = (a.Cout + BN - 1) / BN, mt = (a.M + BM - 1) / BM;
 #ifndef VF_GEMM_BF16_DIRECT

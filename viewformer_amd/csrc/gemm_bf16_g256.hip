@@ -452,12 +452,12 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     if (o16 && (a.res || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
     if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
     if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
     const dim3 g((unsigned)(mt * nb));

@@ -283,12 +283,12 @@ int launch_igemm(const vf_igemm_args& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM_T * 32;
     const size_t smem = (size_t)(2 * BM * A_LD + 2 * CK * BN) * sizeof(float);
     auto kern = igemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, PBN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const int nb = (a.Cout + BN - 1) / BN;
     const int mt = (a.M + BM - 1) / BM;

@@ -17,6 +17,19 @@ static inline int vf_last_status() {
     return e == hipSuccess ? VF_OK : (int)e;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: a launcher remembers per device (bit = device
+// ordinal) that it has raised its kernel's limit, so a second GPU driven from the same process gets the limit too
+static inline bool vf_attr_needed(unsigned long long* mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return !((__atomic_load_n(mask, __ATOMIC_RELAXED) >> (d & 63)) & 1ull);
+}
+static inline void vf_attr_done(unsigned long long* mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    __atomic_fetch_or(mask, 1ull << (d & 63), __ATOMIC_RELAXED);
+}
+
 __device__ __forceinline__ float vf_swish(float v) {
     // x * sigmoid(x), precise expf + IEEE division (no fast-math: fp32 parity with the oracle)
     return v / (1.0f + expf(-v));

@@ -205,12 +205,12 @@ int vf_vq_argmin_f32(const float* z, const float* E_packed, const float* e_sq, i
     if (D % CK != 0) return VF_ERR_UNSUPPORTED;
     if (M == 0) return VF_OK;
     const size_t smem = (size_t)(2 * BM * A_LD + 2 * CK * BN + BM) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const unsigned grid = (unsigned)((M + BM - 1) / BM);
     hipLaunchKernelGGL(vq_argmin_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, z, E_packed, e_sq,

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         const float zz_up = zn * zn;
         float eps_row = (zn * e_max) * 1.1300e-3f + ee_max * 7.7e-5f + zz_up * 6.0e-8f + (zn + e_max) * 5.0e-7f + 1e-12f;
         eps_row *= 1.01f;
-        if (!(ss < 3.0e38f)) eps_row = -1.0f;
+        if (!(ss < 3.0e38f) || !(e_max < 6.5e4f)) eps_row = -1.0f;      // (e_max: see consts_kernel — a codebook outside fp16's range)
         if (half == 0) eps_s[wr + l31] = eps_row;
     }
     __syncthreads();                                                                // every wave is done with R0: the ring may start
@@ -445,7 +445,7 @@ __global__ void consts_kernel(const float* __restrict__ ee, float* __restrict__ 
     for (int k = threadIdx.x; k < Kc; k += 256) {
         const float v = ee[k];
         hee[k] = -0.5f * v;
-        m = fmaxf(m, v);
+        m = fmaxf(m, (v < 3.0e38f) ? v : INFINITY);       // a NaN / inf squared norm (fmaxf would drop a NaN) poisons the maximum
     }
     red[threadIdx.x] = m;
     __syncthreads();
@@ -454,7 +454,10 @@ __global__ void consts_kernel(const float* __restrict__ ee, float* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        consts[0] = sqrtf(red[0]) * 1.00001f;      // e_max >= max_k |e_k| (ee is an fp32 sum of squares: relative error < 2^-15)
+        // e_max >= max_k |e_k| (ee is an fp32 sum of squares: relative error < 2^-15).  A codebook the fp16 tiles cannot carry — an
+        // entry beyond fp16's range (|e_k| >= 65504 for some k implies e_max >= 65504) or a non-finite one — leaves e_max = inf here:
+        // the kernel then certifies nothing and every row takes the exact scan (same indices as vq_argmin, at its speed)
+        consts[0] = sqrtf(red[0]) * 1.00001f;
         consts[1] = red[0] * 1.00004f;             // ee_max
         consts[2] = INFINITY;                      // (see update_keys)
     }
@@ -493,12 +496,12 @@ int vf_vq_argmin_filtered_f32(const float* z, const void* packed, int64_t M, int
 #else
     const size_t smem = SMEM_BYTES;
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
+    if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        vf_attr_done(&attr_devs);
     }
     const unsigned grid = (unsigned)((M + BM - 1) / BM);
     hipLaunchKernelGGL(vq_filter_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, z, packed, (long long)M, Kc,

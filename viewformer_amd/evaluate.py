@@ -25,14 +25,25 @@ def _frames_for_encode(images, image_size):
     return flat
 
 
+MAX_SCENES_PER_CALL = 256      # scenes per transformer / decoder pass: the reference's loop batches arbitrary sizes
+                               # (evaluate_transformer.py:219); scenes are independent, so a larger batch is walked in chunks with
+                               # identical results (1024 scenes = 7168 frames would otherwise need 32-bit-offset-breaking activations)
+
+
 def generate_batch_predictions(transformer_model, codebook_model, images, cameras, return_codes: bool = False,
-                               fused_passes: bool = True):
+                               fused_passes: bool = True, max_scenes_per_call: int = None):
     """``fused_passes``: run the generation pass and the localization pass as one twin-view pass
     (MIGT.generate_and_localize; bit-identical rows, 8/14 of the transformer work at S=7); False = the
-    reference's two separate calls."""
+    reference's two separate calls.  Batches above ``max_scenes_per_call`` (default MAX_SCENES_PER_CALL) are processed in scene
+    chunks and concatenated."""
     dev = codebook_model.device
     images = torch.as_tensor(images).to(dev)
     cameras = torch.as_tensor(cameras, dtype=torch.float32).to(dev)
+    chunk = max_scenes_per_call or MAX_SCENES_PER_CALL
+    if images.shape[0] > chunk:
+        parts = [generate_batch_predictions(transformer_model, codebook_model, images[i:i + chunk], cameras[i:i + chunk], return_codes,
+                                            fused_passes, chunk) for i in range(0, images.shape[0], chunk)]
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0] if parts[0][k] is not None}
     ground_truth_cameras = cameras[:, -1]
     transform = None
     if transformer_model.config.augment_poses == 'relative':            # :99-101
@@ -102,3 +113,67 @@ def codebook_batch_predictions(codebook_model, images):
     if codebook_model.data_format == 'NCHW':
         dec = dec.permute(0, 2, 3, 1)
     return dict(ground_truth_images=images, generated_images=ops.postprocess_u8(dec.contiguous()), codes=codes)
+
+
+def stream_batch_predictions(transformer_model, codebook_model, batches, depth: int = 2):
+    """The evaluator's OUTER loop (evaluate_transformer.py:219-222: ``for batch in dataset: generate_batch_predictions(...)`` with
+    host tensors in and out) with the host round trip hidden: batch i+1's frames / cameras are uploaded and batch i-1's results are
+    downloaded on a second HIP stream while batch i computes.  ``batches`` yields ``(images uint8 [B,S,H,W,3], cameras [B,S,7])``
+    host tensors (pinned ones copy asynchronously); yields per batch the same dict as ``generate_batch_predictions`` with
+    ``generated_images`` / ``generated_cameras`` on the host.  Results are those of the plain call, in order.  The host tensors
+    come from a ring of ``depth + 1`` pinned buffers per key: they stay valid until ``depth`` further batches have been yielded
+    (the reference's loop consumes a batch's images before it asks for the next one); copy what must live longer."""
+    dev = codebook_model.device
+    compute = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(dev)
+    ring, ring_pos = {}, [0]
+
+    def host_buffer(k, t):
+        key = (k, tuple(t.shape), t.dtype)
+        if key not in ring:
+            ring[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(depth + 1)]
+        return ring[key][ring_pos[0] % (depth + 1)]
+
+    def upload(b):
+        img, cam = (torch.as_tensor(x) for x in b)
+        with torch.cuda.stream(copy):
+            img_d = img.to(dev, non_blocking=True)
+            cam_d = cam.to(dev, torch.float32, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        return img_d, cam_d, ev
+
+    def download(out):
+        done = torch.cuda.Event()
+        done.record(compute)
+        host = {}
+        with torch.cuda.stream(copy):
+            copy.wait_event(done)
+            for k in ('generated_images', 'generated_cameras'):
+                out[k].record_stream(copy)
+                host[k] = host_buffer(k, out[k])
+                host[k].copy_(out[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        ring_pos[0] += 1
+        return out, host, ev
+
+    it = iter(batches)
+    pending = []                       # results whose download is in flight
+    nxt = next(it, None)
+    up = upload(nxt) if nxt is not None else None
+    while up is not None:
+        img_d, cam_d, ev = up
+        nxt = next(it, None)
+        up = upload(nxt) if nxt is not None else None          # the next batch's copy overlaps this batch's kernels
+        compute.wait_event(ev)
+        img_d.record_stream(compute)
+        cam_d.record_stream(compute)
+        pending.append(download(generate_batch_predictions(transformer_model, codebook_model, img_d, cam_d)))
+        while len(pending) >= depth:
+            out, host, dl = pending.pop(0)
+            dl.synchronize()
+            yield dict(out, **host)
+    for out, host, dl in pending:
+        dl.synchronize()
+        yield dict(out, **host)

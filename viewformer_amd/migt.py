@@ -94,7 +94,18 @@ class MIGT:
             keys.append('pose_loss_weighting_criterion.pos_ori_weights')
         return keys
 
+    _DYN_KEY = 'pose_loss_weighting_criterion.pos_ori_weights'
+
     def load_state_dict(self, state_dict, strict: bool = True):
+        # the one training-only variable (DynamicLossWeightingCriterion, migt.py:105-112, initial value [0, -3]) is tolerated either way:
+        # state dicts written before the key was tracked lack it, and a Keras checkpoint of a model trained with the flag carries it
+        # even when the loading config has the flag off (inference never reads it)
+        if strict and (self._DYN_KEY in state_dict) != bool(self.config.use_dynamic_pose_loss):
+            state_dict = OrderedDict(state_dict)
+            if self.config.use_dynamic_pose_loss:
+                state_dict[self._DYN_KEY] = np.array([0.0, -3.0], dtype=np.float32)
+            else:
+                del state_dict[self._DYN_KEY]
         if strict:
             want, have = set(self.expected_keys()), set(state_dict.keys())
             if want - have:

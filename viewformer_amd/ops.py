@@ -270,7 +270,8 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
 
 
 def conv3_small_cout_supported(mode, Cin, Cout, H, W):
-    return mode == MODE_CONV3_S1 and 1 <= Cout <= 4 and Cin % 32 == 0 and H % 8 == 0 and W % 32 == 0
+    # the kernel keeps ALL weights in LDS (Cin / 32 x 4608 B, at most 96 KiB: Cin <= 672); wider inputs take the implicit-GEMM path
+    return mode == MODE_CONV3_S1 and 1 <= Cout <= 4 and Cin % 32 == 0 and Cin // 32 * 4608 <= 96 * 1024 and H % 8 == 0 and W % 32 == 0
 
 
 def conv3_small_cout(x, w_oihw, bias, n_img, H, W, Cin, Cout, pro=None, pro_swish=True, out=None):

@@ -7,9 +7,11 @@ Mirrors the duck-typed protocol every reference caller uses:
 ``data_format='NCHW'`` = the Torch model (vqgan_th.py), ``'NHWC'`` = its TF twin
 (viewformer/models/vqgan.py:291-301) that the evaluators call.
 
-All arithmetic runs in libvf_hip.so (channels-last fp32, exact-f32 MFMA implicit GEMM, GroupNorm
-statistics + apply fused into the consuming conv, on-chip codebook argmin).  torch is used for
-device allocations, views and the stream only.
+All arithmetic runs in libvf_hip.so: channels-last fp32 activations, implicit-GEMM convolutions in one of the fp32-EQUIVALENT
+arithmetics (``conv_arith`` = 'x3h' — two exact fp16 pieces, three MFMA products, the default — 'x6' or the native 'f32' MFMA;
+DESIGN.md 3), GroupNorm statistics + apply fused into the producing / consuming convolution, the codebook lookup as an fp16-MFMA
+candidate filter with an exact fp32 re-rank (``lookup`` = 'filter'; 'exact' scans every code on the f32 MFMA).
+``decoder_precision='bf16'`` is the tolerance arm of the decoder.  torch is used for device allocations, views and the stream only.
 """
 import re
 from collections import OrderedDict
@@ -33,14 +35,16 @@ class _Conv:
 class VQGAN:
     def __init__(self, config: VQGANConfig = None, data_format: str = 'NCHW', device=None, max_images_per_call: int = 1024,
                  decoder_precision: str = 'f32', conv_arith: str = 'x3h', lookup: str = 'filter'):
-        """``conv_arith`` picks how the fp32 3x3 convolutions are evaluated: 'f32' = native f32 MFMA, 'x6' = the
-        fp32-EQUIVALENT six-term split-bf16 kernel (same error against fp64 as the f32 MFMA, ~1.6x faster; see
-        csrc/conv3_halo_x6.hip), 'x3h' = x6 everywhere except the stride-1 / upsample 3x3 convolutions, which run the
-        three-term split-fp16 kernel (csrc/conv3_halo_x3h.hip: same error against fp64 for activations in fp16's range, half the
-        matrix instructions).  All give bit-identical token indices on the reference's golden vectors.
+        """``conv_arith`` picks the fp32-EQUIVALENT arithmetic of the convolutions (DESIGN.md 3): 'f32' = native f32 MFMA everywhere;
+        'x6' = six exact bf16 partial products per fp32 product (csrc/conv3_halo_x6.hip, gemm_x6.hip); 'x3h' (default) = three exact
+        fp16 partial products (csrc/conv3_halo_x3h.hip, gemm_x3h.hip, attn_spatial.hip) for every 3x3 convolution (stride 1, stride 2,
+        nearest-x2), the 1x1 convolutions (quant_conv included) / q|k|v projections and the AttnBlock core, with x6 left for the
+        shapes the x3h kernels do not tile.  Each has an error against fp64 no larger than the native f32 MFMA's and all give
+        bit-identical token indices on the reference's golden vectors (tests/test_hip_models.py, test_hip_parity_scale.py).
         ``decoder_precision='bf16'`` runs the DECODER's wide 3x3 convolutions and 1x1 projections on the bf16-MFMA
         arm (decoded pixels are tolerance-bounded in the north star); the encoder and the codebook lookup are always
-        exact fp32 so token indices stay bit-exact."""
+        exact fp32 so token indices stay bit-exact.  ``lookup``: 'filter' = fp16-MFMA candidate filter + exact fp32 re-rank
+        (csrc/vq_filter.hip), 'exact' = every code on the f32 MFMA (csrc/vq_argmin.hip); identical indices."""
         self.config = config or VQGANConfig()
         assert data_format in ('NCHW', 'NHWC')
         assert decoder_precision in ('f32', 'bf16') and conv_arith in ('f32', 'x6', 'x3h') and lookup in ('filter', 'exact')
@@ -56,6 +60,9 @@ class VQGAN:
         self._norm = {}
         self._qkv = {}
         self.training = False
+        # conv_arith='x3h': 1x1 convolutions / q|k|v projections on the 3-product split-fp16 GEMM (VF_VQ_DENSE_X3H=0: 6-product x6); read
+        # per instance, like every other environment knob of the package
+        self.dense_x3h = os.environ.get('VF_VQ_DENSE_X3H', '1') != '0'
 
     # ------------------------------------------------------------------ module-ish API
     def eval(self):
@@ -235,7 +242,6 @@ class VQGAN:
 
     _stats_of = None          # (tensor, partials) of the most recent halo-conv output
     fuse_gn_stats = True
-    dense_x3h = os.environ.get('VF_VQ_DENSE_X3H', '1') != '0'     # conv_arith='x3h': 1x1 convolutions / q|k|v projections on the 3-product split-fp16 GEMM (False: 6-product x6)
     fused_attention = True    # AttnBlock core in one kernel where the shape allows (False: batched GEMMs + row softmax, kept for A/B)
 
     def _res(self, x, name, n, H, W, cin, cout):
