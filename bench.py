@@ -259,9 +259,26 @@ def run_train(args, rank, local, world, dev):
     tokens = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8))).to(dev)
     _, cams = synthetic_scene_batch(B, S, 8, seed=rank)
     poses = geometry.normalize_cameras(geometry.to_relative_cameras(torch.from_numpy(cams))[0]).to(dev)
+    tr.grad_allreduce_dtype = args.grad_dtype
     tr.train_step(poses, tokens)                                       # setup (allocator, code objects), untimed
     dt, met = timed(lambda: tr.train_step(poses, tokens), args.steps, args.warmup, dev)
     scenes = sharding.sum_over_ranks(B * args.steps, dev)
+    comm = None
+    if world > 1:
+        # what the collective costs: the same step without it, and the compute stream's wait for the per-layer all-reduces after the
+        # last backward kernel (the part the overlap with the backward pass did not hide), averaged over the timed step count
+        dt_off, _ = timed(lambda: tr.train_step(poses, tokens, reduce_gradients=False), args.steps, 1, dev)
+        tr.time_allreduce = True
+        waits = []
+        for _ in range(args.steps):
+            tr.train_step(poses, tokens)
+            waits.append(tr.exposed_allreduce_ms())
+        tr.time_allreduce = False
+        exposed = sharding.max_over_ranks(sum(waits) / len(waits), dev)
+        comm = {'ms_per_step_without_allreduce': round(dt_off / args.steps * 1e3, 3), 'exposed_allreduce_wait_ms': round(exposed, 3),
+                'gradient_dtype_on_the_links': args.grad_dtype, 'backend': torch.distributed.get_backend(),
+                'note': 'per-layer SUM all-reduce issued as each layer\'s backward completes; exposed = compute-stream wait after the '
+                        'last backward kernel (HIP events), max over ranks'}
     if rank != 0:
         return
     prof = OpTimer()
@@ -281,7 +298,7 @@ def run_train(args, rank, local, world, dev):
                                       'overlapped with the backward pass', 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
                        'precision': ('fp32 master weights, bf16-MFMA dense GEMMs (the reference trains with --fp16)' if arm == 'bf16' else
                                      'fp32-equivalent: x3h forward GEMMs, x6 backward GEMMs, x6 / f32 attention'),
-                       'weights': 'random-init MIGT 88.4M', 'loss': float(met['loss'])},
+                       'weights': 'random-init MIGT 88.4M', 'loss': float(met['loss']), 'collective': comm},
             'roofline': {'bound': 'mfma', 'kernel': 'dense GEMM family of the step (gemm_x3h / gemm_x6 / gemm_bf16 launches: forward, dX, dW)',
                          'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                          'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': n,
@@ -359,6 +376,8 @@ def main():
     ap.add_argument('--encoder-chunk', type=int, default=1024, help='images per encoder / decoder launch chunk (VQGAN max_images_per_call)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     ap.add_argument('--dropout', type=float, default=0.0, help='train: dropout rate (the reference default is 0.1)')
+    ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
+                    help='train: dtype of the gradient buckets on the links (bf16 halves the 354 MB all-reduce; default f32 like the reference)')
     ap.add_argument('--batch-sweep', default=None,
                     help='views workload: comma-separated scenes-per-step list (SURVEY 8d: 1,8,64,256,1024); prints ONE JSON line with the '
                          'views/s of every batch size (same models, inputs resident in HBM, --steps timed steps each)')
@@ -389,8 +408,10 @@ def main():
     if args.batch_sweep:
         sweep = []
         for b in [int(x) for x in args.batch_sweep.split(',')]:
-            fr, cm = synthetic_scene_batch(b, S, 128, seed=rank)
-            fr_d, cm_d = torch.from_numpy(fr).to(dev), torch.from_numpy(cm).to(dev)
+            fr, cm = synthetic_scene_batch(min(b, 256), S, 128, seed=rank)     # (beyond 256 scenes the batch repeats: host-side generation
+            fr_d, cm_d = torch.from_numpy(fr).to(dev), torch.from_numpy(cm).to(dev)   # of 7168 frames takes longer than the measurement)
+            if b > 256:
+                fr_d, cm_d = fr_d.repeat(-(-b // 256), 1, 1, 1, 1)[:b].contiguous(), cm_d.repeat(-(-b // 256), 1, 1)[:b].contiguous()
 
             def step_b():
                 return generate_batch_predictions(tr, vq, fr_d, cm_d)
@@ -475,13 +496,19 @@ def main():
     for o in stream_batch_predictions(tr, vq, ((fr_h, cm_h) for _ in range(n_io))):
         img_h = o['generated_images']                  # host tensors (pinned ring)
     host_dt = (time.perf_counter() - t0) / n_io
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_io):                              # the resident loop again, right beside it (clocks drift between the phases of a run)
+        step()
+    torch.cuda.synchronize()
+    resident_dt = (time.perf_counter() - t0) / n_io
     t0 = time.perf_counter()
     for _ in range(2):
         o = generate_batch_predictions(tr, vq, fr_h.to(dev, non_blocking=True), cm_h.to(dev, non_blocking=True))
         img_s, cam_s = o['generated_images'].cpu(), o['generated_cameras'].cpu()
     serial_dt = (time.perf_counter() - t0) / 2
     line['host_io'] = {'value': round(B / host_dt, 2), 'unit': 'novel views/s', 'steps': n_io,
-                       'serial_value': round(B / serial_dt, 2),
+                       'serial_value': round(B / serial_dt, 2), 'resident_value_same_phase': round(B / resident_dt, 2),
                        'note': f'the evaluator\'s outer loop with host tensors in and out (evaluate.stream_batch_predictions): {fr_h.numel() >> 20} MiB of frames up '
                                f'and {img_h.numel() >> 20} MiB of generated images down per step on a second HIP stream, overlapped with the neighbouring '
                                'steps\' kernels; serial_value = the same copies issued in line with the step (the reference\'s loop); never the headline value'}

@@ -438,6 +438,11 @@ int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* 
  * p -= lr_adam * m / (sqrt(v) + eps)   with lr_adam = lr*sqrt(1-b2^t)/(1-b1^t), lr_decay = lr*weight_decay or 0 */
 int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_decay, float lr_adam, float beta1,
                  float beta2, float eps, void* stream);
+/* the same step over a whole FLAT buffer in one launch: elements inside one of the sorted, disjoint [start, end) element ranges of
+ * nodecay_ranges (device int64 pairs; the "bias" tensors, models/utils.py:424) take lr_decay = 0; bit-identical to per-tensor
+ * vf_adamw_f32 calls.  n % 4 == 0, 16-byte aligned buffers, tensors starting on 4-element boundaries, at most 256 ranges. */
+int vf_adamw_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n, const int64_t* nodecay_ranges, int nranges,
+                      float lr_decay, float lr_adam, float beta1, float beta2, float eps, void* stream);
 int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream);
 /* out = a*x + b*y (y may be NULL: out = a*x); out may alias x or y */
 int vf_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);

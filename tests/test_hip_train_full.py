@@ -1,0 +1,147 @@
+"""GPU: the transformer training step at FULL SIZE (a18 / BASELINE configs[3] was only ever tested at toy width).
+
+CO3D 10-category finetune shape (README.md:250-264; viewformer/models/migt.py:464-505): d_model 768, 12 layers, 12 heads, sequences of
+10 views, 3 streams x 640 tokens per scene, 64 tokens per view, localization head on.  The fp64 autograd oracle does not finish at
+this size in test time, so the checks are the size-independent ones:
+* every gradient tensor finite and non-zero, the loss finite; two runs of the same step bit-identical (no atomics, fixed-order
+  split-K / slab sums);
+* the bf16 arm (the one ``bench.py --workload train`` times) within the stated per-tensor tolerance of the fp32-equivalent arm — the
+  same bound tests/test_train.py holds against the fp64 oracle at toy width;
+* the one-launch AdamWeightDecay == the per-tensor launches bit for bit, and one optimizer step moves every tensor;
+* two ranks (one GPU each over RCCL when the box has two; otherwise both on cuda:0 over gloo) reduce to the sum of their local
+  gradients == world x the single-process gradient of the concatenated batch (per-replica mean loss, SUMmed: migt.py:471-476,488).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16_GRAD_TOL = 6e-2        # per-tensor max |g_bf16 - g_fp32eq| / max |g_fp32eq| (tests/test_train.py: same bound vs the fp64 oracle)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+def _cfg(**kw):
+    from viewformer_amd.config import MIGTConfig
+    base = dict(sequence_size=10, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.0, learning_rate=1e-4,
+                weight_decay=0.05, total_steps=40000)
+    base.update(kw)
+    return MIGTConfig(**base)
+
+
+def _batch(B, S, seed):
+    from viewformer_amd import geometry
+    from viewformer_amd.weights import synthetic_scene_batch
+    g = np.random.Generator(np.random.PCG64(seed))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, seed=seed)
+    poses = geometry.normalize_cameras(geometry.to_relative_cameras(torch.from_numpy(cams))[0])
+    return poses, tokens
+
+
+def _trainer(cfg, dev, precision, seed=0):
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    return MIGTTrainer(MIGT(cfg, precision=precision).load_state_dict(make_migt_weights(cfg, seed=seed)).to(dev))
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-300)).item()
+
+
+def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev):
+    cfg = _cfg()
+    assert (cfg.d_model, cfg.n_layer, cfg.n_head) == (768, 12, 12)
+    B, S = 4, 10
+    poses, tokens = _batch(B, S, seed=7)
+    tr32 = _trainer(cfg, dev, 'f32')
+    tr32.step_count = 2500                                    # past the warm-up: a real learning rate
+    m1 = tr32.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    g1 = tr32.flat_g.clone()
+    assert np.isfinite(float(m1['loss'])) and 6.0 < float(m1['ce_loss']) < 8.0        # ~ln(1024) = 6.93 on random-init weights
+    assert bool(torch.isfinite(g1).all())
+    m2 = tr32.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(tr32.flat_g, g1) and float(m2['loss']) == float(m1['loss'])   # deterministic
+    zero_ok = {'h.%d.attn.c_attn.bias' % i for i in range(cfg.n_layer)}                # the key third of that bias has a zero gradient (softmax shift)
+    for n in tr32.names:
+        assert float(tr32.g(n).abs().max()) > 0 or n in zero_ok, n
+
+    tr16 = _trainer(cfg, dev, 'bf16')
+    tr16.step_count = 2500
+    assert any(dn.wp16 is not None for dn in tr16.model._dense.values()) and len(tr16.wpT16) > 0
+    mb = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert abs(float(mb['loss']) - float(m1['loss'])) < 2e-2 * max(1.0, abs(float(m1['loss'])))
+    worst = ('', 0.0)
+    for n in tr16.names:
+        ref = tr32.g(n)
+        if float(ref.abs().max()) == 0:
+            continue
+        e = _rel(tr16.g(n), ref)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < BF16_GRAD_TOL, (n, e)
+    print('full-size bf16 arm vs fp32-equivalent arm: worst per-tensor gradient error', worst)
+    gb = tr16.flat_g.clone()
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(tr16.flat_g, gb)                       # the bf16 arm (batched split-K dW) is deterministic too
+
+    # one-launch AdamWeightDecay == per-tensor launches, bit for bit; every tensor moves
+    p0, m0, v0 = tr16.flat_p.clone(), tr16.flat_m.clone(), tr16.flat_v.clone()
+    tr16.fused_optimizer = True
+    tr16.apply_gradients()
+    p_fused, m_fused, v_fused = tr16.flat_p.clone(), tr16.flat_m.clone(), tr16.flat_v.clone()
+    tr16.flat_p.copy_(p0); tr16.flat_m.copy_(m0); tr16.flat_v.copy_(v0)
+    tr16.step_count -= 1
+    tr16.fused_optimizer = False
+    tr16.apply_gradients()
+    assert torch.equal(tr16.flat_p, p_fused) and torch.equal(tr16.flat_m, m_fused) and torch.equal(tr16.flat_v, v_fused)
+    for n in tr16.names:
+        a, b, _ = tr16.slices[n]
+        assert float((tr16.flat_p[a:b] - p0[a:b]).abs().max()) > 0 or n in zero_ok, n
+    tr16.fused_optimizer = True
+    m3 = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)   # the refreshed packings are the updated weights
+    assert float(m3['loss']) < float(mb['loss'])
+
+
+def _full_worker(rank, world, port, q):
+    try:
+        from test_hip_multirank import _init, _gather, _rel as rel
+        dev, dist = _init(rank, world, port)
+        cfg = _cfg()
+        tr = _trainer(cfg, dev, 'bf16')
+        tr.step_count = 2500
+        B, S = 2, 10
+        poses, tok = _batch(B, S, 100 + rank)
+        tr.train_step(poses, tok, reduce_gradients=False, apply_update=False)
+        g_local = tr.flat_g.clone()
+        tr.train_step(poses, tok, reduce_gradients=True, apply_update=False)           # per-layer ranges, async, overlapped
+        g_red = tr.flat_g.clone()
+        e_sum = rel(g_red, sum(_gather(g_local, dist, world)))
+        allb = [_batch(B, S, 100 + r) for r in range(world)]
+        tr.train_step(torch.cat([b[0] for b in allb]), torch.cat([b[1] for b in allb]), reduce_gradients=False, apply_update=False)
+        e_cat = rel(g_red, tr.flat_g * world)
+        tr.train_step(poses, tok)                                                      # one optimizer step: replicas stay identical
+        params = _gather(tr.flat_p, dist, world)
+        q.put((rank, 'ok', dict(e_sum=e_sum, e_cat=e_cat, in_sync=all(torch.equal(params[0], p) for p in params[1:]),
+                                backend=dist.get_backend())))
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, 'err', traceback.format_exc() + repr(e)))
+
+
+def test_full_size_two_ranks_equal_the_concatenated_batch():
+    from test_hip_multirank import _run
+    res = _run(_full_worker)
+    print(res)
+    for r, m in res.items():
+        assert m['e_sum'] < 1e-6, m
+        # bf16 GEMMs round differently when the batch (the GEMMs' M) changes tile membership: the concatenated-batch gradient agrees
+        # to the arm's own noise, not bit for bit
+        assert m['e_cat'] < 2e-3, m
+        assert m['in_sync'], m

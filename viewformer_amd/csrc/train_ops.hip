@@ -312,6 +312,42 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// The whole flat parameter buffer in ONE launch (the per-tensor form above took 468 launches per step): elements inside one of the
+// sorted, disjoint [start, end) ranges of `nodecay` (the "bias" tensors, models/utils.py:424) skip the decoupled decay, everything
+// else gets it.  Same expressions per element as adamw_kernel (lr_decay = 0 there), so the two forms agree bit for bit.  Tensors start
+// on 16-byte boundaries of the flat buffer, so a float4 never straddles two tensors; the padding between them holds zeros.
+constexpr int ADAMW_MAX_RANGES = 256;
+__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                  long long n4, const long long* __restrict__ nodecay, int nranges, float lr_decay, float lr_adam,
+                                  float b1, float b2, float eps) {
+    __shared__ long long rs[ADAMW_MAX_RANGES], re[ADAMW_MAX_RANGES];
+    for (int i = threadIdx.x; i < nranges; i += blockDim.x) { rs[i] = nodecay[2 * i]; re[i] = nodecay[2 * i + 1]; }
+    __syncthreads();
+    for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i4 * 4;
+        int lo = 0, hi = nranges;                       // first range with end > i
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (re[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        const float ld = (lo < nranges && rs[lo] <= i) ? 0.f : lr_decay;
+        f32x4 w = *reinterpret_cast<const f32x4*>(p + i);
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mi = *reinterpret_cast<const f32x4*>(m + i), vi = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float we = w[e];
+            we -= ld * we;
+            mi[e] = b1 * mi[e] + (1.f - b1) * gi[e];
+            vi[e] = b2 * vi[e] + (1.f - b2) * gi[e] * gi[e];
+            w[e] = we - lr_adam * mi[e] / (sqrtf(vi[e]) + eps);
+        }
+        *reinterpret_cast<f32x4*>(m + i) = mi;
+        *reinterpret_cast<f32x4*>(v + i) = vi;
+        *reinterpret_cast<f32x4*>(p + i) = w;
+    }
+}
+
 // ------------------------------------------------------------------ dropout: out = x * keep / (1 - rate) [+ res]
 __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
                                    long long n, uint32_t thresh, float scale, uint32_t seed, uint32_t site) {
@@ -482,6 +518,16 @@ int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n,
     if (n == 0) return VF_OK;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n,
                        lr_decay, lr_adam, beta1, beta2, eps);
+    return vf_last_status();
+}
+
+int vf_adamw_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n, const int64_t* nodecay_ranges, int nranges,
+                      float lr_decay, float lr_adam, float beta1, float beta2, float eps, void* stream) {
+    if (!param || !grad || !m || !v || n < 0 || nranges < 0 || (nranges > 0 && !nodecay_ranges)) return VF_ERR_BAD_ARG;
+    if ((n & 3) || nranges > ADAMW_MAX_RANGES || (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15)) return VF_ERR_UNSUPPORTED;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid1(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                       (long long)(n / 4), reinterpret_cast<const long long*>(nodecay_ranges), nranges, lr_decay, lr_adam, beta1, beta2, eps);
     return vf_last_status();
 }
 

@@ -196,6 +196,24 @@ def conv3_x6_supported(mode, Cin, Cout, Hout, Wout):
     return (Hout % 8 == 0 and Wout % 16 == 0) or (mode == MODE_CONV3_S1 and Hout == 8 and Wout == 8)
 
 
+def gemm_bf16_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulate=True):
+    """dst[M][Cout] (+)= x @ W on the bf16 arm with the reduction split over ``splits`` slabs: the split-K of a weight-gradient GEMM
+    (few output tiles, a reduction of tens of thousands of rows) expressed as a BATCHED launch of vf_gemm_bf16 — batch entry s
+    reads columns [s Cin/splits, (s+1) Cin/splits) of x and the matching 64-deep chunk range of the chunk-major packing — followed by
+    the fixed-order slab sum (deterministic).  Cin / splits must be a multiple of 64 (the packing's chunk)."""
+    lib = _lib.load()
+    ks = Cin // splits
+    if splits < 1 or ks * splits != Cin or ks % 64:
+        raise _lib.VfError(f'gemm_bf16_splitk: Cin = {Cin} does not split into {splits} ranges of whole 64-deep chunks')
+    nb = (Cout + 127) // 128
+    slabs = torch.empty((splits, M, Cout), dtype=torch.float32, device=x.device)
+    igemm(x, w_packed, M, ks, Cout, slabs, lda=Cin if lda is None else lda, bf16=True, batch=splits, stride_x=ks,
+          stride_w=(ks // 64) * nb * 64 * 128, stride_out=M * Cout)
+    check(lib.vf_sum_slabs_f32(_p(slabs), splits, M * Cout, M * Cout, _p(_f32(dst)), 1 if accumulate else 0, _stream()),
+          'vf_sum_slabs_f32')
+    return dst
+
+
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,

@@ -166,15 +166,22 @@ class MIGTTrainer:
         m._lm_head16 = None
         m._lm_head6 = None                                  # the LM head / pose heads stay on the native kernel in training
         for name, dn in m._dense.items():
-            if dn.k % 32 == 0:
-                dn.wp = ops.pack(dn.w_raw, dn.k, dn.n, 1, sk=dn.n, sn=1, st=0, out=dn.wp)                  # forward: x @ W
-            if dn.n % 32 == 0:                                                                                # dX = dY @ W^T
+            k32 = dn.k % 32 == 0
+            to16 = bf16 and k32 and dn.k % 128 == 0 and dn.n % 128 == 0
+            to6 = x6 and k32 and dn.k % 64 == 0 and dn.n % 64 == 0
+            # the native-f32 packings are refreshed only where no faster arm applies (they were 477 pack launches per step that nothing
+            # read: the wide layers run on their bf16 / split packings); the transposed native packing of a wide layer is built on demand
+            # in _linear_bwd for row counts its arm does not tile
+            dn.wp = ops.pack(dn.w_raw, dn.k, dn.n, 1, sk=dn.n, sn=1, st=0, out=dn.wp) if k32 and not (to16 or to6) else None    # forward: x @ W
+            if dn.n % 32 == 0 and not (to16 or to6):                                                          # dX = dY @ W^T
                 self.wpT[name] = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0, out=self.wpT.get(name))
+            else:
+                self.wpT.pop(name, None)
             dn.wp6 = dn.wp16 = None
-            if bf16 and dn.wp is not None and dn.k % 128 == 0 and dn.n % 128 == 0:
+            if to16:
                 dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
                 self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
-            if x6 and dn.wp is not None and dn.k % 64 == 0 and dn.n % 64 == 0:
+            if to6:
                 dn.wp6 = ops.pack_dense_kn_x3h(dn.w_raw) if x3h else ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
@@ -198,7 +205,15 @@ class MIGTTrainer:
         x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
         bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
         if bf16:
-            ops.igemm(xt, ops.pack_dense_kn_bf16(dy), K, M, N, gw, res=gw, lda=Mp, bf16=True)        # dW += X^T dY
+            # dW += X^T dY: (K/128)(N/128) = 36..144 output tiles for 256 CUs and a reduction of M = 19 200 rows -> split-K (as the x6
+            # arm below); the split count must cut M into whole 64-row chunks of the packing
+            tiles = ((K + 127) // 128) * ((N + 127) // 128)
+            want = max(1, min(16, 768 // tiles))
+            splits = max([s for s in range(1, want + 1) if M % (64 * s) == 0] or [1])
+            if splits > 1 and (K * N) % 4 == 0:
+                ops.gemm_bf16_splitk(xt, ops.pack_dense_kn_bf16(dy), K, M, N, gw, splits, lda=Mp)
+            else:
+                ops.igemm(xt, ops.pack_dense_kn_bf16(dy), K, M, N, gw, res=gw, lda=Mp, bf16=True)
         elif x6:
             # dW += X^T dY: [K][N] has only (K/128)(N/128) = 36..144 tiles for 256 CUs but a reduction of M = 19200 rows
             tiles = ((K + 127) // 128) * ((N + 127) // 128)
@@ -218,13 +233,18 @@ class MIGTTrainer:
         elif x6:
             ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
         else:
-            ops.igemm(dy, self.wpT[name], M, N, K, dx, res=res)
+            wpT = self.wpT.get(name)
+            if wpT is None:                                                          # (a wide layer at a row count its arm does not tile)
+                wpT = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0)
+            ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
     def _ln_bwd(self, name, dy, x, M):
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
 
+    fused_optimizer = True            # AdamWeightDecay as ONE launch over the flat buffer (False: one launch per tensor, 468 per step; bit-identical)
+    _nodecay = None
     attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
 
     def random_pose_factors(self, B, seed):
@@ -437,8 +457,7 @@ class MIGTTrainer:
             dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
             saved[i] = None
             if overlap:                                                              # this layer's grads are final
-                a, b = self.layer_ranges[i]
-                handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                handles.append(self._allreduce_range(*self.layer_ranges[i]))
         # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
         if rate:
             T.dropout_add(dh, rate, seed, SITE_EMBED, out=dh)
@@ -456,15 +475,47 @@ class MIGTTrainer:
                 T.clip_by_norm_(self.g(n).reshape(-1), float(c.gradient_clip_val), self._scratch)
         if reduce_gradients and self._world() > 1:
             if overlap:
-                a, b = self.head_range
-                handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                handles.append(self._allreduce_range(*self.head_range))
+            elif self.grad_allreduce_dtype == 'bf16':
+                handles += [self._allreduce_range(a, b) for a, b in [self.head_range] + self.layer_ranges]
             else:
-                handles += sharding.allreduce_sum_ranges(self.flat_g, [self.head_range] + self.layer_ranges, self.group)
-            for hd in handles:
+                handles += [(h, None, None) for h in
+                            sharding.allreduce_sum_ranges(self.flat_g, [self.head_range] + self.layer_ranges, self.group)]
+            ev = None
+            if self.time_allreduce:                                                  # what the backward pass did NOT hide: the compute
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))   # stream's wait for the collectives
+                ev[0].record()
+            for hd, buf, rng in handles:
                 hd.wait()
+                if buf is not None:                                                  # bf16 bucket: back into the fp32 gradient buffer
+                    self.flat_g[rng[0]:rng[1]].copy_(buf)
+            if ev is not None:
+                ev[1].record()
+                self._allreduce_events = ev
         if apply_update:
             self.apply_gradients()
         return metrics
+
+    grad_allreduce_dtype = 'f32'      # 'bf16': each range is all-reduced as a bf16 copy (177 MB instead of 354 MB on the links; the sum
+                                      # of the replicas' gradients is then rounded to 8 bits per replica term — an option, off by default:
+                                      # the reference's MirroredStrategy reduces fp32 variables' gradients in fp32)
+    time_allreduce = False            # record HIP events around the wait for the collectives (exposed_allreduce_ms())
+    _allreduce_events = None
+
+    def _allreduce_range(self, a, b):
+        """async SUM all-reduce of flat_g[a:b] -> (handle, bf16 staging buffer or None, (a, b))"""
+        if self.grad_allreduce_dtype == 'bf16':
+            buf = self.flat_g[a:b].to(torch.bfloat16)
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, (a, b)
+        return dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, (a, b)
+
+    def exposed_allreduce_ms(self):
+        """time the compute stream spent waiting for the gradient collectives after the last backward kernel of the most recent step
+        (needs ``time_allreduce = True``): what the per-layer overlap did not hide"""
+        if self._allreduce_events is None:
+            return None
+        self._allreduce_events[1].synchronize()
+        return self._allreduce_events[0].elapsed_time(self._allreduce_events[1])
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -475,11 +526,19 @@ class MIGTTrainer:
         lr = learning_rate(step, c.learning_rate, c.total_steps, self.warmup_steps)
         t = step + 1
         lr_adam = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
-        for n in self.names:
-            a, b, _ = self.slices[n]
-            decay = c.weight_decay > 0 and 'bias' not in n            # models/utils.py:424: only "bias" names are excluded
-            T.adamw_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
-                     lr * c.weight_decay if decay else 0.0, lr_adam, self.b1, self.b2, self.eps)
+        if self.fused_optimizer:
+            # one launch over the flat buffer; the "bias" tensors (models/utils.py:424: the only names excluded) as no-decay ranges
+            if self._nodecay is None:
+                r = [[self.slices[n][0], self.slices[n][1]] for n in self.names if 'bias' in n]
+                self._nodecay = torch.tensor(sorted(r), dtype=torch.int64, device=self.dev).reshape(-1, 2)
+            T.adamw_flat_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self._nodecay if c.weight_decay > 0 else None,
+                          lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam, self.b1, self.b2, self.eps)
+        else:
+            for n in self.names:
+                a, b, _ = self.slices[n]
+                decay = c.weight_decay > 0 and 'bias' not in n            # models/utils.py:424: only "bias" names are excluded
+                T.adamw_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
+                         lr * c.weight_decay if decay else 0.0, lr_adam, self.b1, self.b2, self.eps)
         self.step_count += 1
         self.repack()
 

@@ -111,6 +111,15 @@ def adamw_(param, grad, m, v, lr_decay, lr_adam, beta1, beta2, eps):
                                    beta1, beta2, eps, _stream()), 'vf_adamw_f32')
 
 
+def adamw_flat_(param, grad, m, v, nodecay_ranges, lr_decay, lr_adam, beta1, beta2, eps):
+    """AdamWeightDecay over a whole flat buffer in one launch; ``nodecay_ranges`` = device int64 [R][2] of sorted element ranges that
+    skip the decay (bias tensors)"""
+    check(_lib.load().vf_adamw_flat_f32(_p(_f32(param)), _p(_f32(grad)), _p(_f32(m)), _p(_f32(v)), param.numel(),
+                                        _p(nodecay_ranges) if nodecay_ranges is not None and nodecay_ranges.numel() else None,
+                                        0 if nodecay_ranges is None else nodecay_ranges.shape[0], lr_decay, lr_adam, beta1, beta2, eps,
+                                        _stream()), 'vf_adamw_flat_f32')
+
+
 def add_(a, b):
     check(_lib.load().vf_add_inplace_f32(_p(_f32(a)), _p(_f32(b)), a.numel(), _stream()), 'vf_add_inplace_f32')
     return a
