@@ -429,9 +429,12 @@ int vf_softmax_ce_f32(const float* logits, const int32_t* target, const float* r
  * terms is weighted separately (w_pos, w_ori [rows]: DynamicLossWeightingCriterion :107-120 scales them differently) */
 int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const float* w_ori, const float* xyz_div, float* pos_loss,
                     float* ori_loss, float* draw, int64_t rows, int L, float position_multiplier, void* stream);
-/* backward of vf_embed_sum_f32: dwte (atomic scatter), dwpe (atomic), dadd[bs][:] = sum_l dh */
+/* backward of vf_embed_sum_f32 (the tf.gather / wpe slice of migt.py:358-368 under autograd): dwte[id] += sum of dh over the tokens
+ * with that id, dwpe[l] += sum_bs dh, dadd[bs][:] = sum_l dh.  Deterministic (fixed-order partial sums, no float atomics);
+ * workspace = vf_embed_bwd_workspace_bytes(d, vocab) bytes. */
+size_t vf_embed_bwd_workspace_bytes(int d, int vocab);
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
-                     int vocab, void* stream);
+                     int vocab, void* workspace, void* stream);
 /* weight/bias gradient of vf_dense_small_k_gelu_f32's linear part: dW[k][n] += sum_r x[r][k]*dy[r][n], db[n] += sum_r dy */
 int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* db, int64_t rows, int K, int N, void* stream);
 /* AdamWeightDecay step (viewformer/models/utils.py:507-537 on Keras Adam): p -= lr_decay*p; m,v update;

@@ -212,6 +212,27 @@ def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev
     assert err < ATTN_TOL, err
 
 
+@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 10, 'streams'), (1, 3, 9, 'causal'), (2, 1, 17, 'causal'), (1, 2, 21, 'twin')])
+def test_attention_dma_8_wave_form_is_bit_identical_to_the_4_wave_form(dev, B, H, S, mode, monkeypatch):
+    """the 8-wave workgroup (8 query views, 8-slot ring: every K / V tile of a (scene, head) fetched once per 8 views; taken for more than
+    4 views) against the 4-wave workgroup it replaces there (VF_ATTN_DMA8=0): per-wave arithmetic is the same, so are the bits.  Covers the
+    bench shape (8 views), workgroups whose last waves have no view, > 8 key views (ring slots recycled) and the training mask."""
+    from viewformer_amd import ops
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    q16 = _rand((B * T, 3 * d), 93, 0.35).to(dev).to(torch.bfloat16)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VF_ATTN_DMA8', flag)
+        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
+        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        outs[flag] = out
+    assert not torch.isnan(outs['1'].float()).any()
+    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
+
+
 def test_bf16_activation_chain_is_bit_identical(dev):
     """LayerNorm / GELU / attention outputs written as bf16 by their producers and read as bf16 by the GEMMs (a16 / o16): the same
     rounding the GEMM applies to an fp32 operand on load, so everything downstream is bit-identical — kernel by kernel and for the

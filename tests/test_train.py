@@ -481,3 +481,54 @@ def test_label_smoothing_matches_autograd(dev):
     assert abs(ref_metrics['ce_loss'] - plain['ce_loss']) > 1e-3                 # smoothing really changes the loss
     for name in tr.names:
         assert _err(tr.g(name), grads[name].reshape(tr.slices[name][2])) < 2e-3, name
+
+
+@pytest.mark.gpu
+def test_test_step_and_predict_step(dev):
+    """MIGT.test_step / predict_step (migt.py:507-541): the compute_losses graph with training=False.  Without dropout and random pose
+    multiplier it is the training forward, so its losses equal train_step's; with them on it ignores both (deterministic); the pose
+    error metrics follow utils/metrics.py:90-110; predict_step decodes arg-max tokens of every view next to the ground truth."""
+    from oracle import migt_oracle as mg
+    cfg, sd, tokens, poses, tr = _setup(True, dev)
+    tr.step_count = 3
+    m_train = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    m_test = tr.test_step(poses, tokens)
+    for k in ('loss', 'ce_loss', 'acc', 'pose_loss', 'pose_pos_loss', 'pose_ori_loss'):
+        assert float(m_test[k]) == float(m_train[k]), k
+    # the pose error metrics against the oracle's pose_prediction (LOC stream of the 3-stream graph)
+    ref = mg.migt_forward(sd, cfg, tokens, poses, localization_tokens=tokens, output_poses=poses, dtype=torch.float64)
+    pp = ref['pose_prediction'][:, cfg.n_loss_skip:].double()
+    gt = poses[:, cfg.n_loss_skip:, None].double()
+    pos = (pp[..., :3] - gt[..., :3]).norm(dim=-1).mean().item()
+    q1 = pp[..., 3:] / pp[..., 3:].norm(dim=-1, keepdim=True)
+    q2 = (gt[..., 3:] / gt[..., 3:].norm(dim=-1, keepdim=True)).expand_as(q1)
+    w1, v1, w2, v2 = q1[..., :1], q1[..., 1:], q2[..., :1], -q2[..., 1:]
+    vec = w1 * v2 + w2 * v1 + torch.cross(v1, v2, dim=-1)
+    ori = (2 * torch.asin(vec.norm(dim=-1).clamp(max=1))).mean().item()
+    assert abs(float(m_test['pose_pos_err']) - pos) < 1e-4 * max(1.0, pos) and abs(float(m_test['pose_ori_err']) - ori) < 1e-4
+    # training-only randomness is off in test_step
+    cfg2, _, tokens2, poses2, tr2 = _setup(True, dev, dropout=0.0)
+    tr2.cfg.dropout, tr2.cfg.random_pose_multiplier = 0.3, 2.0
+    a, b = tr2.test_step(poses2, tokens2), tr2.test_step(poses2, tokens2)
+    assert float(a['loss']) == float(b['loss']) == float(m_test['loss'])
+    assert float(tr2.train_step(poses2, tokens2, reduce_gradients=False, apply_update=False)['loss']) != float(a['loss'])
+    # PSNR and predict_step: the steps only use the codebook model's duck-typed ``decode_code`` (migt.py:521-526,536-540); a table
+    # look-up stands in for it here (the real decoders are covered by the VQGAN tests)
+    class Codebook:
+        table = (_rand((cfg.n_embeddings, 3), 77) * 0.8).to(dev)
+
+        def decode_code(self, codes):
+            assert codes.dtype == torch.int64 and codes.dim() == 3
+            return self.table[codes]                                   # [N, t, t, 3] "images" in [-1, 1]
+    vq = Codebook()
+    m3 = tr.test_step(poses, tokens, codebook_model=vq)
+    B, S = tokens.shape[:2]
+    gen_last = tr.train_step(poses, tokens, _forward_only=True)[1]['predicted_tokens'][:, -1].reshape(B, 4, 4)
+    a, b = (vq.table[gen_last] / 2 + 0.5).clamp(0, 1), (vq.table[tokens[:, -1].to(dev)] / 2 + 0.5).clamp(0, 1)
+    want = (10 * torch.log10(1.0 / ((a - b) ** 2).reshape(B, -1).mean(1).clamp_min(1e-12))).mean()
+    assert abs(float(m3['psnr']) - float(want)) < 1e-4
+    out = tr.predict_step(poses, tokens, vq)
+    assert tuple(out['latent_code'].shape) == (B, S, 4, 4) and int(out['latent_code'].max()) < cfg.n_embeddings
+    assert tuple(out['decoded_image'].shape) == (B * S, 4, 4, 3) == tuple(out['ground_truth_image'].shape)
+    assert torch.equal(out['ground_truth_image'], vq.table[tokens.reshape(-1, 4, 4).to(dev)])
+    assert torch.equal(out['decoded_image'], vq.table[out['latent_code'].reshape(-1, 4, 4)])

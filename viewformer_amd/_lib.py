@@ -132,7 +132,8 @@ EXPORTS = {
     'vf_softmax_mask_bwd_f32': (c_int, [P, P, c_int64, c_int, c_int, c_int, c_float, P]),
     'vf_softmax_ce_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_float, P]),
     'vf_pose_mse_f32': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, P]),
-    'vf_embed_bwd_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'vf_embed_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'vf_embed_bwd_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P, P]),
     'vf_dense_small_k_bwd_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
     'vf_adamw_f32': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     'vf_adamw_flat_f32': (c_int, [P, P, P, P, c_int64, P, c_int, c_float, c_float, c_float, c_float, c_float, P]),

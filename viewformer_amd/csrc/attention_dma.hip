@@ -298,6 +298,238 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     }
 }
 
+
+// ---- 8-wave form: one workgroup = 8 consecutive query views = ALL of a 6-context-view scene (T = 512 in the fused twin pass) -------------
+// The 4-wave kernel above covers a (scene, head) with two workgroups and the second one re-reads key tiles 0-3 (FETCH_SIZE 393 MB for 302 MB
+// of q / k / v, L2 hit rate 18 %: profiles/r2_new_kernels_pmc.txt).  Here every K / V tile of a (scene, head) is fetched ONCE per 8 query
+// views: 8 waves (wave = view), an 8-slot ring (128 KB: one workgroup per CU, the same 8 waves per CU as two 4-wave workgroups), the
+// waves' Q rows parked in slots 4-7 until they are in registers, tiles 0-3 in flight from the first instruction and 4-7 right behind the
+// Q barrier — with <= 8 key views (the bench shape) no slot is ever recycled.  Per-wave arithmetic (tile order, MFMA sequence, softmax)
+// is the 4-wave kernel's: results are bit-identical.  Each wave moves ONE 1 KB piece of K and one of V per tile.
+// MEASURED (round 3, bench shape 128 scenes x 12 heads x 512 tokens): 176.9 us against the 4-wave kernel's 131.9 us.  The traffic goes
+// down as intended, the time goes up: with one barrier per key tile the workgroup runs in lockstep, and under the block-causal mask wave w
+// only has work for tiles <= w — 36 of the 64 (wave, tile) slots of a workgroup are busy (56 %), where two co-resident 4-wave workgroups
+// (62 % and 81 % busy, not synchronised with each other) fill each other's gaps.  The tile step is bound by the waves' own softmax + MFMA
+// work (~3.7 us), not by the DMA.  Kept opt-in as the record of the experiment; what would help is equal work per wave (32 queries of view
+// w and 32 of view 7 - w per wave, no per-tile barrier once the ring is resident), not fewer bytes.
+constexpr int NW8 = 8, RING8 = 8, QT8 = NW8 * KT;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_lgkm0() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void attn_dma8_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                           const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq, int ldk,
+                                                           int ldv, int ldo, float scale, int twin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING8 x (K image | V image)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qblk = (int)blockIdx.z;
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = qblk * QT8;
+    const int qw0 = q0 + wave * 64;
+    const int nviews = T / KT;
+    const int qview = qw0 / KT;
+    const bool active = qview < nviews;
+
+    const unsigned char* qb8 = reinterpret_cast<const unsigned char*>(q + b * (size_t)T * ldq + h * DH);
+    const unsigned char* kb8 = reinterpret_cast<const unsigned char*>(k + b * (size_t)T * ldk + h * DH);
+    const unsigned char* vb8 = reinterpret_cast<const unsigned char*>(v + b * (size_t)T * ldv + h * DH);
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(qb8), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(kb8), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(vb8), 0, 0x7fffffff, 0x00020000);
+
+    const int Vc = twin >= 0 ? twin : 0x3fffffff;
+    const int Sv = twin <= -2 ? -twin : 0;
+    auto visible = [&](int qv, int kv) {
+        if (Sv > 0) {
+            const int qs = qv / Sv, qi = qv - qs * Sv;
+            const int ks = kv / Sv, ki = kv - ks * Sv;
+            return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+        }
+        return kv == qv || min(kv, Vc) < min(qv, Vc);
+    };
+    const int ntiles = min(nviews, q0 / KT + NW8);
+
+    const int pr = lane >> 3, pc = lane & 7;
+    auto issue_tile = [&](int t) {                                   // this wave's two 1 KB pieces of tile t: K rows 8 wave .. + 7, V piece `wave`
+        unsigned char* dst = smem + (t % RING8) * TILE_BYTES;
+        const int r = wave * 8 + pr;
+        bufds16(k_rs, dst + wave * 1024, (unsigned)(r * ldk * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), (unsigned)(t * KT * ldk * 2));
+        const int key = (wave & 3) * 16 + (lane >> 2);
+        bufds16(v_rs, dst + K_BYTES + wave * 1024, (unsigned)(key * ldv * 2 + (wave >> 2) * 64 + (lane & 3) * 16), (unsigned)(t * KT * ldv * 2));
+    };
+    // Q: the wave's 64 rows -> its private 8 KB of slots 4-7 (same swizzled row image as K)
+    unsigned char* Qs = smem + 4 * TILE_BYTES + wave * K_BYTES;
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi) {
+        const int r = pi * 8 + pr;
+        const int row = min(qw0 + r, T - 1);
+        bufds16(q_rs, Qs + pi * 1024, (unsigned)(row * ldq * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), 0u);
+    }
+    const int first = min(ntiles, 4);
+    for (int t = 0; t < first; ++t) issue_tile(t);
+    // Q has landed once at most the 2 * first tile loads issued behind it are outstanding (vmcnt retires in issue order)
+    if (first == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (first == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (first == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    const unsigned swz = (unsigned)((l31 >> 1) & 7);
+    bf16x8 qb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qb[u][ks] = *reinterpret_cast<const bf16x8*>(Qs + (u * 32 + l31) * 128 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave holds its Q: slots 4-7 are free
+    const int issued0 = min(ntiles, RING8);
+    for (int t = first; t < issued0; ++t) issue_tile(t);
+
+    f32x16 ot[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[u][d][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = scale * LOG2E;
+    const unsigned k_off = (unsigned)(l31 * 128);
+    const unsigned v_off = (unsigned)(K_BYTES + (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // tiles issued so far: 0 .. issued0 - 1 before the loop, then tile j + RING8 - 1 at iteration j >= 1: this wave's two pieces of tile
+        // kt have landed once at most 2 loads per LATER tile are outstanding
+        const int last_issued = min(ntiles - 1, kt == 0 ? issued0 - 1 : max(issued0 - 1, kt + RING8 - 2));
+        switch (last_issued - kt) {
+            case 0: wait_vmcnt_lgkm0<0>(); break;
+            case 1: wait_vmcnt_lgkm0<2>(); break;
+            case 2: wait_vmcnt_lgkm0<4>(); break;
+            case 3: wait_vmcnt_lgkm0<6>(); break;
+            case 4: wait_vmcnt_lgkm0<8>(); break;
+            case 5: wait_vmcnt_lgkm0<10>(); break;
+            case 6: wait_vmcnt_lgkm0<12>(); break;
+            default: wait_vmcnt_lgkm0<14>(); break;
+        }
+        __builtin_amdgcn_s_barrier();                                // tile kt is complete; every wave is done with tile kt - 1
+        if (kt >= 1 && kt + RING8 - 1 < ntiles) issue_tile(kt + RING8 - 1);      // into the slot of tile kt - 1 (more than 8 key views only)
+        if (!active || !visible(qview, kt)) continue;
+        const unsigned char* tile = smem + (kt % RING8) * TILE_BYTES;
+
+        f32x16 st[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][t2][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + k_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[u][ks], st[u][t2], 0, 0, 0);
+            }
+
+        bf16x8 pb[2][2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[u][t2][r]), st[u][t2][r + 1]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx * scale);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * LOG2E);
+            const float mc = m_new * LOG2E;
+            float psum = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t2][ks2 * 8 + e], c2, -mc));
+                        psum += p;
+                        pk[e] = (__bf16)p;
+                    }
+                    pb[u][t2][ks2] = pk;
+                }
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[u][d][r] *= alpha;
+            }
+        }
+
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned char* vp = tile + v_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64;
+                    const bf16x4 v0 = tr_read(vp);
+                    const bf16x4 v1 = tr_read(vp + 8 * 64);
+                    bf16x8 va;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = v0[e]; va[4 + e] = v1[e]; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) ot[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[u][t2][ks2], ot[u][d], 0, 0, 0);
+                }
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+    if (!active) return;
+    unsigned char* Os = smem + wave * K_BYTES;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        const int row = u * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (__bf16)(ot[u][d][4 * j + e] / l_tot);
+                *reinterpret_cast<bf16x4*>(Os + row * 128 + ((((unsigned)(d * 4 + j)) ^ swz) << 4) + 8 * half) = o4;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __bf16* __restrict__ ob = out + (b * (size_t)T + qw0) * ldo + h * DH;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + pr;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(Os + row * 128 + pc * 16);
+        const int c = pc ^ ((row >> 1) & 7);
+        *reinterpret_cast<f32x4*>(ob + (size_t)row * ldo + c * 8) = val;
+    }
+}
+
 }  // namespace
 
 // Launcher used by vf_attn_blockcausal_bf16_v2 (attention_lp.hip).  VF_ERR_UNSUPPORTED when the call does not qualify (the caller then
@@ -312,6 +544,22 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
+    }
+    // the 8-wave form (every K / V tile fetched once per 8 query views) is OPT-IN (VF_ATTN_DMA8=1): measured SLOWER at the bench shape — 176.9
+    // vs 131.9 us per launch inside the step (gpurun_out r3c) — see the note above attn_dma8_kernel
+    const char* e8 = getenv("VF_ATTN_DMA8");
+    if (T > QT && e8 && e8[0] == '1') {
+        static unsigned long long attr8_devs = 0;
+        if (vf_attr_needed(&attr8_devs)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING8 * TILE_BYTES);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(&attr8_devs);
+        }
+        dim3 grid8((unsigned)H, (unsigned)B, (unsigned)((T + QT8 - 1) / QT8));
+        hipLaunchKernelGGL(attn_dma8_kernel, grid8, dim3(512), (size_t)RING8 * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk,
+                           ldv, ldo, scale, twin_view);
+        return vf_last_status();
     }
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_dma_kernel, grid, dim3(256), (size_t)RING * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),

@@ -257,25 +257,60 @@ __global__ void pose_loss_kernel(const float* __restrict__ raw, const float* __r
     ori[r] = o / 4.f;
 }
 
-// ------------------------------------------------------------------ embedding backward
-// dwte[ids[tok]] += dh[tok] (float atomics: rows collide), dadd[bs] = sum_l dh, dwpe[l] += sum_bs dh (atomics)
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh, const int* __restrict__ ids,
-                                                        float* __restrict__ dwte, float* __restrict__ dwpe,
-                                                        float* __restrict__ dadd, long long BS, int L, int d, int vocab) {
-    // one block per (bs): threads stride over d; loop over l
-    const long long bs = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const long long tok = bs * L + l;
-            const float g = dh[tok * d + c];
-            acc += g;
-            int id = ids[tok];
-            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-            atomicAdd(dwte + (long long)id * d + c, g);
-            atomicAdd(dwpe + (long long)l * d + c, g);
+// ------------------------------------------------------------------ embedding backward (deterministic: no float atomics)
+// dwte[id] += sum over the tokens with that id of dh[tok]; dwpe[l] += sum_bs dh[bs][l]; dadd[bs] = sum_l dh[bs][l].
+// The first version scattered with float atomicAdd: a third of the training tokens are the MASK id and every position row collects
+// B x V terms, so the order of those additions — and the low bits of two whole gradient tensors — changed from run to run (found by
+// tests/test_hip_train_full.py; every other reduction of the step was already fixed-order).  Now:
+//   embed_bwd_wte_partial: block (id, split s) walks the token range of split s in ascending order and sums its matches -> partial[s][id]
+//   embed_bwd_wte_sum:     dwte[id] += partial[0][id] + partial[1][id] + ... in that order
+//   embed_bwd_pos:         thread (l, c) walks bs ascending; thread (bs, c) walks l ascending
+constexpr int EMB_SPLITS = 16;
+__global__ __launch_bounds__(256) void embed_bwd_wte_partial_kernel(const float* __restrict__ dh, const int* __restrict__ ids,
+                                                                    float* __restrict__ partial, long long ntok, int d, int vocab) {
+    const int id = blockIdx.x, sp = blockIdx.y;
+    const long long per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
+    const long long t0 = sp * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+    float acc[8];                                                     // d <= 2048
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (long long tok = t0; tok < t1; ++tok) {
+        int v = ids[tok];                                             // (uniform across the block: a scalar load)
+        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        if (v != id) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = threadIdx.x + q * 256;
+            if (c < d) acc[q] += dh[tok * d + c];
         }
-        dadd[bs * d + c] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = threadIdx.x + q * 256;
+        if (c < d) partial[((long long)sp * vocab + id) * d + c] = acc[q];
+    }
+}
+__global__ void embed_bwd_wte_sum_kernel(const float* __restrict__ partial, float* __restrict__ dwte, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = partial[i];
+#pragma unroll
+        for (int sp = 1; sp < EMB_SPLITS; ++sp) s += partial[sp * n + i];
+        dwte[i] += s;
+    }
+}
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dh, float* __restrict__ dwpe, float* __restrict__ dadd, long long BS,
+                                     int L, int d) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long n_pos = (long long)L * d, n_add = BS * d;
+    if (i < n_pos) {                                                  // dwpe[l][c]
+        float s = 0.f;
+        for (long long bs = 0; bs < BS; ++bs) s += dh[bs * n_pos + i];
+        dwpe[i] += s;
+    } else if (i < n_pos + n_add) {                                   // dadd[bs][c]
+        const long long j = i - n_pos, bs = j / d, c = j - bs * d;
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += dh[(bs * L + l) * d + c];
+        dadd[j] = s;
     }
 }
 
@@ -496,11 +531,23 @@ int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const
     return vf_last_status();
 }
 
+size_t vf_embed_bwd_workspace_bytes(int d, int vocab) {
+    if (d <= 0 || vocab <= 0) return 0;
+    return (size_t)EMB_SPLITS * vocab * d * sizeof(float);
+}
+
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
-                     int vocab, void* stream) {
-    if (!dh || !ids || !dwte || !dwpe || !dadd || BS <= 0 || L <= 0 || d <= 0 || vocab <= 0) return VF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)BS), dim3(256), 0, (hipStream_t)stream, dh, ids, dwte, dwpe, dadd,
-                       (long long)BS, L, d, vocab);
+                     int vocab, void* workspace, void* stream) {
+    if (!dh || !ids || !dwte || !dwpe || !dadd || !workspace || BS <= 0 || L <= 0 || d <= 0 || vocab <= 0) return VF_ERR_BAD_ARG;
+    if (d > 2048) return VF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(embed_bwd_wte_partial_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), 0, s, dh, ids, partial,
+                       (long long)BS * L, d, vocab);
+    const long long n = (long long)vocab * d;
+    hipLaunchKernelGGL(embed_bwd_wte_sum_kernel, dim3(grid1(n, 256, 4096)), dim3(256), 0, s, partial, dwte, n);
+    const long long m = (long long)L * d + (long long)BS * d;
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, dh, dwpe, dadd, (long long)BS, L, d);
     return vf_last_status();
 }
 

@@ -300,9 +300,11 @@ class MIGTTrainer:
         return dqkv
 
     # ------------------------------------------------------------------ the step
-    def train_step(self, poses, tokens, reduce_gradients: bool = True, apply_update: bool = True):
+    def train_step(self, poses, tokens, reduce_gradients: bool = True, apply_update: bool = True, _forward_only: bool = False):
         """poses [b,S,7] float32 (already through process_batch: relative + normalised), tokens [b,S,t,t] int.
-        Returns the metrics dict of MIGT.train_step (loss, ce_loss, acc, pose_* ...)."""
+        Returns the metrics dict of MIGT.train_step (loss, ce_loss, acc, pose_* ...).  ``_forward_only`` (test_step / predict_step):
+        the same multi-stream graph with ``training=False`` — no dropout, no random pose multiplier — up to the losses; returns
+        ``(metrics, outputs)``."""
         m, c, dev = self.model, self.cfg, self.dev
         poses = poses.to(dev)
         tokens = tokens.to(dev)
@@ -321,13 +323,14 @@ class MIGTTrainer:
         if S < 2:
             raise ValueError('train_step needs sequences of at least 2 views (the STREAMS attention mask encodes the stream '
                              'length as -S <= -2; a 1-view sequence has nothing to condition on)')
-        self.flat_g.zero_()
+        if not _forward_only:
+            self.flat_g.zero_()
 
         # ---- forward with saved activations --------------------------------------------------------------
         seed = self.step_seed(self.step_count)
         rmul = None
         pin = geometry.pose_model_input(poses, c.pose_multiplier)
-        if c.random_pose_multiplier != 1:                                            # migt.py:350-354: rpm ** U(-1, 1) per scene
+        if c.random_pose_multiplier != 1 and not _forward_only:                      # migt.py:350-354: rpm ** U(-1, 1) per scene (training only)
             rmul = self.random_pose_factors(B, seed).to(dev)
             pin = torch.cat([pin[..., :3] * rmul.view(B, 1, 1), pin[..., 3:]], -1)
         pin = pin.reshape(B * S, 7).contiguous()
@@ -344,7 +347,7 @@ class MIGTTrainer:
         ids32 = torch.cat(ids_streams, 1).reshape(M).to(torch.int32).contiguous()
         add = torch.cat(add_streams, 1).contiguous().view(B * V, d)
         h = ops.embed_sum(ids32, m._wte, m._wpe, add, B * V, L, d, nE + 2)
-        rate = float(c.dropout)
+        rate = 0.0 if _forward_only else float(c.dropout)                            # Dropout layers are inert with training=False
         if rate:
             T.dropout_add(h, rate, seed, SITE_EMBED, out=h)                          # self.drop, migt.py:403
         saved = []
@@ -368,7 +371,8 @@ class MIGTTrainer:
                 h_out = T.dropout_add(y, rate, seed, site_mlp(i), res=h_mid, out=y)
             else:
                 h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
-            saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
+            if not _forward_only:
+                saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
             h = h_out
         hf = ops.layernorm(h, *m._ln['ln_f'], M, d).view(B, NS, S, L, d)
 
@@ -418,6 +422,9 @@ class MIGTTrainer:
                 metrics['pose_loss'] = (pos_b + ori_b).mean()
             metrics.update(pose_pos_loss=pos_b.mean(), pose_ori_loss=ori_b.mean(), localization_weight=loc_w)
         metrics['loss'] = loss_b.mean()                                              # reduce_mean, migt.py:476
+        if _forward_only:
+            return metrics, dict(logits=logits.view(B, S, L, nE), predicted_tokens=pred,
+                                 pose_head_raw=raw.view(B, S, L, 7) if use_loc else None)
 
         # ---- backward -------------------------------------------------------------------------------------
         dhf = torch.zeros((B, NS, S, L, d), dtype=torch.float32, device=dev)
@@ -516,6 +523,41 @@ class MIGTTrainer:
             return None
         self._allreduce_events[1].synchronize()
         return self._allreduce_events[0].elapsed_time(self._allreduce_events[1])
+
+    # ------------------------------------------------------------------ evaluation steps (Keras Model.evaluate / predict)
+    def test_step(self, poses, tokens, codebook_model=None):
+        """``MIGT.test_step`` (migt.py:507-527): the compute_losses graph with ``training=False``, the same loss / accuracy metrics as the
+        training step, the pose-head errors, and — given the codebook model — the PSNR of the image decoded from the generated tokens of
+        the LAST view against the image decoded from its ground-truth tokens (:521-526)."""
+        metrics, out = self.train_step(poses, tokens, _forward_only=True)
+        c, skip = self.cfg, self.cfg.n_loss_skip
+        if out['pose_head_raw'] is not None:                                         # :514-519 on pose_prediction[:, n_loss_skip:]
+            B, S = tokens.shape[:2]
+            pp = geometry.pose_head_postprocess(out['pose_head_raw'], c.pose_multiplier)[:, skip:]
+            gt = poses.to(self.dev).view(B, S, 1, 7)[:, skip:]
+            metrics['pose_pos_err'] = (pp[..., :3] - gt[..., :3]).norm(dim=-1).mean()            # CameraPositionError, utils/metrics.py:90-95
+            q1 = geometry.quaternion_normalize(pp[..., 3:])                                     # CameraOrientationError, :98-110: the sine
+            q2 = geometry.quaternion_normalize(gt[..., 3:].expand_as(pp[..., 3:]))              # form, stable near zero rotation
+            diff = geometry.quaternion_multiply(q1, geometry.quaternion_conjugate(q2))
+            metrics['pose_ori_err'] = (2.0 * torch.asin(diff[..., 1:].norm(dim=-1).clamp(max=1.0))).mean()
+        if codebook_model is not None:
+            t = c.token_image_size
+            gen = out['predicted_tokens'][:, -1].reshape(-1, t, t)
+            img = [(codebook_model.decode_code(x.to(torch.int64)).float() / 2 + 0.5).clamp(0, 1) for x in (gen, tokens[:, -1].to(self.dev))]
+            mse = ((img[0] - img[1]) ** 2).reshape(img[0].shape[0], -1).mean(1)
+            metrics['psnr'] = (10.0 * torch.log10(1.0 / mse.clamp_min(1e-12))).mean()    # tf.image.psnr(max_val=1), batch mean
+        return metrics
+
+    def predict_step(self, poses, tokens, codebook_model):
+        """``MIGT.predict_step`` (migt.py:532-541): arg-max tokens of every view from the masked stream (special ids -> 0), decoded next
+        to the decoded ground-truth tokens."""
+        _, out = self.train_step(poses, tokens, _forward_only=True)
+        t, nE = self.cfg.token_image_size, self.cfg.n_embeddings
+        gen = out['predicted_tokens'].reshape(-1, tokens.shape[1], t, t)
+        gen = torch.where(gen < nE, gen, torch.zeros_like(gen))
+        dec = codebook_model.decode_code(gen.reshape(-1, t, t).to(torch.int64))
+        gt = codebook_model.decode_code(tokens.to(self.dev).reshape(-1, t, t).to(torch.int64))
+        return dict(decoded_image=dec, latent_code=gen, ground_truth_image=gt)
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1

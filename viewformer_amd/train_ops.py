@@ -95,9 +95,11 @@ def pose_mse(raw, gt, row_weight, rows, L, position_multiplier, w_ori=None, xyz_
 
 
 def embed_bwd(dh, ids_i32, dwte, dwpe, BS, L, d, vocab):
+    lib = _lib.load()
     dadd = torch.empty((BS, d), dtype=torch.float32, device=dh.device)
-    check(_lib.load().vf_embed_bwd_f32(_p(_f32(dh)), _p(_chk(ids_i32, torch.int32)), _p(_f32(dwte)), _p(_f32(dwpe)), _p(dadd), BS, L,
-                                       d, vocab, _stream()), 'vf_embed_bwd_f32')
+    ws = torch.empty(int(lib.vf_embed_bwd_workspace_bytes(d, vocab)) // 4, dtype=torch.float32, device=dh.device)
+    check(lib.vf_embed_bwd_f32(_p(_f32(dh)), _p(_chk(ids_i32, torch.int32)), _p(_f32(dwte)), _p(_f32(dwpe)), _p(dadd), BS, L,
+                               d, vocab, _p(ws), _stream()), 'vf_embed_bwd_f32')
     return dadd
 
 
