@@ -397,6 +397,18 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo,
                     int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
                     uint32_t drop_site, void* stream);
+/* bf16 arm of the training step's attention (csrc/attention_dma.hip, attention_train_bf16.hip): bf16 q / k / v / out / dout in HBM
+ * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views, no attention dropout — VF_ERR_UNSUPPORTED
+ * otherwise (callers then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the
+ * per-query log-sum-exp; backward = bf16-MFMA flash kernels (P and dS rounded to bf16 as operands, fp32 sums).  Same masks
+ * (twin_view) and the same no-scale convention as the f32 forms; autograd of branching_attention.py:5-18,82-126 under
+ * mixed_float16 (migt.py:464-505 with --fp16). */
+int vf_attn_blockcausal_bf16_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int T, int L,
+                                 int ldq, int ldk, int ldv, int ldo, float scale, int twin_view, void* stream);
+int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
+int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, float* dq, float* dk,
+                     float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale,
+                     int twin_view, void* stream);
 /* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403): out = keep ? x/(1-rate) : 0 [+ res],
  * keep = vf_dropout_hash(seed, site, flat index) >= floor(rate * 2^32); applying it to a gradient gives the backward */
 int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
@@ -405,7 +417,11 @@ int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, 
 /* dst[c][r] = src[r][c], `batch` matrices with strides (floats) */
 int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
                      int64_t bs_src, int64_t bs_dst, void* stream);
-/* out[n] (+)= sum_m x[m][n]  (bias gradients; deterministic two-stage)  ws: vf_colsum_workspace_bytes(N) */
+/* the same from a bf16 source (a saved bf16 activation of the bf16 training arm), widened exactly */
+int vf_transpose_bf16_f32(const void* src_bf16, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
+                          int64_t bs_src, int64_t bs_dst, void* stream);
+/* out[n] (+)= sum_m x[m][n]  (bias gradients; deterministic: fixed-order partial sums, an integer ticket only picks the block that
+ * folds them)  ws: vf_colsum_workspace_bytes(N) bytes whose first 1024 must be ZERO before the first call (every call leaves them zero) */
 size_t vf_colsum_workspace_bytes(int N);
 int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream);
 /* LayerNormalization backward (migt.py:225,227,292): dx, and dgamma/dbeta (+)= */
@@ -414,6 +430,8 @@ int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, fl
                          int64_t rows, int d, float eps, int accumulate, void* ws, void* stream);
 /* exact-erf GELU (tf.nn.gelu, migt.py:13,70) forward on a saved pre-activation, and its backward */
 int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream);
+/* the same value rounded to bf16 on the way out (the bf16 training arm saves the MLP hidden as its next GEMM reads it) */
+int vf_gelu_bf16out_f32(const float* u, void* f_bf16, int64_t n, void* stream);
 int vf_gelu_bwd_f32(const float* u, const float* df, float* du, int64_t n, void* stream);
 /* materialised attention probabilities for the backward pass: s[b][q][k] -> softmax(s*scale masked with -1e4) in
  * place (branching_attention.py:5-18,101-117; mask_spec as vf_attn_blockcausal_f32's twin_view), and

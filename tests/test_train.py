@@ -507,7 +507,7 @@ def test_test_step_and_predict_step(dev):
     ori = (2 * torch.asin(vec.norm(dim=-1).clamp(max=1))).mean().item()
     assert abs(float(m_test['pose_pos_err']) - pos) < 1e-4 * max(1.0, pos) and abs(float(m_test['pose_ori_err']) - ori) < 1e-4
     # training-only randomness is off in test_step
-    cfg2, _, tokens2, poses2, tr2 = _setup(True, dev, dropout=0.0)
+    cfg2, _, tokens2, poses2, tr2 = _setup(True, dev)
     tr2.cfg.dropout, tr2.cfg.random_pose_multiplier = 0.3, 2.0
     a, b = tr2.test_step(poses2, tokens2), tr2.test_step(poses2, tokens2)
     assert float(a['loss']) == float(b['loss']) == float(m_test['loss'])
@@ -532,3 +532,93 @@ def test_test_step_and_predict_step(dev):
     assert tuple(out['decoded_image'].shape) == (B * S, 4, 4, 3) == tuple(out['ground_truth_image'].shape)
     assert torch.equal(out['ground_truth_image'], vq.table[tokens.reshape(-1, 4, 4).to(dev)])
     assert torch.equal(out['decoded_image'], vq.table[out['latent_code'].reshape(-1, 4, 4)])
+
+
+ATTN_BF16_FWD_TOL, ATTN_BF16_BWD_TOL = 1.5e-2, 3e-2     # max error / max |reference| (bf16 operands incl. P and dS; measured below)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,S,mode', [(2, 2, 4, 'causal'), (1, 3, 8, 'twin'), (2, 2, 3, 'streams'), (1, 2, 10, 'streams'), (1, 1, 1, 'causal'),
+                                        (3, 1, 5, 'twin')])
+def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
+    """the bf16 arm's training attention (csrc/attention_dma.hip with its log-sum-exp output, csrc/attention_train_bf16.hip) against
+    the exact-f32 kernels on the SAME bf16-rounded q / k / v / dO — which tests/test_train.py pins to fp64 autograd of
+    branching_attention.py:5-18,82-126 above.  Every mask mode incl. the training step's 3-stream mask at its real size (S = 10:
+    T = 1920, 30 views), workgroups whose second view does not exist, one-view sequences."""
+    from viewformer_amd import train_ops as T
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    Tn = NS * S * L
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    g = np.random.Generator(np.random.PCG64(17))
+    qkv16 = torch.from_numpy((g.standard_normal((B * Tn, 3 * d)) * 0.4).astype(np.float32)).to(dev).to(torch.bfloat16)
+    do16 = torch.from_numpy(g.standard_normal((B * Tn, d)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    qkv32, do32 = qkv16.float(), do16.float()
+    # reference: exact-f32 kernels on the rounded operands
+    att32 = torch.empty((B * Tn, d), device=dev)
+    lse32 = T.attn_fwd_lse(qkv32[:, d:2 * d], qkv32[:, 2 * d:], qkv32[:, :d], att32, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec)
+    ref = torch.empty((B * Tn, 3 * d), device=dev)
+    T.attn_bwd(qkv32[:, d:2 * d], qkv32[:, 2 * d:], qkv32[:, :d], att32, do32, lse32, ref[:, d:2 * d], ref[:, 2 * d:], ref[:, :d],
+               B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+    # bf16 kernels
+    att16 = torch.full((B * Tn, d), float('nan'), dtype=torch.bfloat16, device=dev)
+    lse16 = T.attn_fwd_lse_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec)
+    e_fwd = ((att16.float() - att32).abs().max() / att32.abs().max()).item()
+    e_lse = (lse16 - lse32).abs().max().item()
+    assert e_fwd < ATTN_BF16_FWD_TOL and e_lse < 2e-3, (e_fwd, e_lse)                  # lse: fp32 softmax over bf16-product scores
+    got = torch.full((B * Tn, 3 * d), float('nan'), device=dev)
+    T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got[:, d:2 * d], got[:, 2 * d:], got[:, :d],
+                    B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+    assert not torch.isnan(got).any()
+    errs = {}
+    for name, sl in (('dv', slice(0, d)), ('dq', slice(d, 2 * d)), ('dk', slice(2 * d, 3 * d))):
+        errs[name] = ((got[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max()).item()
+        assert errs[name] < ATTN_BF16_BWD_TOL, (name, errs)
+    print(f'bf16 training attention {mode} B={B} H={H} S={S}: fwd {e_fwd:.2e} lse {e_lse:.2e} bwd {errs}')
+    # deterministic
+    got2 = torch.empty_like(got)
+    T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got2[:, d:2 * d], got2[:, 2 * d:], got2[:, :d],
+                    B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+    assert torch.equal(got, got2)
+
+
+@pytest.mark.gpu
+def test_bf16_attention_is_what_the_bf16_training_arm_runs_at_full_width(dev):
+    """head dim 64, 64-token views, no dropout: the trainer takes the bf16 attention kernels; with attention_arith='f32' the exact-f32
+    ones — gradients of the two agree within the bf16 arm's own tolerance"""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    cfg = MIGTConfig(n_layer=2, d_model=256, n_head=4, sequence_size=4, n_loss_skip=1, localization_weight='2', pose_multiplier=0.2,
+                     dropout=0.0, learning_rate=1e-3, weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=4, std=0.05)
+    g = np.random.Generator(np.random.PCG64(9))
+    B, S = 2, 4                                                   # M = 2 * 3 * 4 * 64 = 1536 rows
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 5)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    grads = {}
+    for arith in ('bf16', 'f32'):
+        tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev), warmup_steps=4)
+        tr.attention_arith = arith
+        tr.step_count = 3
+        calls = []
+        from viewformer_amd import train_ops as T
+        orig = T.attn_bwd_bf16
+        T.attn_bwd_bf16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+        finally:
+            T.attn_bwd_bf16 = orig
+        assert (len(calls) == cfg.n_layer) == (arith == 'bf16')
+        grads[arith] = tr.flat_g.clone()
+    worst = 0.0
+    for n in tr.names:
+        a, b, _ = tr.slices[n]
+        ref = grads['f32'][a:b]
+        if float(ref.abs().max()) > 0:
+            worst = max(worst, ((grads['bf16'][a:b] - ref).abs().max() / ref.abs().max()).item())
+    print('bf16 vs f32 attention inside the bf16 training arm: worst per-tensor gradient difference', worst)
+    assert worst < BF16_GRAD_TOL, worst

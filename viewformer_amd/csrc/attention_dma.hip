@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 
 __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                           const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq, int ldk,
-                                                          int ldv, int ldo, float scale, int twin) {
+                                                          int ldv, int ldo, float scale, int twin, float* __restrict__ lse_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING x (K image | V image)
 
     const int tid = threadIdx.x;
@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     for (int u = 0; u < 2; ++u) {
         const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
         const int row = u * 32 + l31;
+        // the training step's flash backward re-materialises P = exp(S scale - lse) from this per-query log-sum-exp
+        if (lse_out && half == 0) lse_out[((size_t)b * H + h) * T + qw0 + row] = m_run[u] + logf(l_tot);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(512, 1) void attn_dma8_kernel(const __bf16* __restr
 // Launcher used by vf_attn_blockcausal_bf16_v2 (attention_lp.hip).  VF_ERR_UNSUPPORTED when the call does not qualify (the caller then
 // takes the register-staged kernel): bf16 q / k / v / out, 64-token views, T a multiple of 64, 16-byte aligned rows.
 int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                       float scale, int twin_view, hipStream_t stream) {
+                       float scale, int twin_view, hipStream_t stream, float* lse_out) {
     if (L != KT || T % KT != 0 || ((ldq | ldk | ldv | ldo) & 7)) return VF_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return VF_ERR_UNSUPPORTED;
     if ((size_t)T * (size_t)(ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv)) * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit offsets per (scene, head)
@@ -548,7 +550,7 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     // the 8-wave form (every K / V tile fetched once per 8 query views) is OPT-IN (VF_ATTN_DMA8=1): measured SLOWER at the bench shape — 176.9
     // vs 131.9 us per launch inside the step (gpurun_out r3c) — see the note above attn_dma8_kernel
     const char* e8 = getenv("VF_ATTN_DMA8");
-    if (T > QT && e8 && e8[0] == '1') {
+    if (T > QT && e8 && e8[0] == '1' && !lse_out) {
         static unsigned long long attr8_devs = 0;
         if (vf_attr_needed(&attr8_devs)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING8 * TILE_BYTES);
@@ -564,6 +566,15 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_dma_kernel, grid, dim3(256), (size_t)RING * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
                        reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk, ldv,
-                       ldo, scale, twin_view);
+                       ldo, scale, twin_view, lse_out);
     return vf_last_status();
+}
+
+// forward of the bf16 training arm: the same kernel, also writing the per-query log-sum-exp [B][H][T] (fp32) the flash backward
+// (attention_train_bf16.hip) needs.  VF_ERR_UNSUPPORTED for shapes the DMA kernel does not take (the trainer then uses the f32 kernels).
+extern "C" int vf_attn_blockcausal_bf16_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int T, int L,
+                                            int ldq, int ldk, int ldv, int ldo, float scale, int twin_view, void* stream) {
+    if (!q || !k || !v || !out || !lse || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
+    if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
+    return vf_attn_dma_launch(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale, twin_view, (hipStream_t)stream, lse);
 }

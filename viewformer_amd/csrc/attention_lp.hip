@@ -388,7 +388,7 @@ int launch_lp(const void* q, const void* k, const void* v, int in_bf16, void* ou
 }  // namespace
 
 int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                       float scale, int twin_view, hipStream_t stream);        // attention_dma.hip: bf16 in / out, 64-token views, LDS-DMA ring
+                       float scale, int twin_view, hipStream_t stream, float* lse_out = nullptr);        // attention_dma.hip: bf16 in / out, 64-token views, LDS-DMA ring
 
 extern "C" {
 

@@ -1,0 +1,438 @@
+// Backward of the block-causal / streams attention on the bf16 matrix pipe, for the bf16 arm of the training step, gfx950.
+//
+// Flash-style like attention_bwd_f32.hip — P is re-materialised tile by tile from q, k and the forward's per-query log-sum-exp, masked
+// tiles are skipped, no atomics (a query-major dQ kernel and a key-major dK / dV kernel) — but on v_mfma_f32_32x32x16_bf16 with bf16
+// q / k / v / dO in HBM (the c_attn GEMM and the c_proj dX GEMM write them as bf16) and every streamed tile moved HBM -> LDS by
+// LDS-DMA, in the layouts of attention_dma.hip:
+//   * "rows" image of a 64 x 64 tile: 128-byte rows, 16-byte chunk index XORed with bits 1..3 of the row -> conflict-free ds_read_b128
+//     A fragments (rows of the streamed operand, k = features);
+//   * "tr" image: [feature half][row][32 features], read with ds_read_b64_tr_b16 -> the TRANSPOSED A fragment (feature rows, k = the
+//     streamed rows) straight from the row-major tile.
+// Both kernels keep the owner's operands (dQ kernel: Q and dO rows of its 32 queries; dK/dV kernel: K and V rows of its 32 keys) in
+// registers as B fragments and compute the tile products with the owner in the MFMA column = lane, so P / dS sit in registers in the
+// B-operand layout of the accumulating MFMA (the k order of those products is the accumulator's row order, which is the order the
+// transposed reads deliver: attention_dma.hip's P.V step).
+//   dQ kernel, per (wave = 32 queries, visible key tile):  S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T (dP^T - D) scale, dQ^T += K^T.dS^T   (24 MFMAs)
+//   dKV kernel, per (wave = 32 keys, visible query tile):  S = Q.K^T, dP = dO.V^T, dV^T += dO^T.P, dK^T += Q^T.dS                        (32 MFMAs)
+// with P = exp(S scale - lse), D = rowsum(dO * O) (vf_attn_bwd_prep_bf16).  P and dS are rounded to bf16 as MFMA operands; sums, the
+// exponent and D stay fp32; dQ / dK / dV are written as fp32 rows (transposed through LDS, whole 256-byte rows).
+// 64-token views only (every (wave, tile) pair is entirely visible or entirely masked), T a multiple of 64, no attention dropout: the
+// trainer takes attention_bwd_f32.hip otherwise.  Reference: autograd of compute_attention / compute_causal_block_multiend_attention
+// (viewformer/models/branching_attention.py:5-18,82-126) inside MIGT.train_step (migt.py:464-505) under mixed_float16.
+#include "vf_common.h"
+#include "../../include/vf_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DH = 64, KT = 64;
+constexpr int IMG = KT * DH * 2;             // one 64 x 64 bf16 image: 8 KB
+constexpr int OT = 128;                      // owner rows per workgroup: 4 waves x 32
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(p)));
+    return __builtin_bit_cast(bf16x4, r);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {             // 8 consecutive k of the accumulator order: two 4-row groups
+    const bf16x4 v0 = tr_read(p), v1 = tr_read(p + 8 * 64);
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = v0[e]; a[4 + e] = v1[e]; }
+    return a;
+}
+
+struct Vis {
+    int Vc, Sv;
+    __device__ __forceinline__ bool operator()(int qv, int kv) const {
+        if (Sv > 0) {
+            const int qs = qv / Sv, qi = qv - qs * Sv;
+            const int ks = kv / Sv, ki = kv - ks * Sv;
+            return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+        }
+        return kv == qv || min(kv, Vc) < min(qv, Vc);
+    }
+};
+__device__ __forceinline__ Vis make_vis(int twin) { return Vis{twin >= 0 ? twin : 0x3fffffff, twin <= -2 ? -twin : 0}; }
+
+template <int N>
+__device__ __forceinline__ void wait_loads() {                                   // this wave's loads: at most N outstanding; its LDS reads: done
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+}
+
+// a "rows" piece (8 rows x 128 B, lane -> row lane >> 3, LDS chunk lane & 7 = global chunk ^ ((row >> 1) & 7)) and a "tr" piece
+// (16 rows x 64 B of one feature half, lane -> row lane >> 2, chunk lane & 3) of a 64-row tile starting at row t * 64 of an operand
+// with row stride ld (elements)
+__device__ __forceinline__ void dma_rows_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* img, int pi, int lane, int ld, int t) {
+    const int r = pi * 8 + (lane >> 3), pc = lane & 7;
+    bufds16(rs, img + pi * 1024, (unsigned)(r * ld * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), (unsigned)(t * KT * ld * 2));
+}
+__device__ __forceinline__ void dma_tr_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* img, int pi, int lane, int ld, int t) {
+    const int row = (pi & 3) * 16 + (lane >> 2);
+    bufds16(rs, img + pi * 1024, (unsigned)(row * ld * 2 + (pi >> 2) * 64 + (lane & 3) * 16), (unsigned)(t * KT * ld * 2));
+}
+
+// D[b][h][t] = sum_d dO[t][h*64+d] * O[t][h*64+d] (bf16 in, fp32 out); 8 lanes per (row, head), 8 features each
+__global__ __launch_bounds__(256) void attn_bwd_prep_bf16_kernel(const __bf16* __restrict__ dout, const __bf16* __restrict__ out,
+                                                                 float* __restrict__ D, int B, int H, int T, int lddo, int ldo) {
+    const long long i = (blockIdx.x * 256ll + threadIdx.x) >> 3;          // (b, t, h) flat
+    const int c8 = threadIdx.x & 7;
+    const long long total = (long long)B * T * H;
+    float s = 0.f;
+    long long bt = 0;
+    int h = 0;
+    if (i < total) {
+        h = (int)(i % H);
+        bt = i / H;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dout + bt * lddo + h * DH + c8 * 8);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(out + bt * ldo + h * DH + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)a[e], (float)o[e], s);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (i < total && c8 == 0) {
+        const long long b = bt / T, t = bt - b * T;
+        D[(b * H + h) * T + t] = s;
+    }
+}
+
+// the wave's [feature][owner row] accumulators -> fp32 rows of `dst` (32 rows x 64 features), through the wave's 8 KB of LDS
+__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], unsigned char* Os, float* __restrict__ dst, int ld, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[d][4 * j + e];
+            const int c = 8 * d + 2 * j + half;                                   // 16-byte chunk of the row: features 4 c .. 4 c + 3
+            *reinterpret_cast<f32x4*>(Os + l31 * 256 + ((c ^ (l31 & 15)) << 4)) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), cp = lane & 15;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(Os + row * 256 + (cp << 4));
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * ld + ((cp ^ (row & 15)) << 2)) = val;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dQ
+constexpr int DQ_SLOT = 3 * IMG, DQ_RING = 3, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                                  const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                                  float* __restrict__ dq, int H, int T, int ldq, int ldk, int ldv, int lddo,
+                                                                  int lddq, float scale, int twin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int q0 = blockIdx.z * OT;
+    const int qw0 = q0 + wave * 32;
+    const int nviews = T / KT;
+    const int qview = qw0 / KT;
+    const bool active = qview < nviews;
+    const Vis visible = make_vis(twin);
+
+    const __bf16* kb_ = k + b * (size_t)T * ldk + h * DH;
+    const __bf16* vb_ = v + b * (size_t)T * ldv + h * DH;
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb_), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb_), 0, 0x7fffffff, 0x00020000);
+
+    // owner operands: Q and dO rows of this lane's query as B fragments (k = features 16 ks + 8 half .. + 7)
+    const int qrow = active ? qw0 + l31 : 0;
+    bf16x8 qb[4], dob[4];
+    {
+        const __bf16* qs = q + (b * (size_t)T + qrow) * ldq + h * DH + 8 * half;
+        const __bf16* ds = dout + (b * (size_t)T + qrow) * lddo + h * DH + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qb[ks] = *reinterpret_cast<const bf16x8*>(qs + 16 * ks);
+            dob[ks] = *reinterpret_cast<const bf16x8*>(ds + 16 * ks);
+        }
+    }
+    const size_t stat = ((size_t)b * H + h) * T + qrow;
+    const float lse2 = lse[stat] * LOG2E, D_q = Dv[stat];
+    const float c2 = scale * LOG2E;
+
+    // key tiles some wave of this workgroup (two query views) sees
+    const int va = q0 / KT, vb2 = va + 1;
+    unsigned long long need = 0;
+    for (int kt = 0; kt < nviews; ++kt)
+        if (visible(va, kt) || (vb2 < nviews && visible(vb2, kt))) need |= 1ull << kt;
+    const int n = __builtin_popcountll(need);
+
+    auto issue = [&](int seq, int kt) {
+        unsigned char* slot = smem + (seq % DQ_RING) * DQ_SLOT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave * 2 + j;
+            dma_rows_piece(k_rs, slot, pi, lane, ldk, kt);
+            dma_rows_piece(v_rs, slot + IMG, pi, lane, ldv, kt);
+            dma_tr_piece(k_rs, slot + 2 * IMG, pi, lane, ldk, kt);
+        }
+    };
+    unsigned long long pend = need;                                  // tiles not issued yet
+    auto next_tile = [&]() { const int t = __builtin_ctzll(pend); pend &= pend - 1; return t; };
+    int issued = 0;
+    for (; issued < DQ_RING - 1 && issued < n; ++issued) issue(issued, next_tile());
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    const unsigned swz = (unsigned)((l31 >> 1) & 7);
+    const unsigned row_off = (unsigned)(l31 * 128);
+    const unsigned tr_off = (unsigned)((4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+
+    unsigned long long todo = need;
+    for (int i = 0; i < n; ++i) {
+        const int kt = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (issued - 1 > i) wait_loads<DQ_NL>(); else wait_loads<0>();            // tile i has landed (at most the next tile is in flight)
+        __builtin_amdgcn_s_barrier();                                              // ... for every wave; the slot of tile i - 1 is free
+        if (issued < n) { issue(issued, next_tile()); ++issued; }
+        if (!active || !visible(qview, kt)) continue;
+        const unsigned char* slot = smem + (i % DQ_RING) * DQ_SLOT;
+
+        f32x16 st[2], dp[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[t2][r] = 0.f; dp[t2][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const unsigned off = row_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + off);
+                const bf16x8 c = *reinterpret_cast<const bf16x8*>(slot + IMG + off);
+                st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], st[t2], 0, 0, 0);      // S^T = K.Q^T
+                dp[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, dob[ks], dp[t2], 0, 0, 0);     // dP^T = V.dO^T
+            }
+        bf16x8 ds[2][2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = ks2 * 8 + e;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t2][r], c2, -lse2));
+                    ds[t2][ks2][e] = (__bf16)(p * (dp[t2][r] - D_q) * scale);
+                }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const bf16x8 ka = tr_frag(slot + 2 * IMG + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
+                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, ds[t2][ks2], ot[d], 0, 0, 0);   // dQ^T += K^T.dS^T
+                }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+    if (!active) return;
+    store_transposed(ot, smem + wave * 8192, dq + (b * (size_t)T + qw0) * lddq + h * DH, lddq, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dK, dV
+constexpr int KV_SLOT = 4 * IMG + 512, KV_RING = 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                                   const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                                   float* __restrict__ dk, float* __restrict__ dv, int H, int T, int ldq, int ldk,
+                                                                   int ldv, int lddo, int lddk, int lddv, float scale, int twin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int k0 = blockIdx.z * OT;
+    const int kw0 = k0 + wave * 32;
+    const int nviews = T / KT;
+    const int kview = kw0 / KT;
+    const bool active = kview < nviews;
+    const Vis visible = make_vis(twin);
+
+    const __bf16* qb_ = q + b * (size_t)T * ldq + h * DH;
+    const __bf16* dob_ = dout + b * (size_t)T * lddo + h * DH;
+    const float* lse_b = lse + ((size_t)b * H + h) * T;
+    const float* D_b = Dv + ((size_t)b * H + h) * T;
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(qb_), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t do_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(dob_), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lse_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(D_b), 0, 0x7fffffff, 0x00020000);
+
+    // owner operands: K and V rows of this lane's key as B fragments
+    const int krow = active ? kw0 + l31 : 0;
+    bf16x8 kb[4], vb[4];
+    {
+        const __bf16* ks_ = k + (b * (size_t)T + krow) * ldk + h * DH + 8 * half;
+        const __bf16* vs_ = v + (b * (size_t)T + krow) * ldv + h * DH + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kb[ks] = *reinterpret_cast<const bf16x8*>(ks_ + 16 * ks);
+            vb[ks] = *reinterpret_cast<const bf16x8*>(vs_ + 16 * ks);
+        }
+    }
+    const float c2 = scale * LOG2E;
+
+    // query tiles that see a key view of this workgroup
+    const int va = k0 / KT, vb2 = va + 1;
+    unsigned long long need = 0;
+    for (int qt = 0; qt < nviews; ++qt)
+        if (visible(qt, va) || (vb2 < nviews && visible(qt, vb2))) need |= 1ull << qt;
+    const int n = __builtin_popcountll(need);
+
+    auto issue = [&](int seq, int qt) {
+        unsigned char* slot = smem + (seq % KV_RING) * KV_SLOT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave * 2 + j;
+            dma_rows_piece(q_rs, slot, pi, lane, ldq, qt);
+            dma_rows_piece(do_rs, slot + IMG, pi, lane, lddo, qt);
+            dma_tr_piece(q_rs, slot + 2 * IMG, pi, lane, ldq, qt);
+            dma_tr_piece(do_rs, slot + 3 * IMG, pi, lane, lddo, qt);
+        }
+        // lse / D of the tile's 64 queries (256 B each): 16 lanes x 16 B; every wave issues them (same bytes) so that all waves count
+        // the same number of loads per tile
+        if (lane < 16) {
+            bufds16(l_rs, slot + 4 * IMG, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
+            bufds16(d_rs, slot + 4 * IMG + 256, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
+        }
+    };
+    unsigned long long pend = need;
+    auto next_tile = [&]() { const int t = __builtin_ctzll(pend); pend &= pend - 1; return t; };
+    int issued = 0;
+    for (; issued < KV_RING - 1 && issued < n; ++issued) issue(issued, next_tile());
+
+    f32x16 dvacc[2], dkacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[d][r] = 0.f; dkacc[d][r] = 0.f; }
+    const unsigned swz = (unsigned)((l31 >> 1) & 7);
+    const unsigned row_off = (unsigned)(l31 * 128);
+    const unsigned tr_off = (unsigned)((4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+
+    unsigned long long todo = need;
+    for (int i = 0; i < n; ++i) {
+        const int qt = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        wait_loads<0>();                                                           // (ring of 2: nothing else is in flight yet)
+        __builtin_amdgcn_s_barrier();
+        if (issued < n) { issue(issued, next_tile()); ++issued; }
+        if (!active || !visible(qt, kview)) continue;
+        const unsigned char* slot = smem + (i % KV_RING) * KV_SLOT;
+
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                                              // the tile's two 32-query halves
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned off = row_off + u * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + off);
+                const bf16x8 c = *reinterpret_cast<const bf16x8*>(slot + IMG + off);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb[ks], st, 0, 0, 0);              // S = Q.K^T   [query][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, vb[ks], dp, 0, 0, 0);              // dP = dO.V^T
+            }
+            // accumulator row r = query 32 u + (r & 3) + 8 (r >> 2) + 4 half: its lse / D from the tile's table
+            bf16x8 pf[2], sf[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + 256 + (32 * u + 8 * j + 4 * half) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * j + e;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e] * LOG2E));
+                    pf[r >> 3][r & 7] = (__bf16)p;
+                    sf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - d4[e]) * scale);
+                }
+            }
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned off = tr_off + d * 4096 + (u * 32 + ks2 * 16) * 64;
+                    const bf16x8 oa = tr_frag(slot + 3 * IMG + off);
+                    dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, pf[ks2], dvacc[d], 0, 0, 0);   // dV^T += dO^T.P
+                    const bf16x8 qa = tr_frag(slot + 2 * IMG + off);
+                    dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sf[ks2], dkacc[d], 0, 0, 0);   // dK^T += Q^T.dS
+                }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!active) return;
+    unsigned char* Os = smem + wave * 8192;
+    store_transposed(dkacc, Os, dk + (b * (size_t)T + kw0) * lddk + h * DH, lddk, lane);
+    store_transposed(dvacc, Os, dv + (b * (size_t)T + kw0) * lddv + h * DH, lddv, lane);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream) {
+    if (!dout || !out || !D || B <= 0 || H <= 0 || T <= 0) return VF_ERR_BAD_ARG;
+    if (lddo < H * DH || ldo < H * DH || ((lddo | ldo) & 7)) return VF_ERR_BAD_ARG;
+    const long long total = (long long)B * T * H * 8;
+    hipLaunchKernelGGL(attn_bwd_prep_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(dout), reinterpret_cast<const __bf16*>(out), D, B, H, T, lddo, ldo);
+    return vf_last_status();
+}
+
+int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, float* dq, float* dk,
+                     float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale,
+                     int twin_view, void* stream) {
+    if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
+    if (L != KT || T % KT != 0 || T / KT > 64) return VF_ERR_UNSUPPORTED;                     // 64-token views, at most 64 of them (tile bit masks)
+    if (ldq < H * DH || ldk < H * DH || ldv < H * DH || lddo < H * DH || lddq < H * DH || lddk < H * DH || lddv < H * DH) return VF_ERR_BAD_ARG;
+    if (((ldq | ldk | ldv | lddo) & 7) || ((lddq | lddk | lddv) & 3)) return VF_ERR_BAD_ARG;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) return VF_ERR_UNSUPPORTED;
+    const size_t ldmax = (size_t)(ldq > ldk ? ldq : ldk) > (size_t)(ldv > lddo ? ldv : lddo) ? (size_t)(ldq > ldk ? ldq : ldk) : (size_t)(ldv > lddo ? ldv : lddo);
+    if ((size_t)T * ldmax * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;                     // 32-bit buffer offsets per (scene, head)
+    static unsigned long long attr_devs = 0;
+    if (vf_attr_needed(&attr_devs)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
+        if (e != hipSuccess) return (int)e;
+        vf_attr_done(&attr_devs);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, reinterpret_cast<const __bf16*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const __bf16*>(dout), lse, D, dq,
+                       H, T, ldq, ldk, ldv, lddo, lddq, scale, twin_view);
+    int st = vf_last_status();
+    if (st) return st;
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, reinterpret_cast<const __bf16*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const __bf16*>(dout), lse, D, dk,
+                       dv, H, T, ldq, ldk, ldv, lddo, lddk, lddv, scale, twin_view);
+    return vf_last_status();
+}
+
+}  // extern "C"

@@ -20,18 +20,19 @@ inline unsigned grid1(long long total, int per_block, unsigned cap = 32768) {
 }
 
 // ------------------------------------------------------------------ batched 2-D transpose (32x32 LDS tiles)
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+template <typename TS>          // TS = float, or __bf16 (a saved bf16 activation widened on the way: exact)
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, float* __restrict__ dst, int rows,
                                                         int cols, long long ld_src, long long ld_dst,
                                                         long long bs_src, long long bs_dst) {
     __shared__ float tile[32][33];
-    const float* s = src + blockIdx.z * bs_src;
+    const TS* s = src + blockIdx.z * bs_src;
     float* d = dst + blockIdx.z * bs_dst;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? s[(long long)r * ld_src + c] : 0.f;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? (float)s[(long long)r * ld_src + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -60,6 +61,57 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     float s = 0.f;
     for (int i = 0; i < nsplit; ++i) s += part[(long long)i * N + n];
     out[n] = accumulate ? out[n] + s : s;
+}
+
+// One launch (vf_colsum_f32): float4 columns, four row phases per block combined in a fixed order, and the LAST block of a column block to
+// finish (an integer ticket) reduces that column block's split slabs in slab order — the result does not depend on which block that is.
+// The two-kernel form above spent as long in its 127 tiny second-stage launches per training step as in reading the matrices, and its
+// one-column-per-thread first stage ran the narrow (N = 768) matrices at 1.3 TB/s.
+constexpr int COLSUM_COUNTER_BYTES = 1024;           // 256 column-block tickets at the START of the workspace (zero before first use, left zero)
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, float* __restrict__ part, float* __restrict__ out,
+                                                           unsigned* __restrict__ counters, long long M, int N, long long ld, int nsplit,
+                                                           int accumulate) {
+    __shared__ float red[4][256];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, cq = tid & 63, ph = tid >> 6;
+    const int col0 = blockIdx.x * 256, col = col0 + cq * 4;
+    const long long per = (M + nsplit - 1) / nsplit;
+    const long long m0 = blockIdx.y * per, m1 = min(M, m0 + per);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = col + 3 < N && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0;
+    if (vec) {
+        long long m = m0 + ph;
+        for (; m + 12 < m1; m += 16) {                                // four independent loads in flight
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + m * ld + col), b = *reinterpret_cast<const f32x4*>(x + (m + 4) * ld + col);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(x + (m + 8) * ld + col), e = *reinterpret_cast<const f32x4*>(x + (m + 12) * ld + col);
+            acc += a; acc += b; acc += c; acc += e;
+        }
+        for (; m < m1; m += 4) acc += *reinterpret_cast<const f32x4*>(x + m * ld + col);
+    } else {
+        for (long long m = m0 + ph; m < m1; m += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < N) acc[e] += x[m * ld + col + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ph][cq * 4 + e] = acc[e];
+    __syncthreads();
+    if (col0 + tid < N) part[(long long)blockIdx.y * N + col0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(&counters[blockIdx.x], 1u);     // integer ticket: only decides WHO reduces, never the order of the sum
+        is_last = t == (unsigned)nsplit - 1;
+        if (is_last) counters[blockIdx.x] = 0;                       // left zero for the next call
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int n = col0 + tid;
+    if (n >= N) return;
+    float sum = 0.f;
+    for (int i = 0; i < nsplit; ++i) sum += __builtin_nontemporal_load(part + (long long)i * N + n);
+    out[n] = accumulate ? out[n] + sum : sum;
 }
 
 // ------------------------------------------------------------------ LayerNorm backward (one wave per row)
@@ -147,6 +199,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 __global__ void gelu_kernel(const float* __restrict__ u, float* __restrict__ f, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         f[i] = vf_gelu_erf(u[i]);
+}
+__global__ void gelu_bf16out_kernel(const float* __restrict__ u, __bf16* __restrict__ f, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        f[i] = (__bf16)vf_gelu_erf(u[i]);
 }
 __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df, float* __restrict__ du, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -269,19 +325,39 @@ constexpr int EMB_SPLITS = 16;
 __global__ __launch_bounds__(256) void embed_bwd_wte_partial_kernel(const float* __restrict__ dh, const int* __restrict__ ids,
                                                                     float* __restrict__ partial, long long ntok, int d, int vocab) {
     const int id = blockIdx.x, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63;
     const long long per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
     const long long t0 = sp * per, t1 = t0 + per < ntok ? t0 + per : ntok;
     float acc[8];                                                     // d <= 2048
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    for (long long tok = t0; tok < t1; ++tok) {
-        int v = ids[tok];                                             // (uniform across the block: a scalar load)
-        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
-        if (v != id) continue;
+    // 64 tokens per round: every wave ballots the same 64 ids (lane = token), then walks the matches in ascending order, four rows
+    // in flight (a third of the training tokens carry the MASK id: one row per load latency made this kernel 1.6 ms)
+    for (long long base = t0; base < t1; base += 64) {
+        int v = -1;
+        if (base + lane < t1) {
+            v = ids[base + lane];
+            v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        }
+        unsigned long long m = __ballot(v == id);
+        while (m) {
+            long long tk[4];
+            int n = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = threadIdx.x + q * 256;
-            if (c < d) acc[q] += dh[tok * d + c];
+            for (int u = 0; u < 4; ++u) {
+                if (m) { tk[u] = base + __builtin_ctzll(m); m &= m - 1; n = u + 1; } else tk[u] = base;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = threadIdx.x + q * 256;
+                if (c < d) {
+                    float x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = dh[tk[u] * d + c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[q] += (u < n) ? x[u] : 0.f;     // ascending token order: deterministic
+                }
+            }
         }
     }
 #pragma unroll
@@ -428,12 +504,21 @@ int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t l
                      int64_t bs_src, int64_t bs_dst, void* stream) {
     if (!src || !dst || rows <= 0 || cols <= 0 || batch < 1 || ld_src < cols || ld_dst < rows) return VF_ERR_BAD_ARG;
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, (long long)ld_src,
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, (long long)ld_src,
                        (long long)ld_dst, (long long)bs_src, (long long)bs_dst);
     return vf_last_status();
 }
 
-size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)256 * N * sizeof(float) : 0; }
+int vf_transpose_bf16_f32(const void* src_bf16, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
+                          int64_t bs_src, int64_t bs_dst, void* stream) {
+    if (!src_bf16 || !dst || rows <= 0 || cols <= 0 || batch < 1 || ld_src < cols || ld_dst < rows) return VF_ERR_BAD_ARG;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(src_bf16), dst,
+                       rows, cols, (long long)ld_src, (long long)ld_dst, (long long)bs_src, (long long)bs_dst);
+    return vf_last_status();
+}
+
+size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)256 * N * sizeof(float) + COLSUM_COUNTER_BYTES : 0; }
 
 // rows per split 128, at most max_split splits (= rows of the [split][N] scratch the caller provides): the bias gradients of
 // the training step reduce 19200 x 768..3072 matrices, which 64 splits x 3..12 column blocks left on a fraction of the CUs
@@ -450,7 +535,14 @@ static int colsum_launch(const float* x, float* out, int64_t M, int N, int64_t l
 }
 
 int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream) {
-    return colsum_launch(x, out, M, N, ld, accumulate, ws, 256, stream);
+    if (!x || !out || !ws || M <= 0 || N <= 0 || ld < N) return VF_ERR_BAD_ARG;
+    if ((N + 255) / 256 > COLSUM_COUNTER_BYTES / 4) return colsum_launch(x, out, M, N, ld, accumulate, (unsigned char*)ws + COLSUM_COUNTER_BYTES, 256, stream);
+    int nsplit = (int)((M + 127) / 128);
+    if (nsplit > 256) nsplit = 256;
+    hipLaunchKernelGGL(colsum_fused_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<float*>((unsigned char*)ws + COLSUM_COUNTER_BYTES), out, reinterpret_cast<unsigned*>(ws), (long long)M, N,
+                       (long long)ld, nsplit, accumulate);
+    return vf_last_status();
 }
 
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
@@ -488,6 +580,13 @@ int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream) {
     if (!u || !f || n < 0) return VF_ERR_BAD_ARG;
     if (n == 0) return VF_OK;
     hipLaunchKernelGGL(gelu_kernel, dim3(grid1(n, 256)), dim3(256), 0, (hipStream_t)stream, u, f, (long long)n);
+    return vf_last_status();
+}
+
+int vf_gelu_bf16out_f32(const float* u, void* f_bf16, int64_t n, void* stream) {
+    if (!u || !f_bf16 || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(gelu_bf16out_kernel, dim3(grid1(n, 256)), dim3(256), 0, (hipStream_t)stream, u, reinterpret_cast<__bf16*>(f_bf16), (long long)n);
     return vf_last_status();
 }
 

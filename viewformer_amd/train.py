@@ -191,8 +191,9 @@ class MIGTTrainer:
     def _linear(self, x, name, M, res=None):
         return self.model._gemm(x, name, M, res=res)
 
-    def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None):
-        """grads of y = x @ W + b given dy [M,N]; returns dx (+res) or None"""
+    def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None, dx_bf16=False):
+        """grads of y = x @ W + b given dy [M,N]; returns dx (+res) or None.  ``x`` may be a saved bf16 activation (bf16 arm);
+        ``dx_bf16``: the bf16 arm's dX GEMM writes bf16 (the attention backward's dO operand)."""
         dn = self.model._dense[name]
         K, N = dn.k, dn.n
         T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
@@ -227,9 +228,11 @@ class MIGTTrainer:
             ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                         # dW += X^T dY
         if not need_dx:
             return None
-        dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        if dx_bf16 and not (bf16 and res is None):
+            raise RuntimeError('dx_bf16 needs the bf16 arm and no residual')
+        dx = torch.empty((M, K), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=x.device)
         if bf16:
-            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True)
+            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, o16=dx_bf16)
         elif x6:
             ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
         else:
@@ -243,6 +246,8 @@ class MIGTTrainer:
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
 
+    bf16_saved_activations = True     # bf16 arm: LayerNorm outputs / MLP hidden saved as bf16 (see train_step); False keeps them fp32 (same gradients)
+    attention_arith = 'bf16'          # bf16 arm only: 'bf16' = attention forward / backward on the bf16 matrix pipe; 'f32' = the exact-f32 kernels
     fused_optimizer = True            # AdamWeightDecay as ONE launch over the flat buffer (False: one launch per tensor, 468 per step; bit-identical)
     _nodecay = None
     attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
@@ -351,21 +356,38 @@ class MIGTTrainer:
         if rate:
             T.dropout_add(h, rate, seed, SITE_EMBED, out=h)                          # self.drop, migt.py:403
         saved = []
+        # attention of the bf16 arm on the bf16 matrix pipe (csrc/attention_dma.hip + attention_train_bf16.hip) where its kernels apply:
+        # 64-token views, no attention dropout, the wide c_attn / c_proj layers on their bf16 packings; otherwise the exact-f32 kernels
+        ca, cp = m._dense['h.0.attn.c_attn'], m._dense['h.0.attn.c_proj']
+        attn16 = (self.attention_arith == 'bf16' and m.precision == 'bf16' and rate == 0.0 and T.attn_bf16_supported(Tn, L)
+                  and d // H == 64 and ca.wp16 is not None and cp.wp16 is not None and M % 128 == 0)
+        # bf16 arm, wide layers: the activations only GEMMs read — both LayerNorm outputs, the attention output, the MLP hidden — are
+        # SAVED AS bf16 by their producers (the rounding the GEMM applied on load before: identical products), so the forward GEMMs take
+        # the 256-tile LDS-DMA kernel (bf16 A operand) and the saved activations halve; the backward reads them through the widening
+        # transpose (dW) and never otherwise (LayerNorm / GELU backward use the fp32 h / u)
+        act16 = attn16 and self.bf16_saved_activations and all(m._dense[f'h.0.{n}'].wp16 is not None for n in ('mlp.c_fc', 'mlp.c_proj'))
         for i in range(c.n_layer):
             p = f'h.{i}'
-            n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d)
-            qkv = self._linear(n1, p + '.attn.c_attn', M)
-            att = torch.empty((M, d), dtype=torch.float32, device=dev)
-            lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
-                                 drop=(rate, seed, site_attn(i)))
+            n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d, out_bf16=act16)
+            if attn16:
+                # bf16 arm: c_attn writes q | k | v as bf16, the LDS-DMA kernel of the inference arm (+ log-sum-exp) writes a bf16 output
+                # that c_proj reads as it is (the rounding the GEMM would apply on load)
+                qkv = m._gemm(n1, p + '.attn.c_attn', M, out_bf16=True)
+                att = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
+                lse = T.attn_fwd_lse_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S)
+            else:
+                qkv = self._linear(n1, p + '.attn.c_attn', M)
+                att = torch.empty((M, d), dtype=torch.float32, device=dev)
+                lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
+                                     drop=(rate, seed, site_attn(i)))
             if rate:                                                                 # resid_dropout, migt.py:216
                 y = self._linear(att, p + '.attn.c_proj', M)
                 h_mid = T.dropout_add(y, rate, seed, site_resid(i), res=h, out=y)
             else:
                 h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
-            n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d)
+            n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d, out_bf16=act16)
             u = self._linear(n2, p + '.mlp.c_fc', M)
-            f = T.gelu(u)
+            f = T.gelu(u, out_bf16=act16)
             if rate:                                                                 # MLP dropout, migt.py:72
                 y = self._linear(f, p + '.mlp.c_proj', M)
                 h_out = T.dropout_add(y, rate, seed, site_mlp(i), res=h_mid, out=y)
@@ -458,8 +480,14 @@ class MIGTTrainer:
             du = T.gelu_bwd(u, df)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
             dh_mid = T.add_(self._ln_bwd(p + '.ln_2', dn2, h_mid, M), dh)
-            datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M)
-            dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
+            datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M,
+                                    dx_bf16=attn16)
+            if attn16:
+                dqkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
+                T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
+                                B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S)
+            else:
+                dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
             dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
             saved[i] = None

@@ -16,25 +16,30 @@ def transpose(src, rows, cols, ld_src=None, batch=1, bs_src=0, out=None, ld_dst=
     ld_dst = rows if ld_dst is None else ld_dst
     if out is None:
         out = torch.empty((batch, cols, ld_dst), dtype=torch.float32, device=src.device)
-    check(_lib.load().vf_transpose_f32(_p(_f32(src)), _p(out), rows, cols, ld_src, ld_dst, batch, bs_src, cols * ld_dst, _stream()),
-          'vf_transpose_f32')
+    lib = _lib.load()
+    if src.dtype == torch.bfloat16:                 # a saved bf16 activation: widened exactly on the way
+        check(lib.vf_transpose_bf16_f32(_p(_chk(src, torch.bfloat16)), _p(out), rows, cols, ld_src, ld_dst, batch, bs_src, cols * ld_dst,
+                                        _stream()), 'vf_transpose_bf16_f32')
+    else:
+        check(lib.vf_transpose_f32(_p(_f32(src)), _p(out), rows, cols, ld_src, ld_dst, batch, bs_src, cols * ld_dst, _stream()),
+              'vf_transpose_f32')
     return out
 
 
 _ws_cache = {}
 
 
-def _ws(nbytes, dev, key):
+def _ws(nbytes, dev, key, zero=False):
     t = _ws_cache.get((key, dev))
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        t = (torch.zeros if zero else torch.empty)(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _ws_cache[(key, dev)] = t
     return t
 
 
 def colsum(x, out, M, N, ld=None, accumulate=False):
     lib = _lib.load()
-    ws = _ws(int(lib.vf_colsum_workspace_bytes(N)), x.device, 'colsum')
+    ws = _ws(int(lib.vf_colsum_workspace_bytes(N)), x.device, 'colsum', zero=True)       # the ticket counters start (and are left) at zero
     check(lib.vf_colsum_f32(_p(_f32(x)), _p(_f32(out)), M, N, N if ld is None else ld, 1 if accumulate else 0, _p(ws), _stream()),
           'vf_colsum_f32')
     return out
@@ -49,7 +54,11 @@ def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=Tru
     return dx
 
 
-def gelu(u):
+def gelu(u, out_bf16=False):
+    if out_bf16:
+        f = torch.empty(u.shape, dtype=torch.bfloat16, device=u.device)
+        check(_lib.load().vf_gelu_bf16out_f32(_p(_f32(u)), _p(f), u.numel(), _stream()), 'vf_gelu_bf16out_f32')
+        return f
     f = torch.empty_like(u)
     check(_lib.load().vf_gelu_f32(_p(_f32(u)), _p(f), u.numel(), _stream()), 'vf_gelu_f32')
     return f
@@ -167,6 +176,32 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo
     check(lib.vf_attn_bwd_f32(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), B, H, T, L, ldq, ldk, ldv,
                               lddo, lddq, lddk, lddv, scale, mask_spec, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]),
                               _stream()), 'vf_attn_bwd_f32')
+
+
+def attn_bf16_supported(T, L):
+    """shapes the bf16 training attention takes (64-token views, whole views, at most 64 of them); otherwise the f32 kernels"""
+    return L == 64 and T % 64 == 0 and T // 64 <= 64
+
+
+def attn_fwd_lse_bf16(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1):
+    """bf16 q / k / v -> bf16 ``out`` (LDS-DMA kernel of the inference arm) plus the per-query log-sum-exp [B,H,T] fp32"""
+    for t in (q, k, v, out):
+        _chk(t, torch.bfloat16)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    check(_lib.load().vf_attn_blockcausal_bf16_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), B, H, T, L, ldq, ldk, ldv, ldo, scale, mask_spec,
+                                                   _stream()), 'vf_attn_blockcausal_bf16_lse')
+    return lse
+
+
+def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0, mask_spec=-1):
+    """dQ, dK, dV (fp32, written in place; column views allowed) from bf16 q / k / v / out / dout on the bf16 matrix pipe"""
+    lib = _lib.load()
+    for t in (q, k, v, out, dout):
+        _chk(t, torch.bfloat16)
+    D = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    check(lib.vf_attn_bwd_prep_bf16(_p(dout), _p(out), _p(D), B, H, T, lddo, ldo, _stream()), 'vf_attn_bwd_prep_bf16')
+    check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(_f32(dq)), _p(_f32(dk)), _p(_f32(dv)), B, H, T, L, ldq, ldk,
+                               ldv, lddo, lddq, lddk, lddv, scale, mask_spec, _stream()), 'vf_attn_bwd_bf16')
 
 
 def dropout_add(x, rate, seed, site, res=None, out=None):
