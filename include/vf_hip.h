@@ -397,6 +397,12 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo,
                     int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
                     uint32_t drop_site, void* stream);
+/* weight + bias gradient of a dense layer in the bf16 training arm (csrc/gemm_tn_bf16.hip): for split s of the M rows,
+ * w_slabs[s][K][N] = sum_m x[m][k] * dy[m][n] and (b_slabs != NULL) b_slabs[s][N] = sum_m dy[m][n], with x a saved bf16 activation
+ * [M][ldx] and dy the fp32 gradient [M][ldy], both read as they lie (no transposed copy, no packed copy, no separate column-sum pass).
+ * Fold the slabs with vf_sum_slabs_f32 (fixed order).  K % 256 == N % 256 == M % 64 == 0; autograd of Conv1D.call (migt.py:89-96). */
+int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const float* dy, int ldy, int M, int K, int N, int splits, float* w_slabs,
+                    float* b_slabs, void* stream);
 /* bf16 arm of the training step's attention (csrc/attention_dma.hip, attention_train_bf16.hip): bf16 q / k / v / out / dout in HBM
  * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views, no attention dropout — VF_ERR_UNSUPPORTED
  * otherwise (callers then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the
@@ -420,8 +426,7 @@ int vf_transpose_f32(const float* src, float* dst, int rows, int cols, int64_t l
 /* the same from a bf16 source (a saved bf16 activation of the bf16 training arm), widened exactly */
 int vf_transpose_bf16_f32(const void* src_bf16, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch,
                           int64_t bs_src, int64_t bs_dst, void* stream);
-/* out[n] (+)= sum_m x[m][n]  (bias gradients; deterministic: fixed-order partial sums, an integer ticket only picks the block that
- * folds them)  ws: vf_colsum_workspace_bytes(N) bytes whose first 1024 must be ZERO before the first call (every call leaves them zero) */
+/* out[n] (+)= sum_m x[m][n]  (bias gradients; deterministic two-stage: fixed-order partial sums)  ws: vf_colsum_workspace_bytes(N) */
 size_t vf_colsum_workspace_bytes(int N);
 int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream);
 /* LayerNormalization backward (migt.py:225,227,292): dx, and dgamma/dbeta (+)= */

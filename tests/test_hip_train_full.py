@@ -96,6 +96,14 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     assert torch.equal(tr16.flat_g, gb)
     tr16.bf16_saved_activations = True
+    # weight gradients straight from the row-major operands (csrc/gemm_tn_bf16.hip) vs transpose + pack + batched split-K GEMM + column
+    # sums: the same bf16 products, another summation order
+    tr16.tn_weight_gradient = False
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    worst_t = max(_rel(gb[a:b], tr16.flat_g[a:b]) for a, b, _ in (tr16.slices[n] for n in tr16.names) if float(tr16.flat_g[a:b].abs().max()) > 0)
+    print('full-size bf16 arm: TN weight-gradient kernel vs the transpose + pack path, worst per-tensor gradient difference', worst_t)
+    assert worst_t < 1e-4, worst_t
+    tr16.tn_weight_gradient = True
     # the exact-f32 attention kernels inside the bf16 arm: the bf16 attention stays within the arm's tolerance of them
     tr16.attention_arith = 'f32'
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)

@@ -509,6 +509,7 @@ def test_test_step_and_predict_step(dev):
     # training-only randomness is off in test_step
     cfg2, _, tokens2, poses2, tr2 = _setup(True, dev)
     tr2.cfg.dropout, tr2.cfg.random_pose_multiplier = 0.3, 2.0
+    tr2.step_count = 3                                             # (the localization-weight schedule follows the step counter)
     a, b = tr2.test_step(poses2, tokens2), tr2.test_step(poses2, tokens2)
     assert float(a['loss']) == float(b['loss']) == float(m_test['loss'])
     assert float(tr2.train_step(poses2, tokens2, reduce_gradients=False, apply_update=False)['loss']) != float(a['loss'])
@@ -622,3 +623,34 @@ def test_bf16_attention_is_what_the_bf16_training_arm_runs_at_full_width(dev):
             worst = max(worst, ((grads['bf16'][a:b] - ref).abs().max() / ref.abs().max()).item())
     print('bf16 vs f32 attention inside the bf16 training arm: worst per-tensor gradient difference', worst)
     assert worst < BF16_GRAD_TOL, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N', [(64, 256, 256), (640, 512, 256), (1920, 256, 768), (19200, 768, 2304)])
+def test_tn_weight_gradient_gemm(dev, M, K, N):
+    """csrc/gemm_tn_bf16.hip: dW = x^T dy and db = column sums of dy from the row-major bf16 activation and fp32 gradient, against fp64 on
+    the operands it multiplies (x as stored, dy rounded to bf16 — products of bf16 values are exact in fp32, so only the accumulation
+    order differs) and against the path it replaces (widening transpose + bf16 packing + batched split-K GEMM + column sums)."""
+    from viewformer_amd import ops
+    from viewformer_amd import train_ops as T
+    g = np.random.Generator(np.random.PCG64(M + K))
+    x16 = torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    dy = torch.from_numpy((g.standard_normal((M, N)) * 0.1).astype(np.float32)).to(dev)
+    assert ops.gemm_tn_bf16_supported(x16, M, K, N)
+    dw0 = torch.from_numpy(g.standard_normal((K, N)).astype(np.float32)).to(dev)
+    db0 = torch.from_numpy(g.standard_normal((N,)).astype(np.float32)).to(dev)
+    dw, db = dw0.clone(), db0.clone()
+    ops.gemm_tn_bf16(x16, dy, M, K, N, dw, db)                                  # accumulates
+    ref_w = x16.double().T @ dy.to(torch.bfloat16).double()
+    ref_b = dy.double().sum(0)
+    e_w = ((dw.double() - dw0.double() - ref_w).abs().max() / ref_w.abs().max()).item()
+    e_b = ((db.double() - db0.double() - ref_b).abs().max() / ref_b.abs().max()).item()
+    assert e_w < 2e-5 and e_b < 2e-5, (e_w, e_b)
+    dw2, db2 = dw0.clone(), db0.clone()
+    ops.gemm_tn_bf16(x16, dy, M, K, N, dw2, db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                        # deterministic
+    if M % 128 == 0:                                                            # the replaced path, same operands
+        xt = T.transpose(x16, M, K)
+        old = torch.zeros((K, N), device=dev)
+        ops.igemm(xt, ops.pack_dense_kn_bf16(dy), K, M, N, old, lda=M, bf16=True)
+        assert ((old.double() - ref_w).abs().max() / ref_w.abs().max()).item() < 2e-5

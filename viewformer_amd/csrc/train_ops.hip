@@ -63,23 +63,19 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[n] = accumulate ? out[n] + s : s;
 }
 
-// One launch (vf_colsum_f32): float4 columns, four row phases per block combined in a fixed order, and the LAST block of a column block to
-// finish (an integer ticket) reduces that column block's split slabs in slab order — the result does not depend on which block that is.
-// The two-kernel form above spent as long in its 127 tiny second-stage launches per training step as in reading the matrices, and its
-// one-column-per-thread first stage ran the narrow (N = 768) matrices at 1.3 TB/s.
-constexpr int COLSUM_COUNTER_BYTES = 1024;           // 256 column-block tickets at the START of the workspace (zero before first use, left zero)
-__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, float* __restrict__ part, float* __restrict__ out,
-                                                           unsigned* __restrict__ counters, long long M, int N, long long ld, int nsplit,
-                                                           int accumulate) {
+// stage 1 for wide matrices (vf_colsum_f32): float4 columns, four row phases per block combined in a fixed order.  (A one-launch form in
+// which the last block of a column block to finish — an integer ticket — folded the slabs was tried in round 3 and REMOVED: the
+// device-scope fence it needs between the slab writes and the ticket makes every block write its XCD's L2 back (8 XCDs, 8 L2s), and the
+// launch took 158 us on average where these two take 30-45 + 17.)
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x, float* __restrict__ part, long long M, int N,
+                                                              long long ld, int nsplit) {
     __shared__ float red[4][256];
-    __shared__ int is_last;
     const int tid = threadIdx.x, cq = tid & 63, ph = tid >> 6;
     const int col0 = blockIdx.x * 256, col = col0 + cq * 4;
     const long long per = (M + nsplit - 1) / nsplit;
     const long long m0 = blockIdx.y * per, m1 = min(M, m0 + per);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = col + 3 < N && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0;
-    if (vec) {
+    if (col + 3 < N) {
         long long m = m0 + ph;
         for (; m + 12 < m1; m += 16) {                                // four independent loads in flight
             const f32x4 a = *reinterpret_cast<const f32x4*>(x + m * ld + col), b = *reinterpret_cast<const f32x4*>(x + (m + 4) * ld + col);
@@ -97,21 +93,6 @@ __global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) red[ph][cq * 4 + e] = acc[e];
     __syncthreads();
     if (col0 + tid < N) part[(long long)blockIdx.y * N + col0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(&counters[blockIdx.x], 1u);     // integer ticket: only decides WHO reduces, never the order of the sum
-        is_last = t == (unsigned)nsplit - 1;
-        if (is_last) counters[blockIdx.x] = 0;                       // left zero for the next call
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    const int n = col0 + tid;
-    if (n >= N) return;
-    float sum = 0.f;
-    for (int i = 0; i < nsplit; ++i) sum += __builtin_nontemporal_load(part + (long long)i * N + n);
-    out[n] = accumulate ? out[n] + sum : sum;
 }
 
 // ------------------------------------------------------------------ LayerNorm backward (one wave per row)
@@ -518,7 +499,7 @@ int vf_transpose_bf16_f32(const void* src_bf16, float* dst, int rows, int cols, 
     return vf_last_status();
 }
 
-size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)256 * N * sizeof(float) + COLSUM_COUNTER_BYTES : 0; }
+size_t vf_colsum_workspace_bytes(int N) { return N > 0 ? (size_t)256 * N * sizeof(float) : 0; }
 
 // rows per split 128, at most max_split splits (= rows of the [split][N] scratch the caller provides): the bias gradients of
 // the training step reduce 19200 x 768..3072 matrices, which 64 splits x 3..12 column blocks left on a fraction of the CUs
@@ -536,12 +517,12 @@ static int colsum_launch(const float* x, float* out, int64_t M, int N, int64_t l
 
 int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int accumulate, void* ws, void* stream) {
     if (!x || !out || !ws || M <= 0 || N <= 0 || ld < N) return VF_ERR_BAD_ARG;
-    if ((N + 255) / 256 > COLSUM_COUNTER_BYTES / 4) return colsum_launch(x, out, M, N, ld, accumulate, (unsigned char*)ws + COLSUM_COUNTER_BYTES, 256, stream);
+    if ((ld & 3) || ((uintptr_t)x & 15) || N < 64) return colsum_launch(x, out, M, N, ld, accumulate, ws, 256, stream);   // narrow / unaligned: one column per thread
     int nsplit = (int)((M + 127) / 128);
     if (nsplit > 256) nsplit = 256;
-    hipLaunchKernelGGL(colsum_fused_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream, x,
-                       reinterpret_cast<float*>((unsigned char*)ws + COLSUM_COUNTER_BYTES), out, reinterpret_cast<unsigned*>(ws), (long long)M, N,
-                       (long long)ld, nsplit, accumulate);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, s, x, (float*)ws, (long long)M, N, (long long)ld, nsplit);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ws, out, N, nsplit, accumulate);
     return vf_last_status();
 }
 

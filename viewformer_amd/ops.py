@@ -214,6 +214,26 @@ def gemm_bf16_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulat
     return dst
 
 
+def gemm_tn_bf16_supported(x, M, K, N):
+    return x.dtype == torch.bfloat16 and K % 256 == 0 and N % 256 == 0 and M % 64 == 0 and M * K * 2 < 2 ** 31
+
+
+def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
+    """dw[K][N] (+)= x16^T @ dy and db[N] (+)= column sums of dy, straight from the row-major bf16 activation x16 [M][K] and the fp32
+    gradient dy [M][N] (csrc/gemm_tn_bf16.hip): split-K slabs folded in slab order (deterministic)."""
+    lib = _lib.load()
+    _chk(x16, torch.bfloat16, 'x16')
+    tiles = (K // 256) * (N // 256)
+    splits = max(1, min(M // 64, 256 // tiles if tiles <= 256 else 1))
+    ws = torch.empty((splits, K, N), dtype=torch.float32, device=dy.device)
+    bs = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if db is not None else None
+    check(lib.vf_gemm_tn_bf16(_p(x16), x16.stride(0), _p(_f32(dy)), dy.stride(0), M, K, N, splits, _p(ws), _p(bs), _stream()), 'vf_gemm_tn_bf16')
+    check(lib.vf_sum_slabs_f32(_p(ws), splits, K * N, K * N, _p(_f32(dw)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')
+    if db is not None:
+        check(lib.vf_sum_slabs_f32(_p(bs), splits, N, N, _p(_f32(db)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')
+    return dw
+
+
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,

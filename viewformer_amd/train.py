@@ -196,6 +196,12 @@ class MIGTTrainer:
         ``dx_bf16``: the bf16 arm's dX GEMM writes bf16 (the attention backward's dO operand)."""
         dn = self.model._dense[name]
         K, N = dn.k, dn.n
+        bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
+        if bf16 and self.tn_weight_gradient and dy.dtype == torch.float32 and ops.gemm_tn_bf16_supported(x, M, K, N):
+            # bf16 arm with a saved bf16 activation: dW and db in ONE pass over x and dy as they lie (csrc/gemm_tn_bf16.hip) — no widening
+            # transpose of x, no packed bf16 copy of dy, no column-sum pass
+            ops.gemm_tn_bf16(x, dy, M, K, N, self.g(name + '.weight'), self.g(name + '.bias'))
+            return self._linear_dx(name, dy, M, res, dx_bf16) if need_dx else None
         T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
         Mp = (M + 31) // 32 * 32                                                     # reduction length padded to the K stage
         xt = None
@@ -204,7 +210,6 @@ class MIGTTrainer:
         xt = T.transpose(x, M, K, out=xt, ld_dst=Mp)                                 # [K][Mp]
         gw = self.g(name + '.weight')
         x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
-        bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
         if bf16:
             # dW += X^T dY: (K/128)(N/128) = 36..144 output tiles for 256 CUs and a reduction of M = 19 200 rows -> split-K (as the x6
             # arm below); the split count must cut M into whole 64-row chunks of the packing
@@ -228,9 +233,17 @@ class MIGTTrainer:
             ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                         # dW += X^T dY
         if not need_dx:
             return None
+        return self._linear_dx(name, dy, M, res, dx_bf16)
+
+    def _linear_dx(self, name, dy, M, res=None, dx_bf16=False):
+        """dx = dy @ W^T (+ res)"""
+        dn = self.model._dense[name]
+        K, N = dn.k, dn.n
+        x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
+        bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
         if dx_bf16 and not (bf16 and res is None):
             raise RuntimeError('dx_bf16 needs the bf16 arm and no residual')
-        dx = torch.empty((M, K), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=x.device)
+        dx = torch.empty((M, K), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dy.device)
         if bf16:
             ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, o16=dx_bf16)
         elif x6:
@@ -246,6 +259,7 @@ class MIGTTrainer:
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
 
+    tn_weight_gradient = True         # bf16 arm: dW / db of the wide layers straight from the row-major operands (False: transpose + pack + column sums)
     bf16_saved_activations = True     # bf16 arm: LayerNorm outputs / MLP hidden saved as bf16 (see train_step); False keeps them fp32 (same gradients)
     attention_arith = 'bf16'          # bf16 arm only: 'bf16' = attention forward / backward on the bf16 matrix pipe; 'f32' = the exact-f32 kernels
     fused_optimizer = True            # AdamWeightDecay as ONE launch over the flat buffer (False: one launch per tensor, 468 per step; bit-identical)

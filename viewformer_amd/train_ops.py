@@ -39,7 +39,7 @@ def _ws(nbytes, dev, key, zero=False):
 
 def colsum(x, out, M, N, ld=None, accumulate=False):
     lib = _lib.load()
-    ws = _ws(int(lib.vf_colsum_workspace_bytes(N)), x.device, 'colsum', zero=True)       # the ticket counters start (and are left) at zero
+    ws = _ws(int(lib.vf_colsum_workspace_bytes(N)), x.device, 'colsum')
     check(lib.vf_colsum_f32(_p(_f32(x)), _p(_f32(out)), M, N, N if ld is None else ld, 1 if accumulate else 0, _p(ws), _stream()),
           'vf_colsum_f32')
     return out
