@@ -87,7 +87,7 @@ class OpTimer:
 
     def install(self):
         from viewformer_amd import ops
-        self._orig = (ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal)
+        self._orig = (ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal, ops.gemm_tn_bf16)
         t = self
 
         def ev():
@@ -140,11 +140,18 @@ class OpTimer:
             by = B * T * H * 64 * (3 * q.element_size() + out.element_size())             # q, k, v read once, o written once
             t.attn.append((e0, e1, 4.0 * H * 64 * L * L * pairs * B, arm, (B, H, T, L, twin_view), dma, by))
             return r
-        ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal = igemm, vqf, vqe, attn
+        def gemm_tn(x16, dy, M, K, N, dw, db=None, accumulate=True):          # the training step's weight-gradient GEMM (+ its slab sums)
+            e0, e1 = ev()
+            e0.record()
+            r = t._orig[4](x16, dy, M, K, N, dw, db, accumulate)
+            e1.record()
+            t.gemm.append((e0, e1, 2.0 * M * K * N, ('tn', M, K, N, 1)))
+            return r
+        ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal, ops.gemm_tn_bf16 = igemm, vqf, vqe, attn, gemm_tn
 
     def uninstall(self):
         from viewformer_amd import ops
-        ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal = self._orig
+        ops.igemm, ops.vq_argmin_filtered, ops.vq_argmin, ops.attn_blockcausal, ops.gemm_tn_bf16 = self._orig
 
     def gemm_summary(self):
         torch.cuda.synchronize()
@@ -299,7 +306,7 @@ def run_train(args, rank, local, world, dev):
                        'precision': ('fp32 master weights, bf16-MFMA dense GEMMs (the reference trains with --fp16)' if arm == 'bf16' else
                                      'fp32-equivalent: x3h forward GEMMs, x6 backward GEMMs, x6 / f32 attention'),
                        'weights': 'random-init MIGT 88.4M', 'loss': float(met['loss']), 'collective': comm},
-            'roofline': {'bound': 'mfma', 'kernel': 'dense GEMM family of the step (gemm_x3h / gemm_x6 / gemm_bf16 launches: forward, dX, dW)',
+            'roofline': {'bound': 'mfma', 'kernel': 'dense GEMM family of the step (gemm_bf16 / gemm_bf16_g256 / gemm_tn_bf16 or gemm_x3h / gemm_x6 launches: forward, dX, dW incl. its slab sums)',
                          'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                          'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': n,
                          'kernel_ms_per_step': round(ms, 3), 'algorithmic_gflop_per_step': round(fl / 1e9, 1),
