@@ -190,6 +190,8 @@ class OpTimer:
                 'f32': 'attn_blockcausal_kernel'}[arm]
         if dma:
             name = 'attn_dma_kernel (bf16 q/k/v tiles by LDS-DMA, 3 in flight)'
+            if 64 < shape[2] <= 512 and os.environ.get('VF_ATTN_RES') == '1':
+                name = 'attn_res_kernel (K / V of a (scene, head) resident in LDS by LDS-DMA, equal work per wave, one barrier)'
         return {'kernel': name, 'bound': 'mfma', 'launches': len(self.attn),
                 'B_H_T_L_twin': list(shape), 'avg_launch_us': round(ms / len(self.attn) * 1e3, 1),
                 'achieved': round(fl / ms / 1e9, 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s (useful: visible tile pairs only)',

@@ -233,6 +233,29 @@ def test_attention_dma_8_wave_form_is_bit_identical_to_the_4_wave_form(dev, B, H
     assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
 
 
+@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 8, 'causal'), (1, 3, 7, 'causal'), (2, 1, 2, 'causal'), (1, 2, 3, 'twin'), (2, 2, 5, 'twin'),
+                                        (1, 1, 2, 'streams'), (4, 12, 8, 'twin')])
+def test_attention_resident_form_is_bit_identical_to_the_ring_kernel(dev, B, H, S, mode, monkeypatch):
+    """the resident kernel (attn_res_kernel: K / V of a (scene, head) in LDS behind one barrier, wave = 32 queries of view p and of view
+    nviews - 1 - p; opt-in, VF_ATTN_RES=1, for 2 .. 8 views — measured slower than the ring kernel) against the 4-wave ring kernel (VF_ATTN_RES=0): the same per-query arithmetic, the same bits.
+    Even and odd view counts (the middle view of an odd count has no partner), every mask mode that fits 8 views, the bench's twin shape."""
+    from viewformer_amd import ops
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    assert T <= 512
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    q16 = _rand((B * T, 3 * d), 95, 0.35).to(dev).to(torch.bfloat16)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VF_ATTN_RES', flag)
+        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
+        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        outs[flag] = out
+    assert not torch.isnan(outs['1'].float()).any()
+    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
+
+
 def test_bf16_activation_chain_is_bit_identical(dev):
     """LayerNorm / GELU / attention outputs written as bf16 by their producers and read as bf16 by the GEMMs (a16 / o16): the same
     rounding the GEMM applies to an fp32 operand on load, so everything downstream is bit-identical — kernel by kernel and for the

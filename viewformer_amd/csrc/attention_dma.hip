@@ -57,9 +57,8 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     const int half = lane >> 5, l31 = lane & 31;
     // grid (H, B, query blocks): all first blocks (4 key tiles), then all second blocks (8) — measured faster than interleaving the two
     // kinds on a CU (145 us) although the second kind re-reads tiles 0-3 from HBM; ADMA_HEAVY_FIRST flips the order
-    const int nqb = (T + QT - 1) / QT;
 #ifdef ADMA_HEAVY_FIRST
-    const int qblk = nqb - 1 - (int)blockIdx.z;
+    const int qblk = (T + QT - 1) / QT - 1 - (int)blockIdx.z;
 #else
     const int qblk = (int)blockIdx.z;
 #endif
@@ -532,6 +531,211 @@ __global__ __launch_bounds__(512, 1) void attn_dma8_kernel(const __bf16* __restr
     }
 }
 
+
+// ---- resident form: K / V of a whole (scene, head) in LDS, equal work per wave, ONE barrier ----------------------------------------
+// What the 8-wave record above showed is that the bytes were not the problem, the lockstep was: under the block-causal mask view w has
+// w + 1 key tiles of work, so a workgroup that walks the tiles together waits for its last view at every step.  Here (<= 8 views, i.e.
+// T <= 512: the evaluator's 6-context-view scenes incl. the fused twin pass) the 8 waves of a workgroup first move the (scene, head)'s
+// K / V into LDS — all 8 tiles, 128 KB, every byte fetched once — behind a single vmcnt(0) + barrier, and then never synchronise again:
+// wave (p, hq) owns queries 32 hq .. 32 hq + 31 of view p AND of view nviews - 1 - p, so every wave has the same number of
+// (32-query, 64-key) units (9 of 36 per pair at 8 views) and walks its tiles at its own pace.  K fragments are shared by the two views
+// of a wave where both see the tile.  Per-query arithmetic (tile order, MFMA sequence, fp32 online softmax) is the 4-wave kernel's, so
+// results are bit-identical to it.  Q comes straight from global memory as B fragments; O leaves through 2 KB of LDS per wave as
+// whole 128-byte rows, 16 rows at a time.
+// MEASURED (round 3, bench shape): 188.5 us against the ring kernel's 130.7 us, bit-identical outputs.  Equal work and no barriers did not
+// help, because splitting a view's 64 queries over two waves halves what a K / V^T fragment feeds: a wave's second view sees most of its
+// tiles alone, so there one LDS fragment read serves one MFMA instead of two, and the (load everything, then compute) order leaves the
+// memory pipe idle while the single workgroup of a CU computes (6 x ~5 us of exposed loads per CU).  Together with the 8-wave record
+// above this says where the ring kernel's time is: ~3300 SIMD cycles per (64-query, 64-key) unit against 1024 of MFMA and ~1600 of
+// softmax VALU work — dependency stalls inside a wave (S MFMAs -> softmax -> P.V MFMAs, two waves per SIMD), not bytes and not balance.
+// The form left to try keeps the ring kernel and issues tile t + 1's S MFMAs before tile t's softmax (one more score set in registers).
+constexpr int RES_TILES = 8, RES_OS = 2048;
+
+__global__ __launch_bounds__(512, 1) void attn_res_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                          const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq, int ldk,
+                                                          int ldv, int ldo, float scale, int twin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RES_TILES x (K image | V image), then 8 x RES_OS of O staging
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x;
+    const size_t b = blockIdx.y;
+    const int nviews = T / KT;                                       // <= 8 (launcher)
+
+    const unsigned char* kb8 = reinterpret_cast<const unsigned char*>(k + b * (size_t)T * ldk + h * DH);
+    const unsigned char* vb8 = reinterpret_cast<const unsigned char*>(v + b * (size_t)T * ldv + h * DH);
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(kb8), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(vb8), 0, 0x7fffffff, 0x00020000);
+
+    const int Vc = twin >= 0 ? twin : 0x3fffffff;
+    const int Sv = twin <= -2 ? -twin : 0;
+    auto visible = [&](int qv, int kv) {
+        if (Sv > 0) {
+            const int qs = qv / Sv, qi = qv - qs * Sv;
+            const int ks = kv / Sv, ki = kv - ks * Sv;
+            return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+        }
+        return kv == qv || min(kv, Vc) < min(qv, Vc);
+    };
+
+    // this wave's two query blocks: view p (few key tiles) and view nviews - 1 - p (many)
+    const int p = wave & 3, hq = wave >> 2;
+    const int vw[2] = {p, nviews - 1 - p};
+    const bool act[2] = {p < (nviews + 1) / 2, p < nviews / 2};      // (odd view count: the middle view is block 0 of its wave only)
+
+    // Q fragments straight from global memory (B operand of S^T = K.Q^T): Q[64 view + 32 hq + l31][16 ks + 8 half + 0..7]
+    bf16x8 qb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = act[u] ? vw[u] * KT + hq * 32 + l31 : 0;
+        const __bf16* qs = q + (b * (size_t)T + row) * ldq + h * DH + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qb[u][ks] = *reinterpret_cast<const bf16x8*>(qs + 16 * ks);
+    }
+    // K / V: every wave moves one 1 KB piece of K and one of V of every tile (as the 8-wave kernel), all in flight at once
+    const int pr = lane >> 3, pc = lane & 7;
+    for (int t = 0; t < nviews; ++t) {
+        unsigned char* dst = smem + t * TILE_BYTES;
+        const int r = wave * 8 + pr;
+        bufds16(k_rs, dst + wave * 1024, (unsigned)(r * ldk * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), (unsigned)(t * KT * ldk * 2));
+        const int key = (wave & 3) * 16 + (lane >> 2);
+        bufds16(v_rs, dst + K_BYTES + wave * 1024, (unsigned)(key * ldv * 2 + (wave >> 2) * 64 + (lane & 3) * 16), (unsigned)(t * KT * ldv * 2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // the (scene, head)'s K / V are resident: no synchronisation from here on
+
+    f32x16 ot[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[u][d][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = scale * LOG2E;
+    const unsigned swz = (unsigned)((l31 >> 1) & 7);
+    const unsigned k_off = (unsigned)(l31 * 128);
+    const unsigned v_off = (unsigned)(K_BYTES + (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+
+    for (int kt = 0; kt < nviews; ++kt) {
+        const bool on[2] = {act[0] && visible(vw[0], kt), act[1] && visible(vw[1], kt)};     // wave-uniform
+        if (!on[0] && !on[1]) continue;
+        const unsigned char* tile = smem + kt * TILE_BYTES;
+
+        f32x16 st[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][t2][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + k_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (on[u]) st[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[u][ks], st[u][t2], 0, 0, 0);
+            }
+
+        bf16x8 pb[2][2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!on[u]) continue;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[u][t2][r]), st[u][t2][r + 1]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx * scale);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * LOG2E);
+            const float mc = m_new * LOG2E;
+            float psum = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t2][ks2 * 8 + e], c2, -mc));
+                        psum += pe;
+                        pk[e] = (__bf16)pe;
+                    }
+                    pb[u][t2][ks2] = pk;
+                }
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[u][d][r] *= alpha;
+            }
+        }
+
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned char* vp = tile + v_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64;
+                    const bf16x4 v0 = tr_read(vp);
+                    const bf16x4 v1 = tr_read(vp + 8 * 64);
+                    bf16x8 va;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = v0[e]; va[4 + e] = v1[e]; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (on[u]) ot[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[u][t2][ks2], ot[u][d], 0, 0, 0);
+                }
+    }
+
+    // ---- normalise, round, 16 rows at a time through the wave's 2 KB, store whole 128-byte rows
+    unsigned char* Os = smem + RES_TILES * TILE_BYTES + wave * RES_OS;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!act[u]) continue;
+        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        __bf16* __restrict__ ob = out + (b * (size_t)T + vw[u] * KT + hq * 32) * ldo + h * DH;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if ((l31 >> 4) == part) {
+                const int row = l31 & 15;
+                const unsigned sw = (unsigned)((l31 >> 1) & 7);
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (__bf16)(ot[u][d][4 * j + e] / l_tot);
+                        *reinterpret_cast<bf16x4*>(Os + row * 128 + ((((unsigned)(d * 4 + j)) ^ sw) << 4) + 8 * half) = o4;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + pr;                             // 0 .. 15 within the part
+                const int qrow = part * 16 + row;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(Os + row * 128 + pc * 16);
+                const int c = pc ^ ((qrow >> 1) & 7);
+                *reinterpret_cast<f32x4*>(ob + (size_t)qrow * ldo + c * 8) = val;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 }  // namespace
 
 // Launcher used by vf_attn_blockcausal_bf16_v2 (attention_lp.hip).  VF_ERR_UNSUPPORTED when the call does not qualify (the caller then
@@ -546,6 +750,22 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
+    }
+    // <= 8 views: the resident form (K / V of the (scene, head) in LDS, equal work per wave, one barrier) is OPT-IN (VF_ATTN_RES=1): measured
+    // SLOWER at the bench shape, 188.5 vs 130.7 us per launch inside the step (gpurun_out r3h) — see the note above attn_res_kernel
+    const char* er = getenv("VF_ATTN_RES");
+    if (T <= RES_TILES * KT && T > KT && !lse_out && er && er[0] == '1') {
+        static unsigned long long attr_res_devs = 0;
+        constexpr int RES_SMEM = RES_TILES * TILE_BYTES + 8 * RES_OS;
+        if (vf_attr_needed(&attr_res_devs)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RES_SMEM);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(&attr_res_devs);
+        }
+        hipLaunchKernelGGL(attn_res_kernel, dim3((unsigned)H, (unsigned)B), dim3(512), (size_t)RES_SMEM, stream, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk,
+                           ldv, ldo, scale, twin_view);
+        return vf_last_status();
     }
     // the 8-wave form (every K / V tile fetched once per 8 query views) is OPT-IN (VF_ATTN_DMA8=1): measured SLOWER at the bench shape — 176.9
     // vs 131.9 us per launch inside the step (gpurun_out r3c) — see the note above attn_dma8_kernel
