@@ -401,8 +401,8 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
  * w_slabs[s][K][N] = sum_m x[m][k] * dy[m][n] and (b_slabs != NULL) b_slabs[s][N] = sum_m dy[m][n], with x a saved bf16 activation
  * [M][ldx] and dy the fp32 gradient [M][ldy], both read as they lie (no transposed copy, no packed copy, no separate column-sum pass).
  * Fold the slabs with vf_sum_slabs_f32 (fixed order).  K % 256 == N % 256 == M % 64 == 0; autograd of Conv1D.call (migt.py:89-96). */
-int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const float* dy, int ldy, int M, int K, int N, int splits, float* w_slabs,
-                    float* b_slabs, void* stream);
+int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16, int ldy, int M, int K, int N, int splits, float* w_slabs,
+                    float* b_slabs, void* stream);      /* dy_is_bf16: the gradient arrives already rounded to bf16 (ldy in elements) */
 /* bf16 arm of the training step's attention (csrc/attention_dma.hip, attention_train_bf16.hip): bf16 q / k / v / out / dout in HBM
  * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views, no attention dropout — VF_ERR_UNSUPPORTED
  * otherwise (callers then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the
@@ -412,9 +412,9 @@ int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const float* dy, int ldy, int M
 int vf_attn_blockcausal_bf16_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int T, int L,
                                  int ldq, int ldk, int ldv, int ldo, float scale, int twin_view, void* stream);
 int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
-int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, float* dq, float* dk,
-                     float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale,
-                     int twin_view, void* stream);
+int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, void* dq, void* dk,
+                     void* dv, int out_bf16 /* gradients written as bf16 (ldd* in elements) instead of fp32 */, int B, int H, int T, int L,
+                     int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale, int twin_view, void* stream);
 /* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403): out = keep ? x/(1-rate) : 0 [+ res],
  * keep = vf_dropout_hash(seed, site, flat index) >= floor(rate * 2^32); applying it to a gradient gives the backward */
 int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
@@ -432,12 +432,14 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 /* LayerNormalization backward (migt.py:225,227,292): dx, and dgamma/dbeta (+)= */
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d);
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                         int64_t rows, int d, float eps, int accumulate, void* ws, void* stream);
+                         int64_t rows, int d, float eps, int accumulate, const float* res /* NULL or [rows][d]: dx += res */, void* ws,
+                         void* stream);
 /* exact-erf GELU (tf.nn.gelu, migt.py:13,70) forward on a saved pre-activation, and its backward */
 int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream);
 /* the same value rounded to bf16 on the way out (the bf16 training arm saves the MLP hidden as its next GEMM reads it) */
 int vf_gelu_bf16out_f32(const float* u, void* f_bf16, int64_t n, void* stream);
 int vf_gelu_bwd_f32(const float* u, const float* df, float* du, int64_t n, void* stream);
+int vf_gelu_bwd_bf16out_f32(const float* u, const float* df, void* du_bf16, int64_t n, void* stream);
 /* materialised attention probabilities for the backward pass: s[b][q][k] -> softmax(s*scale masked with -1e4) in
  * place (branching_attention.py:5-18,101-117; mask_spec as vf_attn_blockcausal_f32's twin_view), and
  * dS = P*(dP - sum dP*P)*scale (zero where masked) in place on dp */

@@ -576,6 +576,11 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
         errs[name] = ((got[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max()).item()
         assert errs[name] < ATTN_BF16_BWD_TOL, (name, errs)
     print(f'bf16 training attention {mode} B={B} H={H} S={S}: fwd {e_fwd:.2e} lse {e_lse:.2e} bwd {errs}')
+    # gradients written as bf16 (the c_attn GEMMs' operand format): the fp32 result rounded once
+    got16 = torch.full((B * Tn, 3 * d), float('nan'), dtype=torch.bfloat16, device=dev)
+    T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got16[:, d:2 * d], got16[:, 2 * d:], got16[:, :d],
+                    B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)
+    assert torch.equal(got16, got.to(torch.bfloat16))
     # deterministic
     got2 = torch.empty_like(got)
     T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got2[:, d:2 * d], got2[:, 2 * d:], got2[:, :d],
@@ -649,6 +654,13 @@ def test_tn_weight_gradient_gemm(dev, M, K, N):
     dw2, db2 = dw0.clone(), db0.clone()
     ops.gemm_tn_bf16(x16, dy, M, K, N, dw2, db2)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)                        # deterministic
+    # the gradient arriving already rounded to bf16 (its producer wrote the rounding this kernel applies): the same products in the
+    # same order -> the same dW bit for bit; db becomes the sum of the rounded values
+    dw3, db3 = dw0.clone(), db0.clone()
+    ops.gemm_tn_bf16(x16, dy.to(torch.bfloat16), M, K, N, dw3, db3)
+    assert torch.equal(dw3, dw)
+    ref_b16 = dy.to(torch.bfloat16).double().sum(0)
+    assert ((db3.double() - db0.double() - ref_b16).abs().max() / ref_b16.abs().max()).item() < 2e-5
     if M % 128 == 0:                                                            # the replaced path, same operands
         xt = T.transpose(x16, M, K)
         old = torch.zeros((K, N), device=dev)

@@ -88,10 +88,10 @@ EXPORTS = {
     'vf_attn_bwd_prep_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
-    'vf_gemm_tn_bf16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    'vf_gemm_tn_bf16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     'vf_attn_blockcausal_bf16_lse': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'vf_attn_bwd_prep_bf16': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'vf_attn_bwd_bf16': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    'vf_attn_bwd_bf16': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_int, P]),
     'vf_attn_spatial_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
     'vf_attn_spatial_x3h': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
@@ -131,9 +131,10 @@ EXPORTS = {
     'vf_colsum_workspace_bytes': (c_size_t, [c_int]),
     'vf_colsum_f32': (c_int, [P, P, c_int64, c_int, c_int64, c_int, P, P]),
     'vf_layernorm_bwd_workspace_bytes': (c_size_t, [c_int64, c_int]),
-    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P]),
+    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, P]),
     'vf_gelu_f32': (c_int, [P, P, c_int64, P]),
     'vf_gelu_bf16out_f32': (c_int, [P, P, c_int64, P]),
+    'vf_gelu_bwd_bf16out_f32': (c_int, [P, P, P, c_int64, P]),
     'vf_gelu_bwd_f32': (c_int, [P, P, P, c_int64, P]),
     'vf_softmax_mask_f32': (c_int, [P, c_int64, c_int, c_int, c_int, c_float, P]),
     'vf_softmax_mask_bwd_f32': (c_int, [P, P, c_int64, c_int, c_int, c_int, c_float, P]),

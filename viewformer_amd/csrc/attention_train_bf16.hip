@@ -130,13 +130,40 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], unsigne
     __builtin_amdgcn_wave_barrier();
 }
 
+// the same as bf16 rows (the gradient's consumers — the c_attn dX and dW GEMMs of the bf16 arm — round it to bf16 on load anyway):
+// 32 rows x 128 B through the wave's LDS, 16-byte chunk c stored at c ^ (row & 7)
+__device__ __forceinline__ void store_transposed_bf16(const f32x16 (&acc)[2], unsigned char* Os, __bf16* __restrict__ dst, int ld, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[d][4 * j + e];
+            const int c = 4 * d + j;                                              // features 8 c .. 8 c + 7; this half: + 4 half .. + 3
+            *reinterpret_cast<bf16x4*>(Os + l31 * 128 + ((c ^ (l31 & 7)) << 4) + 8 * half) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), cp = lane & 7;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(Os + row * 128 + (cp << 4));
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * ld + ((cp ^ (row & 7)) << 3)) = val;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------------------------- dQ
 constexpr int DQ_SLOT = 3 * IMG, DQ_RING = 3, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
 
+template <bool O16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                   const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                                  float* __restrict__ dq, int H, int T, int ldq, int ldk, int ldv, int lddo,
+                                                                  void* __restrict__ dq, int H, int T, int ldq, int ldk, int ldv, int lddo,
                                                                   int lddq, float scale, int twin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,16 +278,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
     if (!active) return;
-    store_transposed(ot, smem + wave * 8192, dq + (b * (size_t)T + qw0) * lddq + h * DH, lddq, lane);
+    if constexpr (O16) store_transposed_bf16(ot, smem + wave * 8192, reinterpret_cast<__bf16*>(dq) + (b * (size_t)T + qw0) * lddq + h * DH, lddq, lane);
+    else store_transposed(ot, smem + wave * 8192, reinterpret_cast<float*>(dq) + (b * (size_t)T + qw0) * lddq + h * DH, lddq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
 constexpr int KV_SLOT = 4 * IMG + 512, KV_RING = 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
 
+template <bool O16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                    const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                                   float* __restrict__ dk, float* __restrict__ dv, int H, int T, int ldq, int ldk,
+                                                                   void* __restrict__ dk, void* __restrict__ dv, int H, int T, int ldq, int ldk,
                                                                    int ldv, int lddo, int lddk, int lddv, float scale, int twin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,8 +417,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     __builtin_amdgcn_s_barrier();
     if (!active) return;
     unsigned char* Os = smem + wave * 8192;
-    store_transposed(dkacc, Os, dk + (b * (size_t)T + kw0) * lddk + h * DH, lddk, lane);
-    store_transposed(dvacc, Os, dv + (b * (size_t)T + kw0) * lddv + h * DH, lddv, lane);
+    if constexpr (O16) {
+        store_transposed_bf16(dkacc, Os, reinterpret_cast<__bf16*>(dk) + (b * (size_t)T + kw0) * lddk + h * DH, lddk, lane);
+        store_transposed_bf16(dvacc, Os, reinterpret_cast<__bf16*>(dv) + (b * (size_t)T + kw0) * lddv + h * DH, lddv, lane);
+    } else {
+        store_transposed(dkacc, Os, reinterpret_cast<float*>(dk) + (b * (size_t)T + kw0) * lddk + h * DH, lddk, lane);
+        store_transposed(dvacc, Os, reinterpret_cast<float*>(dv) + (b * (size_t)T + kw0) * lddv + h * DH, lddv, lane);
+    }
 }
 
 }  // namespace
@@ -405,33 +439,40 @@ int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, in
     return vf_last_status();
 }
 
-int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, float* dq, float* dk,
-                     float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale,
-                     int twin_view, void* stream) {
+int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, void* dq, void* dk,
+                     void* dv, int out_bf16, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv,
+                     float scale, int twin_view, void* stream) {
     if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
     if (L != KT || T % KT != 0 || T / KT > 64) return VF_ERR_UNSUPPORTED;                     // 64-token views, at most 64 of them (tile bit masks)
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || lddo < H * DH || lddq < H * DH || lddk < H * DH || lddv < H * DH) return VF_ERR_BAD_ARG;
-    if (((ldq | ldk | ldv | lddo) & 7) || ((lddq | lddk | lddv) & 3)) return VF_ERR_BAD_ARG;
+    if (((ldq | ldk | ldv | lddo) & 7) || ((lddq | lddk | lddv) & (out_bf16 ? 7 : 3))) return VF_ERR_BAD_ARG;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) return VF_ERR_UNSUPPORTED;
     const size_t ldmax = (size_t)(ldq > ldk ? ldq : ldk) > (size_t)(ldv > lddo ? ldv : lddo) ? (size_t)(ldq > ldk ? ldq : ldk) : (size_t)(ldv > lddo ? ldv : lddo);
     if ((size_t)T * ldmax * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;                     // 32-bit buffer offsets per (scene, head)
     static unsigned long long attr_devs = 0;
     if (vf_attr_needed(&attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
+        hipError_t e = hipSuccess;
+        for (const void* f : {reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<false>), reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<true>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
+        for (const void* f : {reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<false>), reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<true>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, reinterpret_cast<const __bf16*>(q),
-                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const __bf16*>(dout), lse, D, dq,
-                       H, T, ldq, ldk, ldv, lddo, lddq, scale, twin_view);
+    const __bf16 *q_ = reinterpret_cast<const __bf16*>(q), *k_ = reinterpret_cast<const __bf16*>(k), *v_ = reinterpret_cast<const __bf16*>(v),
+                 *do_ = reinterpret_cast<const __bf16*>(dout);
+    if (out_bf16) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<true>, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
+                                     ldv, lddo, lddq, scale, twin_view);
+    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<false>, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk, ldv,
+                            lddo, lddq, scale, twin_view);
     int st = vf_last_status();
     if (st) return st;
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, reinterpret_cast<const __bf16*>(q),
-                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const __bf16*>(dout), lse, D, dk,
-                       dv, H, T, ldq, ldk, ldv, lddo, lddk, lddv, scale, twin_view);
+    if (out_bf16) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<true>, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
+                                     ldk, ldv, lddo, lddk, lddv, scale, twin_view);
+    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<false>, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq, ldk,
+                            ldv, lddo, lddk, lddv, scale, twin_view);
     return vf_last_status();
 }
 

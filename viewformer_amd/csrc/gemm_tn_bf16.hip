@@ -41,7 +41,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
     return a;
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __restrict__ x, const float* __restrict__ dy,
+// Y16: dY arrives as bf16 (its producer — gelu_bwd, the attention backward — wrote the rounding this kernel would apply): it takes the DMA
+// path of X, and the bias sums are read back from the landed LDS image instead of the staging registers.
+template <bool Y16>
+__global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __restrict__ x, const void* __restrict__ dy_,
                                                               float* __restrict__ w_slabs, float* __restrict__ b_slabs, int M, int K, int N,
                                                               int ldx, int ldy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x (X image | dY image)
@@ -56,7 +59,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 
     const __bf16* xb = x + (size_t)tk * TK;
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(xb), 0, 0x7fffffff, 0x00020000);
-    const float* dyb = dy + (size_t)tn * TN_;
+    const float* dyb = reinterpret_cast<const float*>(dy_) + (size_t)tn * TN_;                          // (!Y16)
+    const __bf16* dyb16 = reinterpret_cast<const __bf16*>(dy_) + (size_t)tn * TN_;                      // (Y16)
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(dyb16), 0, 0x7fffffff, 0x00020000);
 
     // X: wave w moves column block w (32 columns) of the chunk: 4 pieces of 16 rows x 64 B
     auto issue_x = [&](int stage, int chunk) {
@@ -67,22 +72,42 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
     };
     // dY: thread -> column quad nq (this wave reads whole 1 KB rows), rows mg + 8 j
     const int nq = tid & 63, mg = tid >> 6;
-    f32x4 yreg[8];
-    auto load_y = [&](int chunk) {
-        const float* src = dyb + (size_t)(chunk * CM + mg) * ldy + nq * 4;
+    f32x4 yreg[Y16 ? 1 : 8];
+    auto load_y = [&](int stage, int chunk) {
+        if constexpr (Y16) {                                          // the X path: wave w moves column block w, 4 pieces of 16 rows x 64 B
+            unsigned char* img = smem + stage * STAGE + IMG + wave * 4096;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) yreg[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(8 * j) * ldy);
+            for (int g = 0; g < 4; ++g)
+                bufds16(y_rs, img + g * 1024, (unsigned)((g * 16 + (lane >> 2)) * ldy * 2 + wave * 64 + (lane & 3) * 16), (unsigned)(chunk * CM * ldy * 2));
+        } else {
+            const float* src = dyb + (size_t)(chunk * CM + mg) * ldy + nq * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yreg[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(8 * j) * ldy);
+        }
     };
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    auto park_y = [&](int stage) {
-        unsigned char* img = smem + stage * STAGE + IMG + (nq >> 3) * 4096 + (nq & 7) * 8;
+    auto park_y = [&](int stage) {                                    // (!Y16) registers -> bf16 image, column sums on the way
+        if constexpr (!Y16) {
+            unsigned char* img = smem + stage * STAGE + IMG + (nq >> 3) * 4096 + (nq & 7) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bsum += yreg[j];
-            bf16x4 o;
+            for (int j = 0; j < 8; ++j) {
+                bsum += yreg[j];
+                bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)yreg[j][e];
-            *reinterpret_cast<bf16x4*>(img + (mg + 8 * j) * 64) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)yreg[j][e];
+                *reinterpret_cast<bf16x4*>(img + (mg + 8 * j) * 64) = o;
+            }
+        }
+    };
+    auto sum_y = [&](int stage) {                                     // (Y16) column sums of the landed image: this thread's 8 rows x 4 columns
+        if constexpr (Y16) {
+            const unsigned char* img = smem + stage * STAGE + IMG + (nq >> 3) * 4096 + (nq & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(img + (mg + 8 * j) * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += (float)t[e];
+            }
         }
     };
 
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 
     if (c0 < c1) {
         issue_x(0, c0);
-        load_y(c0);
+        load_y(0, c0);
         park_y(0);
     }
     for (int c = c0; c < c1; ++c) {
@@ -108,8 +133,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
         const bool more = c + 1 < c1;
         if (more) {
             issue_x(st ^ 1, c + 1);
-            load_y(c + 1);
+            load_y(st ^ 1, c + 1);
         }
+        if (b_slabs && tk == 0) sum_y(st);
         const unsigned char* sx = smem + st * STAGE;
         const unsigned char* sy = sx + IMG;
 #pragma unroll
@@ -158,22 +184,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 
 extern "C" {
 
-int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const float* dy, int ldy, int M, int K, int N, int splits, float* w_slabs,
+int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16, int ldy, int M, int K, int N, int splits, float* w_slabs,
                     float* b_slabs, void* stream) {
     if (!x_bf16 || !dy || !w_slabs || M <= 0 || K <= 0 || N <= 0 || splits < 1) return VF_ERR_BAD_ARG;
     if (ldx < K || ldy < N) return VF_ERR_BAD_ARG;
-    if (K % TK || N % TN_ || M % CM || (ldx & 7) || (ldy & 3) || splits > M / CM) return VF_ERR_UNSUPPORTED;
+    if (K % TK || N % TN_ || M % CM || (ldx & 7) || (ldy & (dy_is_bf16 ? 7 : 3)) || splits > M / CM) return VF_ERR_UNSUPPORTED;
     if (((uintptr_t)x_bf16 | (uintptr_t)dy | (uintptr_t)w_slabs) & 15) return VF_ERR_UNSUPPORTED;
-    if ((size_t)M * ldx * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;                    // 32-bit buffer offsets
+    if ((size_t)M * ldx * 2 >= (1ull << 31) || (dy_is_bf16 && (size_t)M * ldy * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     static unsigned long long attr_devs = 0;
     if (vf_attr_needed(&attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
     }
     const dim3 grid((unsigned)((K / TK) * (N / TN_)), (unsigned)splits);
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
-                       w_slabs, b_slabs, M, K, N, ldx, ldy);
+    if (dy_is_bf16)
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
+                           w_slabs, b_slabs, M, K, N, ldx, ldy);
+    else
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
+                           w_slabs, b_slabs, M, K, N, ldx, ldy);
     return vf_last_status();
 }
 

@@ -101,7 +101,7 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgb_part, long long rows, int d, float eps,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, const float* __restrict__ res) {
     // each wave walks rows_per_block/4 rows and keeps per-lane dgamma/dbeta partials in registers
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -160,6 +160,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[i][e] - sg - xv[i][e] * sgx);
+                if (res) {                                      // the residual branch's gradient joins here (was a separate add pass)
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + row * d + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                }
                 *reinterpret_cast<f32x4*>(dx + row * d + c * 4) = o;
             }
         }
@@ -191,6 +196,14 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
         const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
         const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
         du[i] = df[i] * (cdf + x * pdf);
+    }
+}
+__global__ void gelu_bwd_bf16out_kernel(const float* __restrict__ u, const float* __restrict__ df, __bf16* __restrict__ du, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = u[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        du[i] = (__bf16)(df[i] * (cdf + x * pdf));             // the rounding both consumers (dX and dW GEMMs of the bf16 arm) applied on load
     }
 }
 
@@ -534,15 +547,15 @@ size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
 }
 
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                         int64_t rows, int d, float eps, int accumulate, void* ws, void* stream) {
+                         int64_t rows, int d, float eps, int accumulate, const float* res, void* ws, void* stream) {
     if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !ws || rows <= 0 || d <= 0) return VF_ERR_BAD_ARG;
     if ((d & 3) || d > 1024) return VF_ERR_UNSUPPORTED;
     const int rpb = 64;
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
-    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
-    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb);
+    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
     int st = vf_last_status();
     if (st) return st;
     // partial layout [blocks*4][2][d]: reduce the (blocks*4) rows of the [.., 2d] matrix
@@ -554,6 +567,14 @@ int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, fl
     if (st) return st;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv, dgamma, d, 1, accumulate);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv + d, dbeta, d, 1, accumulate);
+    return vf_last_status();
+}
+
+int vf_gelu_bwd_bf16out_f32(const float* u, const float* df, void* du_bf16, int64_t n, void* stream) {
+    if (!u || !df || !du_bf16 || n < 0) return VF_ERR_BAD_ARG;
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(gelu_bwd_bf16out_kernel, dim3(grid1(n, 256)), dim3(256), 0, (hipStream_t)stream, u, df, reinterpret_cast<__bf16*>(du_bf16),
+                       (long long)n);
     return vf_last_status();
 }
 

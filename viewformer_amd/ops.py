@@ -227,7 +227,9 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
     splits = max(1, min(M // 64, 256 // tiles if tiles <= 256 else 1))
     ws = torch.empty((splits, K, N), dtype=torch.float32, device=dy.device)
     bs = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if db is not None else None
-    check(lib.vf_gemm_tn_bf16(_p(x16), x16.stride(0), _p(_f32(dy)), dy.stride(0), M, K, N, splits, _p(ws), _p(bs), _stream()), 'vf_gemm_tn_bf16')
+    y16 = dy.dtype == torch.bfloat16
+    check(lib.vf_gemm_tn_bf16(_p(x16), x16.stride(0), _p(dy if y16 else _f32(dy)), 1 if y16 else 0, dy.stride(0), M, K, N, splits, _p(ws), _p(bs),
+                              _stream()), 'vf_gemm_tn_bf16')
     check(lib.vf_sum_slabs_f32(_p(ws), splits, K * N, K * N, _p(_f32(dw)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')
     if db is not None:
         check(lib.vf_sum_slabs_f32(_p(bs), splits, N, N, _p(_f32(db)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')

@@ -197,11 +197,13 @@ class MIGTTrainer:
         dn = self.model._dense[name]
         K, N = dn.k, dn.n
         bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
-        if bf16 and self.tn_weight_gradient and dy.dtype == torch.float32 and ops.gemm_tn_bf16_supported(x, M, K, N):
+        if bf16 and self.tn_weight_gradient and ops.gemm_tn_bf16_supported(x, M, K, N):
             # bf16 arm with a saved bf16 activation: dW and db in ONE pass over x and dy as they lie (csrc/gemm_tn_bf16.hip) — no widening
             # transpose of x, no packed bf16 copy of dy, no column-sum pass
             ops.gemm_tn_bf16(x, dy, M, K, N, self.g(name + '.weight'), self.g(name + '.bias'))
             return self._linear_dx(name, dy, M, res, dx_bf16) if need_dx else None
+        if dy.dtype != torch.float32:
+            raise RuntimeError('a bf16 gradient operand needs the TN weight-gradient path')
         T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
         Mp = (M + 31) // 32 * 32                                                     # reduction length padded to the K stage
         xt = None
@@ -245,7 +247,7 @@ class MIGTTrainer:
             raise RuntimeError('dx_bf16 needs the bf16 arm and no residual')
         dx = torch.empty((M, K), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dy.device)
         if bf16:
-            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, o16=dx_bf16)
+            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, a16=dy.dtype == torch.bfloat16, o16=dx_bf16)   # (bf16 dY: the 256-tile kernel)
         elif x6:
             ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
         else:
@@ -255,10 +257,11 @@ class MIGTTrainer:
             ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
-    def _ln_bwd(self, name, dy, x, M):
+    def _ln_bwd(self, name, dy, x, M, res=None):
         d = self.cfg.d_model
-        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d)
+        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res)
 
+    bf16_gradient_operands = True     # bf16 arm: gelu_bwd / attention backward write their gradients as bf16 (see train_step)
     tn_weight_gradient = True         # bf16 arm: dW / db of the wide layers straight from the row-major operands (False: transpose + pack + column sums)
     bf16_saved_activations = True     # bf16 arm: LayerNorm outputs / MLP hidden saved as bf16 (see train_step); False keeps them fp32 (same gradients)
     attention_arith = 'bf16'          # bf16 arm only: 'bf16' = attention forward / backward on the bf16 matrix pipe; 'f32' = the exact-f32 kernels
@@ -379,7 +382,12 @@ class MIGTTrainer:
         # SAVED AS bf16 by their producers (the rounding the GEMM applied on load before: identical products), so the forward GEMMs take
         # the 256-tile LDS-DMA kernel (bf16 A operand) and the saved activations halve; the backward reads them through the widening
         # transpose (dW) and never otherwise (LayerNorm / GELU backward use the fp32 h / u)
+        # ... and the two gradients only GEMMs read — d(MLP pre-activation) from the GELU backward, d(q | k | v) from the attention backward —
+        # are WRITTEN as bf16 by those kernels (again the rounding their consumers applied on load: identical dX / dW; the bias gradients
+        # become sums of the rounded values), so that dX takes the 256-tile kernel and the TN kernel moves half the bytes
+        grad16 = False
         act16 = attn16 and self.bf16_saved_activations and all(m._dense[f'h.0.{n}'].wp16 is not None for n in ('mlp.c_fc', 'mlp.c_proj'))
+        grad16 = act16 and self.bf16_gradient_operands and self.tn_weight_gradient
         for i in range(c.n_layer):
             p = f'h.{i}'
             n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d, out_bf16=act16)
@@ -491,19 +499,19 @@ class MIGTTrainer:
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
             df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
-            du = T.gelu_bwd(u, df)
+            du = T.gelu_bwd(u, df, out_bf16=grad16)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
-            dh_mid = T.add_(self._ln_bwd(p + '.ln_2', dn2, h_mid, M), dh)
+            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh)                  # (+ the residual branch's gradient, same pass)
             datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M,
                                     dx_bf16=attn16)
             if attn16:
-                dqkv = torch.empty((M, 3 * d), dtype=torch.float32, device=dev)
+                dqkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if grad16 else torch.float32, device=dev)
                 T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
                                 B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S)
             else:
                 dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
-            dh = T.add_(self._ln_bwd(p + '.ln_1', dn1, h_in, M), dh_mid)
+            dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid)
             saved[i] = None
             if overlap:                                                              # this layer's grads are final
                 handles.append(self._allreduce_range(*self.layer_ranges[i]))

@@ -45,12 +45,13 @@ def colsum(x, out, M, N, ld=None, accumulate=False):
     return out
 
 
-def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True):
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True, res=None):
+    """``res``: the residual branch's gradient, added to dx in the same pass (dx = LN'(dy) + res)"""
     lib = _lib.load()
     dx = torch.empty_like(x)
     ws = _ws(int(lib.vf_layernorm_bwd_workspace_bytes(rows, d)), x.device, 'lnbwd')
     check(lib.vf_layernorm_bwd_f32(_p(_f32(dy)), _p(_f32(x)), _p(_f32(gamma)), _p(dx), _p(dgamma), _p(dbeta), rows, d, eps,
-                                   1 if accumulate else 0, _p(ws), _stream()), 'vf_layernorm_bwd_f32')
+                                   1 if accumulate else 0, _p(_f32(res)) if res is not None else None, _p(ws), _stream()), 'vf_layernorm_bwd_f32')
     return dx
 
 
@@ -64,7 +65,11 @@ def gelu(u, out_bf16=False):
     return f
 
 
-def gelu_bwd(u, df):
+def gelu_bwd(u, df, out_bf16=False):
+    if out_bf16:
+        du = torch.empty(u.shape, dtype=torch.bfloat16, device=u.device)
+        check(_lib.load().vf_gelu_bwd_bf16out_f32(_p(_f32(u)), _p(_f32(df)), _p(du), u.numel(), _stream()), 'vf_gelu_bwd_bf16out_f32')
+        return du
     du = torch.empty_like(u)
     check(_lib.load().vf_gelu_bwd_f32(_p(_f32(u)), _p(_f32(df)), _p(du), u.numel(), _stream()), 'vf_gelu_bwd_f32')
     return du
@@ -194,13 +199,17 @@ def attn_fwd_lse_bf16(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, m
 
 
 def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0, mask_spec=-1):
-    """dQ, dK, dV (fp32, written in place; column views allowed) from bf16 q / k / v / out / dout on the bf16 matrix pipe"""
+    """dQ, dK, dV (fp32, or bf16 when the output tensors are bf16; written in place; column views allowed) from bf16 q / k / v / out / dout
+    on the bf16 matrix pipe"""
     lib = _lib.load()
     for t in (q, k, v, out, dout):
         _chk(t, torch.bfloat16)
     D = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(lib.vf_attn_bwd_prep_bf16(_p(dout), _p(out), _p(D), B, H, T, lddo, ldo, _stream()), 'vf_attn_bwd_prep_bf16')
-    check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(_f32(dq)), _p(_f32(dk)), _p(_f32(dv)), B, H, T, L, ldq, ldk,
+    o16 = dq.dtype == torch.bfloat16
+    for t in (dq, dk, dv):
+        _chk(t, torch.bfloat16 if o16 else torch.float32)
+    check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), 1 if o16 else 0, B, H, T, L, ldq, ldk,
                                ldv, lddo, lddq, lddk, lddv, scale, mask_spec, _stream()), 'vf_attn_bwd_bf16')
 
 
