@@ -256,6 +256,28 @@ def test_attention_resident_form_is_bit_identical_to_the_ring_kernel(dev, B, H, 
     assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
 
 
+@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 10, 'streams'), (1, 3, 7, 'causal'), (2, 1, 1, 'causal'), (1, 2, 21, 'twin'), (2, 2, 3, 'streams')])
+def test_attention_ring_kernel_software_pipelined_form_is_bit_identical(dev, B, H, S, mode, monkeypatch):
+    """attn_dma_kernel<5, true> (tile t's S MFMAs issued before tile t - 1's softmax + P.V, five ring slots; opt-in, VF_ATTN_PIPE=1: measured
+    slower — it spills) against <4, false>: the same
+    per-query arithmetic in the same order — identical bits — in every mask mode, with masked tiles in between (streams), one-view and
+    21-view sequences"""
+    from viewformer_amd import ops
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    T = NS * S * L
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    q16 = _rand((B * T, 3 * d), 97, 0.35).to(dev).to(torch.bfloat16)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VF_ATTN_PIPE', flag)
+        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
+        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        outs[flag] = out
+    assert not torch.isnan(outs['1'].float()).any()
+    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
+
+
 def test_bf16_activation_chain_is_bit_identical(dev):
     """LayerNorm / GELU / attention outputs written as bf16 by their producers and read as bf16 by the GEMMs (a16 / o16): the same
     rounding the GEMM applies to an fp32 operand on load, so everything downstream is bit-identical — kernel by kernel and for the

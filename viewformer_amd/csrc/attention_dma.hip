@@ -27,7 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DH = 64, KT = 64, QT = 256, RING = 4;
+constexpr int DH = 64, KT = 64, QT = 256;
 constexpr int K_BYTES = KT * DH * 2;         // 8192
 constexpr int TILE_BYTES = 2 * K_BYTES;      // K image then V image
 
@@ -46,10 +46,19 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
     return __builtin_bit_cast(bf16x4, r);
 }
 
+// PIPE (round 3): the wave's S^T MFMAs of tile t are issued BEFORE the softmax + P.V of tile t - 1 (one more score set in registers, a fifth
+// ring slot because tile t - 1's V image stays live one iteration longer): the two records below located the kernel's time in dependency
+// stalls inside a wave — S MFMAs -> softmax -> P.V MFMAs with two waves per SIMD — so the matrix pipe now works on the next tile's scores
+// while the vector ALU does this tile's exponentials.  Per-query arithmetic and order are unchanged: bit-identical to PIPE = false.
+// MEASURED: 273 us against 130 us — st_new + st_old + O^T + Q + P are 256 registers before any address arithmetic, the compiler spills 65,
+// and (the round-2 rule) spilled registers in the inner loop cost more than what they buy.  Kept as the third attention record of the
+// round; at two waves per SIMD this kernel has no registers left to pipeline with.
+template <int RINGN, bool PIPE>
 __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                           const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq, int ldk,
                                                           int ldv, int ldo, float scale, int twin, float* __restrict__ lse_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING x (K image | V image)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RINGN x (K image | V image)
+    constexpr int RING = RINGN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,33 +174,8 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
     // 32 d + 16 (g & 1) + 4 (i & 3) .. + 3 with i = lane & 15  ->  lane receives keys .. + 0..3 of feature 32 d + l31
     const unsigned v_off = (unsigned)(K_BYTES + (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
 
-    for (int kt = 0; kt < ntiles; ++kt) {
-        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
-        // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
-        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
-        if (last_issued - kt >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (last_issued - kt == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#ifdef ADMA_X_NODMA
-        if (kt == 0) { issue_tile(ntiles > 2 ? 2 : 0); issue_tile(ntiles > 3 ? 3 : 0); }
-        else if (kt + 3 < ntiles) { asm volatile("s_nop 0"); }
-#else
-        if (kt == 0) {
-            if (ntiles > 2) issue_tile(2);
-            if (ntiles > 3) issue_tile(3);
-        } else if (kt + 3 < ntiles) {
-            issue_tile(kt + 3);
-        }
-#endif
-#ifdef ADMA_X_NOCOMPUTE
-        continue;
-#endif
-        if (!active || !visible(qview, kt)) continue;                // masked for all 64 queries: contributes exactly 0.0f
-        const unsigned char* tile = smem + (kt % RING) * TILE_BYTES;
-
-        // ---- S^T = K . Q^T: each K fragment feeds both query tiles
-        f32x16 st[2][2];                                             // [query tile][key half]
+    // ---- S^T = K . Q^T of one tile: each K fragment feeds both query tiles
+    auto scores = [&](const unsigned char* tile, f32x16 (&st)[2][2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -207,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
                 for (int u = 0; u < 2; ++u) st[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[u][ks], st[u][t2], 0, 0, 0);
             }
 
+    };
+    // ---- online softmax + O^T += V^T . P^T of one tile
+    auto softmax_pv = [&](f32x16 (&st)[2][2], const unsigned char* tile) {
         // ---- online softmax (lane = one query of each tile; its 32 keys of this key tile per half-wave)
         bf16x8 pb[2][2][2];                                          // [query tile][key half][k-step]
 #pragma unroll
@@ -264,6 +251,56 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
 #pragma unroll
                     for (int u = 0; u < 2; ++u) ot[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[u][t2][ks2], ot[u][d], 0, 0, 0);
                 }
+    };
+    f32x16 st_old[2][2];
+    bool have_old = false;
+    int tile_old = 0;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
+        // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
+        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
+        if (last_issued - kt >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (last_issued - kt == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef ADMA_X_NODMA
+        if (kt == 0) { issue_tile(ntiles > 2 ? 2 : 0); issue_tile(ntiles > 3 ? 3 : 0); }
+        else if (kt + 3 < ntiles) { asm volatile("s_nop 0"); }
+#else
+        if (kt == 0) {
+            if (ntiles > 2) issue_tile(2);
+            if (ntiles > 3) issue_tile(3);
+        } else if (kt + 3 < ntiles) {
+            issue_tile(kt + 3);
+        }
+#endif
+#ifdef ADMA_X_NOCOMPUTE
+        continue;
+#endif
+        const bool vis = active && visible(qview, kt);               // (masked for all 64 queries: the tile contributes exactly 0.0f)
+        if constexpr (!PIPE) {
+            if (!vis) continue;
+            f32x16 st[2][2];                                         // [query tile][key half]
+            scores(smem + (kt % RING) * TILE_BYTES, st);
+            softmax_pv(st, smem + (kt % RING) * TILE_BYTES);
+        } else {
+            f32x16 st_new[2][2];
+            if (vis) scores(smem + (kt % RING) * TILE_BYTES, st_new);          // 16 MFMAs in flight ...
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_old) softmax_pv(st_old, smem + (tile_old % RING) * TILE_BYTES);   // ... under the previous visible tile's softmax + P.V
+            if (vis) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) st_old[u][t2] = st_new[u][t2];
+                tile_old = kt;
+            }
+            have_old = vis;
+        }
+    }
+    if constexpr (PIPE) {
+        if (have_old) softmax_pv(st_old, smem + (tile_old % RING) * TILE_BYTES);
     }
 
     // ---- normalise, round, transpose through the wave's slice of the (now idle) ring, store whole rows
@@ -747,7 +784,8 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     if ((size_t)T * (size_t)(ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv)) * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit offsets per (scene, head)
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
     if (vf_attr_needed(&attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING * TILE_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
     }
@@ -784,9 +822,17 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
         return vf_last_status();
     }
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
-    hipLaunchKernelGGL(attn_dma_kernel, grid, dim3(256), (size_t)RING * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
-                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk, ldv,
-                       ldo, scale, twin_view, lse_out);
+    // the software-pipelined form is OPT-IN (VF_ATTN_PIPE=1): measured 273 us against 130 us at the bench shape (gpurun_out r3k) — the second
+    // score set takes the kernel to 256 VGPRs with 65 spilled (two waves per SIMD leave no more), and the spills cost more than the stalls
+    const char* ep = getenv("VF_ATTN_PIPE");
+    if (!(ep && ep[0] == '1'))
+        hipLaunchKernelGGL((attn_dma_kernel<4, false>), grid, dim3(256), (size_t)4 * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk, ldv,
+                           ldo, scale, twin_view, lse_out);
+    else
+        hipLaunchKernelGGL((attn_dma_kernel<5, true>), grid, dim3(256), (size_t)5 * TILE_BYTES, stream, reinterpret_cast<const __bf16*>(q),
+                           reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<__bf16*>(out), H, T, ldq, ldk, ldv,
+                           ldo, scale, twin_view, lse_out);
     return vf_last_status();
 }
 
