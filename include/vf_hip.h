@@ -58,7 +58,10 @@ const char* vf_build_flag_name(int i);
  * the GroupNorm(32, eps 1e-6)+swish of vqgan_th.py:11-17,80-85,122,222-223,315-316.
  * ------------------------------------------------------------------------------------- */
 enum { VF_MODE_GEMM = 0, VF_MODE_CONV3_S1 = 1, VF_MODE_CONV3_S2PAD = 2, VF_MODE_CONV3_UP2 = 3 };
-enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1 };
+enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1,
+       VF_EPI_GELU_BWD = 2 };   /* vf_gemm_bf16 with bf16 output only: out = bf16(acc * gelu'(res[m][n])) — `res` carries the saved fp32
+                                   pre-activation, not a residual: the GELU backward of the training step inside the dX GEMM that
+                                   produces its input (migt.py:70 under autograd) */
 
 typedef struct vf_igemm_args {
     const float* x;          /* GEMM: [M][lda]; conv: NHWC [Nimg][Hin][Win][Cin] */

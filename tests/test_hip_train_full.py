@@ -91,6 +91,11 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     gb = tr16.flat_g.clone()
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     assert torch.equal(tr16.flat_g, gb)                       # the bf16 arm (batched split-K dW) is deterministic too
+    # the GELU backward inside the epilogue of the mlp.c_proj dX GEMM vs the separate pass: the same expressions on the same values
+    tr16.fuse_gelu_backward = False
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(tr16.flat_g, gb)
+    tr16.fuse_gelu_backward = True
     # gelu_bwd / the attention backward writing their gradients as bf16 (256-tile dX GEMMs, half the bytes through the TN kernel) vs fp32
     # gradients rounded by their consumers on load: the same GEMM operands -> every gradient bit-identical, except the two bias
     # gradients that are now sums of the rounded values

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
         // adjacent columns of one row — instead of 16 x 2 bytes.  Ragged edges fall back to single elements.
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         const bool gelu16 = p.epilogue == VF_EPI_GELU_ERF;
+        const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;             // out = acc * gelu'(u), u = p.res[m][n] (the saved pre-activation)
         __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
         const bool pairs = (p.ldc & 1) == 0 && (p.Cout & 1) == 0;
         const int odd = l31 & 1;
@@ -282,10 +283,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
             for (int i = 0; i < MI; ++i) {
                 const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
                 float t[16];
+                if (gbwd) {
+                    // the expressions of gelu_bwd_kernel (train_ops.hip) on the value the un-fused path would have stored as fp32: same bits
+                    float uu[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    t[r] = acc[i][j][r] + bias;
-                    if (gelu16) t[r] = vf_gelu_erf_fast(t[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (r & 3) + 8 * (r >> 2);
+                        uu[r] = p.res[(size_t)(m < p.M ? m : 0) * p.ldr + (n < p.Cout ? n : 0)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float x = uu[r];
+                        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+                        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+                        t[r] = (acc[i][j][r] + bias) * (cdf + x * pdf);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        t[r] = acc[i][j][r] + bias;
+                        if (gelu16) t[r] = vf_gelu_erf_fast(t[r]);
+                    }
                 }
                 if (pairs) {
 #pragma unroll
@@ -539,6 +557,7 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
     if (a.mode != VF_MODE_GEMM || a.pro_mean) return VF_ERR_UNSUPPORTED;
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
+    if (a.epilogue == VF_EPI_GELU_BWD && !(a.reserved0 & 2)) return VF_ERR_UNSUPPORTED;      // (bf16-output form only)
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     const size_t smem = (size_t)2 * (A_BYTES + B_BYTES);
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
@@ -563,7 +582,8 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     const bool a16 = a.reserved0 & 1, o16 = a.reserved0 & 2;      // bf16 activations in / out (see gemm_bf16_direct_kernel)
     if (a16 || o16) {
         if (a.Cin % (2 * CK) != 0 || a.batch > 1) return VF_ERR_UNSUPPORTED;
-        if ((a16 && (a.lda & 7)) || (o16 && a.res)) return VF_ERR_BAD_ARG;
+        if ((a16 && (a.lda & 7)) || (o16 && a.res && a.epilogue != VF_EPI_GELU_BWD)) return VF_ERR_BAD_ARG;
+        if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res && a.ldr >= a.Cout)) return VF_ERR_BAD_ARG;
         // large token matrices with 256-aligned widths: the 256 x 256 LDS-DMA kernel (bit-identical results; VF_GEMM_G256=0 keeps
         // the 128 x 128 kernel for A/B runs)
         const char* g256_env = getenv("VF_GEMM_G256");          // (read per call: the parity test flips it in-process)

@@ -333,6 +333,7 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
+    if (a.epilogue != VF_EPI_NONE && a.epilogue != VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;      // (VF_EPI_GELU_BWD: vf_gemm_bf16 only)
     if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.mode < VF_MODE_GEMM || a.mode > VF_MODE_CONV3_UP2) return VF_ERR_BAD_ARG;

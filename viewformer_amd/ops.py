@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import VfIgemmArgs, check
 
 MODE_GEMM, MODE_CONV3_S1, MODE_CONV3_S2PAD, MODE_CONV3_UP2 = 0, 1, 2, 3
-EPI_NONE, EPI_GELU = 0, 1
+EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
 
 
 def _stream():

@@ -191,7 +191,7 @@ class MIGTTrainer:
     def _linear(self, x, name, M, res=None):
         return self.model._gemm(x, name, M, res=res)
 
-    def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None, dx_bf16=False):
+    def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None, dx_bf16=False, gelu_bwd_u=None):
         """grads of y = x @ W + b given dy [M,N]; returns dx (+res) or None.  ``x`` may be a saved bf16 activation (bf16 arm);
         ``dx_bf16``: the bf16 arm's dX GEMM writes bf16 (the attention backward's dO operand)."""
         dn = self.model._dense[name]
@@ -201,7 +201,7 @@ class MIGTTrainer:
             # bf16 arm with a saved bf16 activation: dW and db in ONE pass over x and dy as they lie (csrc/gemm_tn_bf16.hip) — no widening
             # transpose of x, no packed bf16 copy of dy, no column-sum pass
             ops.gemm_tn_bf16(x, dy, M, K, N, self.g(name + '.weight'), self.g(name + '.bias'))
-            return self._linear_dx(name, dy, M, res, dx_bf16) if need_dx else None
+            return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u) if need_dx else None
         if dy.dtype != torch.float32:
             raise RuntimeError('a bf16 gradient operand needs the TN weight-gradient path')
         T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
@@ -235,10 +235,11 @@ class MIGTTrainer:
             ops.igemm(xt, dyp, K, Mp, N, gw, res=gw, lda=Mp)                         # dW += X^T dY
         if not need_dx:
             return None
-        return self._linear_dx(name, dy, M, res, dx_bf16)
+        return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u)
 
-    def _linear_dx(self, name, dy, M, res=None, dx_bf16=False):
-        """dx = dy @ W^T (+ res)"""
+    def _linear_dx(self, name, dy, M, res=None, dx_bf16=False, gelu_bwd_u=None):
+        """dx = dy @ W^T (+ res).  ``gelu_bwd_u`` (bf16 arm): the saved fp32 pre-activation u of the GELU that produced this layer's input —
+        the GEMM's epilogue then returns bf16(dx * gelu'(u)), the GELU backward without the fp32 dx ever reaching HBM"""
         dn = self.model._dense[name]
         K, N = dn.k, dn.n
         x6 = name in self.wpT6 and dn.wp6 is not None and M % 64 == 0
@@ -246,7 +247,11 @@ class MIGTTrainer:
         if dx_bf16 and not (bf16 and res is None):
             raise RuntimeError('dx_bf16 needs the bf16 arm and no residual')
         dx = torch.empty((M, K), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dy.device)
-        if bf16:
+        if gelu_bwd_u is not None:
+            if not (bf16 and dx_bf16 and res is None):
+                raise RuntimeError('the fused GELU backward needs the bf16 arm, a bf16 result and no residual')
+            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=gelu_bwd_u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=dy.dtype == torch.bfloat16, o16=True)
+        elif bf16:
             ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, a16=dy.dtype == torch.bfloat16, o16=dx_bf16)   # (bf16 dY: the 256-tile kernel)
         elif x6:
             ops.igemm(dy, self.wpT6[name], M, N, K, dx, res=res, x6=True)
@@ -261,6 +266,7 @@ class MIGTTrainer:
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res)
 
+    fuse_gelu_backward = True         # bf16 arm: d(pre-activation) = dX(mlp.c_proj) * gelu'(u) in that GEMM's epilogue (same bits as the two passes)
     bf16_gradient_operands = True     # bf16 arm: gelu_bwd / attention backward write their gradients as bf16 (see train_step)
     tn_weight_gradient = True         # bf16 arm: dW / db of the wide layers straight from the row-major operands (False: transpose + pack + column sums)
     bf16_saved_activations = True     # bf16 arm: LayerNorm outputs / MLP hidden saved as bf16 (see train_step); False keeps them fp32 (same gradients)
@@ -498,8 +504,11 @@ class MIGTTrainer:
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
-            df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
-            du = T.gelu_bwd(u, df, out_bf16=grad16)
+            if grad16 and self.fuse_gelu_backward:                                   # GELU backward in the epilogue of the dX GEMM that feeds it
+                du = self._linear_bwd(p + '.mlp.c_proj', f, dh, M, dx_bf16=True, gelu_bwd_u=u)
+            else:
+                df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
+                du = T.gelu_bwd(u, df, out_bf16=grad16)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
             dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh)                  # (+ the residual branch's gradient, same pass)
             datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M,
