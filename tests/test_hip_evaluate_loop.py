@@ -1,0 +1,64 @@
+"""GPU: the evaluator's batch handling around ``generate_batch_predictions`` (viewformer/evaluate/evaluate_transformer.py:97-146, outer loop
+:219-222) — scene chunking of large batches and the double-buffered host round trip — against the plain per-batch call: scenes are
+independent, so both must return the plain call's values exactly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def models(dev):
+    from viewformer_amd.config import VQGANConfig, MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_migt_weights, make_vqgan_weights
+    vcfg = VQGANConfig(ch=32, ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[16], image_size=32, z_channels=32, embed_dim=32, n_embed=128)
+    mcfg = MIGTConfig(n_embeddings=128, n_head=2, d_model=128, n_layer=2, token_image_size=8, sequence_size=3, pose_multiplier=0.2)
+    vq = VQGAN(vcfg, data_format='NHWC').load_state_dict(make_vqgan_weights(vcfg, seed=1, codebook_scale=0.05)).to(dev)
+    tr = MIGT(mcfg).load_state_dict(make_migt_weights(mcfg, seed=1, std=0.05)).to(dev)
+    return tr, vq
+
+
+KEYS = ('generated_images', 'generated_cameras', 'ground_truth_images', 'ground_truth_cameras')
+
+
+def test_large_batches_are_walked_in_scene_chunks_with_identical_results(dev, models):
+    from viewformer_amd.evaluate import generate_batch_predictions
+    from viewformer_amd.weights import synthetic_scene_batch
+    tr, vq = models
+    frames, cams = synthetic_scene_batch(11, 3, 32, seed=5)
+    whole = generate_batch_predictions(tr, vq, frames, cams, return_codes=True)
+    for chunk in (4, 1, 11, 64):                                       # ragged last chunk, one scene per pass, exactly one chunk, no chunking
+        part = generate_batch_predictions(tr, vq, frames, cams, return_codes=True, max_scenes_per_call=chunk)
+        for k in KEYS + ('codes', 'generated_codes', 'logits_last'):
+            assert torch.equal(part[k], whole[k]), (chunk, k)
+        assert part['generated_images'].shape[0] == 11
+
+
+def test_streamed_host_round_trip_returns_the_plain_results_in_order(dev, models):
+    """evaluate.stream_batch_predictions: uploads / downloads on a second HIP stream, pinned ring buffers of depth + 1 — every yielded batch
+    equals the plain call on that batch (compared at yield time: the host buffers are recycled ``depth`` batches later)"""
+    from viewformer_amd.evaluate import generate_batch_predictions, stream_batch_predictions
+    from viewformer_amd.weights import synthetic_scene_batch
+    tr, vq = models
+    batches = [synthetic_scene_batch(3 + (i % 2), 3, 32, seed=10 + i) for i in range(6)]           # two batch sizes: two buffer rings
+    plain = [generate_batch_predictions(tr, vq, f, c) for f, c in batches]
+    host_batches = [(torch.from_numpy(f).pin_memory(), torch.from_numpy(c).pin_memory()) for f, c in batches]
+    for depth in (2, 1, 3):
+        n = 0
+        for i, out in enumerate(stream_batch_predictions(tr, vq, iter(host_batches), depth=depth)):
+            assert not out['generated_images'].is_cuda and not out['generated_cameras'].is_cuda
+            assert torch.equal(out['generated_images'], plain[i]['generated_images'].cpu()), (depth, i)
+            assert torch.equal(out['generated_cameras'], plain[i]['generated_cameras'].cpu()), (depth, i)
+            assert torch.equal(out['ground_truth_images'].cpu(), plain[i]['ground_truth_images'].cpu())
+            n += 1
+        assert n == len(batches)
+    assert list(stream_batch_predictions(tr, vq, iter([]))) == []
