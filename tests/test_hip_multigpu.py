@@ -17,8 +17,8 @@ import torch
 
 from conftest import REPO
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs >= 2 GPUs (RCCL path)')]
+pytestmark = pytest.mark.gpu
+two_gpus = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs >= 2 GPUs (RCCL path)')
 
 
 def _port():
@@ -29,8 +29,10 @@ def _port():
     return p
 
 
-def _launch(extra, n=2, timeout=900):
+def _launch(extra, n=2, timeout=900, backend=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if backend:
+        env['VF_DIST_BACKEND'] = backend
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(_port()), os.path.join(REPO, 'bench.py'), '--gpus', str(n)] + extra
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
@@ -40,6 +42,7 @@ def _launch(extra, n=2, timeout=900):
     return json.loads(lines[0])
 
 
+@two_gpus
 def test_views_workload_two_gpus_scene_shards():
     one = _launch(['--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-f32-arm'], n=1)
     two = _launch(['--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-f32-arm'], n=2)
@@ -47,6 +50,7 @@ def test_views_workload_two_gpus_scene_shards():
     assert two['value'] > 1.5 * one['value'], (one['value'], two['value'])      # independent shards: close to 2x
 
 
+@two_gpus
 def test_train_workload_two_gpus_rccl_allreduce():
     line = _launch(['--workload', 'train', '--steps', '3', '--warmup', '1'], n=2)
     assert line['n_gpus'] == 2 and line['value'] > 0
@@ -54,4 +58,21 @@ def test_train_workload_two_gpus_rccl_allreduce():
     assert c['backend'] == 'nccl'                                               # RCCL
     assert c['ms_per_step_without_allreduce'] > 0 and c['exposed_allreduce_wait_ms'] >= 0
     half = _launch(['--workload', 'train', '--steps', '3', '--warmup', '1', '--grad-dtype', 'bf16'], n=2)
+    assert half['config']['collective']['gradient_dtype_on_the_links'] == 'bf16' and half['value'] > 0
+
+
+def test_two_rank_launch_line_on_one_gpu_over_gloo():
+    """the same launch line with two ranks on whatever GPUs the box has (VF_DIST_BACKEND=gloo: ranks share cuda:0 on a 1-GPU box and the
+    collectives carry device tensors over gloo): bench.py's N > 1 branches — scene shards summed over ranks, max-over-ranks time, one JSON
+    line from rank 0, the training line's collective block (step without the all-reduce, exposed wait) — run end to end.  Not a
+    performance statement: two ranks on one GPU halve each other's throughput."""
+    views = _launch(['--steps', '2', '--warmup', '1', '--batch', '8', '--no-cpu-baseline', '--no-f32-arm'], n=2, backend='gloo')
+    assert views['n_gpus'] == 2 and views['scaling'] == 'weak' and views['value'] > 0
+    assert 'x2' in views['config']['parallelism']
+    train = _launch(['--workload', 'train', '--steps', '2', '--warmup', '1', '--batch', '2'], n=2, backend='gloo')
+    assert train['n_gpus'] == 2 and train['value'] > 0
+    c = train['config']['collective']
+    assert c['backend'] == 'gloo' and c['ms_per_step_without_allreduce'] > 0 and c['exposed_allreduce_wait_ms'] >= 0
+    assert c['gradient_dtype_on_the_links'] == 'f32'
+    half = _launch(['--workload', 'train', '--steps', '2', '--warmup', '1', '--batch', '2', '--grad-dtype', 'bf16'], n=2, backend='gloo')
     assert half['config']['collective']['gradient_dtype_on_the_links'] == 'bf16' and half['value'] > 0

@@ -26,13 +26,17 @@ def init_from_env(backend: str = None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if torch.cuda.is_available() and backend != 'gloo':
+    # VF_DIST_BACKEND=gloo: the same N-process code path on a box with fewer GPUs than ranks (ranks share devices, the collectives carry
+    # device tensors over gloo) — how the 1-GPU test boxes exercise bench.py's N > 1 branches; the product launch leaves it unset (RCCL)
+    backend = backend or os.environ.get('VF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        if backend == 'gloo':
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)                      # bind this rank's GPU BEFORE RCCL creates its communicator
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (the host driver has no legacy IPC)
-        dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
-                                rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 
