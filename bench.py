@@ -292,7 +292,7 @@ def run_train(args, rank, local, world, dev):
         return
     prof = OpTimer()
     prof.install()
-    tr.train_step(poses, tokens)
+    tr.train_step(poses, tokens, reduce_gradients=False)              # rank 0 alone from here on: no collective (the other ranks have returned)
     ms, fl, n, top = prof.gemm_summary()
     prof.uninstall()
     grad_mb = sum(int(t.numel()) for t in [tr.flat_g]) * 4 / 2 ** 20

@@ -29,7 +29,7 @@ def _port():
     return p
 
 
-def _launch(extra, n=2, timeout=900, backend=None):
+def _launch(extra, n=2, timeout=420, backend=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if backend:
         env['VF_DIST_BACKEND'] = backend

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                 const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
                 float t[16];
                 if (gbwd) {
-                    // the expressions of gelu_bwd_kernel (train_ops.hip) on the value the un-fused path would have stored as fp32: same bits
+                    // gelu_bwd_kernel's expression (vf_gelu_grad: explicitly rounded) on the value the un-fused path would have stored as fp32: same bits
                     float uu[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -292,12 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                         uu[r] = p.res[(size_t)(m < p.M ? m : 0) * p.ldr + (n < p.Cout ? n : 0)];
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float x = uu[r];
-                        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-                        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-                        t[r] = (acc[i][j][r] + bias) * (cdf + x * pdf);
-                    }
+                    for (int r = 0; r < 16; ++r) t[r] = __fmul_rn(__fadd_rn(acc[i][j][r], bias), vf_gelu_grad(uu[r]));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

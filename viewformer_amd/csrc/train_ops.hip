@@ -192,18 +192,12 @@ __global__ void gelu_bf16out_kernel(const float* __restrict__ u, __bf16* __restr
 }
 __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df, float* __restrict__ du, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float x = u[i];
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-        du[i] = df[i] * (cdf + x * pdf);
+        du[i] = __fmul_rn(df[i], vf_gelu_grad(u[i]));
     }
 }
 __global__ void gelu_bwd_bf16out_kernel(const float* __restrict__ u, const float* __restrict__ df, __bf16* __restrict__ du, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float x = u[i];
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-        du[i] = (__bf16)(df[i] * (cdf + x * pdf));             // the rounding both consumers (dX and dW GEMMs of the bf16 arm) applied on load
+        du[i] = (__bf16)__fmul_rn(df[i], vf_gelu_grad(u[i]));   // the rounding both consumers (dX and dW GEMMs of the bf16 arm) applied on load
     }
 }
 

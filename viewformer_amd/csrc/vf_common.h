@@ -55,6 +55,14 @@ __device__ __forceinline__ float vf_gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+// d/dx of the exact-erf GELU, with explicitly rounded operations (no contraction freedom): the stand-alone backward kernels
+// (train_ops.hip) and the GELU-backward epilogue of vf_gemm_bf16 (VF_EPI_GELU_BWD) must produce the same bits
+__device__ __forceinline__ float vf_gelu_grad(float x) {
+    const float cdf = __fmul_rn(0.5f, __fadd_rn(1.0f, erff(__fmul_rn(x, 0.70710678118654752440f))));
+    const float pdf = __fmul_rn(0.39894228040143267794f, expf(__fmul_rn(-0.5f, __fmul_rn(x, x))));
+    return __fmaf_rn(x, pdf, cdf);
+}
+
 __device__ __forceinline__ float vf_gelu_erf_fast(float v) {
     // erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on the hardware exp2 / rcp: ~16 VALU instead
     // of ~45 for erff.  Only for the bf16 tolerance arm, whose consumers round this value to 8 mantissa bits anyway (the erff
