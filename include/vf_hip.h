@@ -269,6 +269,15 @@ int vf_resize_u8(const uint8_t* src, uint8_t* dst, int n_img, int Hin, int Win, 
 size_t vf_gemm_bf16_packed_elems(int K, int N);            /* number of bf16 elements of the packed weight */
 int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int batch,
                       int64_t src_bstride, void* stream);
+/* the same packing for many weights in ONE launch: `descs_device` = n descriptors in DEVICE memory (src [K][N] with element strides sk / sn,
+ * dst of vf_gemm_bf16_packed_elems(K, N) bf16) — the training step's per-step refresh of every layer's W and W^T packing */
+typedef struct vf_pack_desc {
+    const float* src;
+    void* dst;
+    int32_t K, N;
+    int64_t sk, sn;
+} vf_pack_desc;
+int vf_gemm_bf16_pack_multi(const vf_pack_desc* descs_device, int n, void* stream);
 int vf_gemm_bf16(const vf_igemm_args* args /* host */, void* stream);
 /* vf_gemm_bf16 reads args->reserved0 as dtype flags: bit 0 = x is bf16 [M][lda] (lda in elements, % 8 == 0), bit 1 = out is bf16
  * [M][ldc] (no residual).  Both need Cin % 128 == 0.  For activations that only bf16 GEMMs consume (LayerNorm / GELU / attention

@@ -107,6 +107,7 @@ EXPORTS = {
     # ---- bf16 arm (transformer dense layers, decoder convolutions)
     'vf_gemm_bf16_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_gemm_bf16_pack': (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int64, P]),
+    'vf_gemm_bf16_pack_multi': (c_int, [P, c_int, P]),
     'vf_gemm_bf16': (c_int, [POINTER(VfIgemmArgs), P]),
     'vf_conv3_bf16_packed_elems': (c_size_t, [c_int, c_int]),
     'vf_conv3_bf16_pack': (c_int, [P, P, c_int, c_int, P]),

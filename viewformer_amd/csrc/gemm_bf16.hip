@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                 const int m0 = mtile * BM + wave_m * 64 + i * 32 + 4 * half;
                 float t[16];
                 if (gbwd) {
-                    // gelu_bwd_kernel's expression (vf_gelu_grad: explicitly rounded) on the value the un-fused path would have stored as fp32: same bits
+                    // gelu_bwd_bf16out_kernel's expression (vf_gelu_grad_fast: explicitly rounded) on the value the un-fused path would have stored
+                    // as fp32: same bits
                     float uu[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                         uu[r] = p.res[(size_t)(m < p.M ? m : 0) * p.ldr + (n < p.Cout ? n : 0)];
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) t[r] = __fmul_rn(__fadd_rn(acc[i][j][r], bias), vf_gelu_grad(uu[r]));
+                    for (int r = 0; r < 16; ++r) t[r] = __fmul_rn(__fadd_rn(acc[i][j][r], bias), vf_gelu_grad_fast(uu[r]));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -523,6 +524,30 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restri
     }
 }
 
+// the same packing for MANY weights in one launch (blockIdx.y = descriptor): the training step re-packs 2 x 48 layer weights after every
+// optimizer step, 96 launches of a few microseconds each
+__global__ void pack_bf16_multi_kernel(const vf_pack_desc* __restrict__ descs) {
+    const vf_pack_desc d = descs[blockIdx.y];
+    const int nb = (d.N + BN - 1) / BN, nchunks = (d.K + CK - 1) / CK;
+    const long long total = (long long)nchunks * nb * CK * BN;
+    __bf16* __restrict__ dst = reinterpret_cast<__bf16*>(d.dst);
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        long long t = idx >> 3;
+        const int nl = (int)(t % BN); t /= BN;
+        const int half = (int)(t & 1);
+        const int ks = (int)((t >> 1) & 3);
+        t >>= 3;
+        const int nblk = (int)(t % nb);
+        const int chunk = (int)(t / nb);
+        const int k = chunk * CK + ks * 16 + half * 8 + e;
+        const int n = nblk * BN + nl;
+        float v = 0.f;
+        if (k < d.K && n < d.N) v = d.src[k * d.sk + n * d.sn];
+        dst[idx] = (__bf16)v;
+    }
+}
+
 }  // namespace
 
 int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream);      // gemm_bf16_g256.hip: 256 x 256 tile, LDS-DMA operands
@@ -542,6 +567,12 @@ int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, K, N,
                        (long long)sk, (long long)sn, nb, nchunks, (long long)src_bstride, total);
+    return vf_last_status();
+}
+
+int vf_gemm_bf16_pack_multi(const vf_pack_desc* descs_device, int n, void* stream) {
+    if (!descs_device || n <= 0) return VF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(128, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_device);
     return vf_last_status();
 }
 

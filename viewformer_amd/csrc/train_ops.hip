@@ -197,7 +197,7 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ u, const float* __rest
 }
 __global__ void gelu_bwd_bf16out_kernel(const float* __restrict__ u, const float* __restrict__ df, __bf16* __restrict__ du, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        du[i] = (__bf16)__fmul_rn(df[i], vf_gelu_grad(u[i]));   // the rounding both consumers (dX and dW GEMMs of the bf16 arm) applied on load
+        du[i] = (__bf16)__fmul_rn(df[i], vf_gelu_grad_fast(u[i]));   // the rounding both consumers (dX and dW GEMMs of the bf16 arm) applied on load
     }
 }
 

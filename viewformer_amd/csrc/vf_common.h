@@ -63,6 +63,23 @@ __device__ __forceinline__ float vf_gelu_grad(float x) {
     return __fmaf_rn(x, pdf, cdf);
 }
 
+// The same derivative for the bf16 training arm, whose consumers round it (times the incoming gradient) to 8 mantissa bits: erf from
+// Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) and the Gaussian from the SAME hardware exp2 (exp(-x^2/2) is the erf formula's
+// exponential), ~18 VALU instead of ~60 for erff + expf — as an epilogue of the dX GEMM the library forms cost 60 % of the K loop.
+// Explicitly rounded, so the stand-alone bf16-output kernel and the GEMM epilogue agree bit for bit.
+__device__ __forceinline__ float vf_gelu_grad_fast(float x) {
+    const float z = __fmul_rn(fabsf(x), 0.70710678118654752440f);
+    const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, z, 1.0f));
+    float p = __fmaf_rn(1.061405429f, t, -1.453152027f);
+    p = __fmaf_rn(p, t, 1.421413741f);
+    p = __fmaf_rn(p, t, -0.284496736f);
+    p = __fmaf_rn(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, __fmul_rn(z, z)));      // exp(-z^2) = exp(-x^2 / 2)
+    const float erf_abs = __fmaf_rn(-__fmul_rn(p, t), e, 1.0f);
+    const float cdf = __fmul_rn(0.5f, __fadd_rn(1.0f, copysignf(erf_abs, x)));
+    return __fmaf_rn(x, __fmul_rn(0.39894228040143267794f, e), cdf);
+}
+
 __device__ __forceinline__ float vf_gelu_erf_fast(float v) {
     // erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on the hardware exp2 / rcp: ~16 VALU instead
     // of ~45 for erff.  Only for the bf16 tolerance arm, whose consumers round this value to 8 mantissa bits anyway (the erff

@@ -88,6 +88,31 @@ def pack_dense_kn_bf16(w):
     return out
 
 
+def pack_bf16_multi(items):
+    """many bf16 packings in one launch.  ``items`` = [(w fp32 [rows][cols] contiguous, transposed, out)]: transposed False packs w as
+    [K = rows][N = cols] (pack_dense_kn_bf16), True as the [N = rows][K = cols] operand (pack_dense_nk_bf16); ``out`` = the bf16 buffer to
+    fill (vf_gemm_bf16_packed_elems(K, N)).  Returns a closure that re-runs the same launch (descriptors stay on the device)."""
+    import numpy as np
+    lib = _lib.load()
+    dt = np.dtype([('src', '<u8'), ('dst', '<u8'), ('K', '<i4'), ('N', '<i4'), ('sk', '<i8'), ('sn', '<i8')])
+    assert dt.itemsize == 40
+    a = np.zeros(len(items), dtype=dt)
+    for i, (w, tr, out) in enumerate(items):
+        _f32(w); _chk(out, torch.bfloat16)
+        assert w.is_contiguous() and w.dim() == 2
+        r, c = w.shape
+        K, N, sk, sn = (c, r, 1, c) if tr else (r, c, c, 1)
+        assert out.numel() >= int(lib.vf_gemm_bf16_packed_elems(K, N))
+        a[i] = (w.data_ptr(), out.data_ptr(), K, N, sk, sn)
+    descs = torch.from_numpy(a.view(np.uint8).copy()).to(items[0][0].device)
+    n = len(items)
+
+    def run():
+        check(lib.vf_gemm_bf16_pack_multi(_p(descs), n, _stream()), 'vf_gemm_bf16_pack_multi')
+    run()
+    return run
+
+
 def pack_dense_nk_bf16(w, n_rows=None):
     """transposed weight [N][K] (x @ W^T; tied LM head, 1x1 conv [Cout][Cin]) -> bf16 packing"""
     lib = _lib.load()

@@ -165,6 +165,11 @@ class MIGTTrainer:
         self.wpT16 = getattr(self, 'wpT16', {})
         m._lm_head16 = None
         m._lm_head6 = None                                  # the LM head / pose heads stay on the native kernel in training
+        # bf16 arm: after the first call (which allocates the packings one by one) every layer's W and W^T packing is refreshed by ONE
+        # launch over a descriptor table (96 pack launches per step before)
+        if self._pack16 is not None:
+            self._pack16()
+        pack_items = []
         for name, dn in m._dense.items():
             k32 = dn.k % 32 == 0
             to16 = bf16 and k32 and dn.k % 128 == 0 and dn.n % 128 == 0
@@ -177,13 +182,20 @@ class MIGTTrainer:
                 self.wpT[name] = ops.pack(dn.w_raw, dn.n, dn.k, 1, sk=1, sn=dn.n, st=0, out=self.wpT.get(name))
             else:
                 self.wpT.pop(name, None)
+            keep16 = dn.wp16 if (to16 and self._pack16 is not None) else None
             dn.wp6 = dn.wp16 = None
             if to16:
-                dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
-                self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
+                if self._pack16 is not None:                          # buffers of the one-launch refresh below: filled there
+                    dn.wp16 = keep16
+                else:
+                    dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
+                    self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
+                    pack_items += [(dn.w_raw, False, dn.wp16), (dn.w_raw, True, self.wpT16[name])]
             if to6:
                 dn.wp6 = ops.pack_dense_kn_x3h(dn.w_raw) if x3h else ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
+        if bf16 and self._pack16 is None and pack_items and self.one_launch_repack:
+            self._pack16 = ops.pack_bf16_multi(pack_items)          # (re-packs once more; from now on the closure is the refresh)
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
         self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
 
@@ -266,6 +278,8 @@ class MIGTTrainer:
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res)
 
+    one_launch_repack = True          # bf16 arm: all weight packings refreshed by one launch per step
+    _pack16 = None
     fuse_gelu_backward = True         # bf16 arm: d(pre-activation) = dX(mlp.c_proj) * gelu'(u) in that GEMM's epilogue (same bits as the two passes)
     bf16_gradient_operands = True     # bf16 arm: gelu_bwd / attention backward write their gradients as bf16 (see train_step)
     tn_weight_gradient = True         # bf16 arm: dW / db of the wide layers straight from the row-major operands (False: transpose + pack + column sums)
