@@ -98,16 +98,17 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     assert torch.equal(tr16.flat_g, gb)
     tr16.fuse_gelu_backward = True
     # gelu_bwd / the attention backward writing their gradients as bf16 (256-tile dX GEMMs, half the bytes through the TN kernel) vs fp32
-    # gradients rounded by their consumers on load: the same GEMM operands -> every gradient bit-identical, except the two bias
-    # gradients that are now sums of the rounded values
+    # gradients rounded by their consumers on load: the same GEMM operands up to the bf16 arm's fast gelu' (1.5e-7 from the library form
+    # the fp32 path keeps: a few of 59 M values round to the neighbouring bf16) -> gradients within 1e-4, except the two bias gradients
+    # that are now sums of the rounded values
     tr16.bf16_gradient_operands = False
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     for n in tr16.names:
         a, b, _ = tr16.slices[n]
         if n.endswith('mlp.c_fc.bias') or n.endswith('attn.c_attn.bias'):
             assert _rel(gb[a:b], tr16.flat_g[a:b]) < 2e-3, n       # (sums of 19 200 values each rounded to 8 bits, many of them cancelling)
-        else:
-            assert torch.equal(gb[a:b], tr16.flat_g[a:b]), n
+        elif float(tr16.flat_g[a:b].abs().max()) > 0:
+            assert _rel(gb[a:b], tr16.flat_g[a:b]) < 1e-4, n
     tr16.bf16_gradient_operands = True
     # weight gradients straight from the row-major operands (csrc/gemm_tn_bf16.hip) vs transpose + pack + batched split-K GEMM + column
     # sums: the same bf16 products, another summation order
