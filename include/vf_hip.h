@@ -59,9 +59,11 @@ const char* vf_build_flag_name(int i);
  * ------------------------------------------------------------------------------------- */
 enum { VF_MODE_GEMM = 0, VF_MODE_CONV3_S1 = 1, VF_MODE_CONV3_S2PAD = 2, VF_MODE_CONV3_UP2 = 3 };
 enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1,
-       VF_EPI_GELU_BWD = 2 };   /* vf_gemm_bf16 with bf16 output only: out = bf16(acc * gelu'(res[m][n])) — `res` carries the saved fp32
+       VF_EPI_GELU_BWD = 2,     /* vf_gemm_bf16 with bf16 output only: out = bf16(acc * gelu'(res[m][n])) — `res` carries the saved fp32
                                    pre-activation, not a residual: the GELU backward of the training step inside the dX GEMM that
                                    produces its input (migt.py:70 under autograd) */
+       VF_EPI_GELU_DUAL = 3 };  /* vf_gemm_bf16, bf16 activations in, fp32 out, 256-aligned shapes only: out = acc + bias (fp32) AND
+                                   out_aux = bf16(gelu(out)) — see vf_igemm_args.out_aux */
 
 typedef struct vf_igemm_args {
     const float* x;          /* GEMM: [M][lda]; conv: NHWC [Nimg][Hin][Win][Cin] */
@@ -90,6 +92,9 @@ typedef struct vf_igemm_args {
     int32_t gn_slots;
     int32_t reserved0;       /* vf_gemm_x6 only: split-K count S > 1 -> S raw partial slabs at out + s*stride_out (no bias /
                               * residual / epilogue), to be summed by vf_sum_slabs_f32; 0 or 1 = off */
+    void* out_aux;           /* VF_EPI_GELU_DUAL only (vf_gemm_bf16, bf16 activations in, fp32 out): bf16 [M][ldc] that receives
+                              * gelu(out) beside the fp32 pre-activation `out` — the training forward's c_fc keeps u for the backward
+                              * pass and hands f to mlp.c_proj from ONE epilogue.  NULL otherwise (other entry points refuse it). */
 } vf_igemm_args;
 
 /* floats needed for the packed form of a [taps][K][N] weight (K,N padded to the tile) */
@@ -444,8 +449,8 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 /* LayerNormalization backward (migt.py:225,227,292): dx, and dgamma/dbeta (+)= */
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d);
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                         int64_t rows, int d, float eps, int accumulate, const float* res /* NULL or [rows][d]: dx += res */, void* ws,
-                         void* stream);
+                         int64_t rows, int d, float eps, int accumulate, const float* res /* NULL or [rows][d]: dx += res */,
+                         void* dx_bf16 /* NULL or [rows][d] bf16: a rounded copy of dx for GEMM consumers */, void* ws, void* stream);
 /* exact-erf GELU (tf.nn.gelu, migt.py:13,70) forward on a saved pre-activation, and its backward */
 int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream);
 /* the same value rounded to bf16 on the way out (the bf16 training arm saves the MLP hidden as its next GEMM reads it) */

@@ -93,23 +93,48 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     assert torch.equal(tr16.flat_g, gb)                       # the bf16 arm (batched split-K dW) is deterministic too
     # the GELU backward inside the epilogue of the mlp.c_proj dX GEMM vs the separate pass: one explicitly rounded expression
     # (vf_gelu_grad, vf_common.h) on the same values -> the same bits
+    # (first: without the LayerNorm backward's bf16 copy of the residual-stream gradient — the two projection layers' backward GEMMs then
+    # take the fp32 gradient and round it on load: the same operands, so the same bits everywhere except those two layers' bias gradients,
+    # which with the copy are sums of the rounded values)
+    tr16.bf16_residual_gradient = False
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    g_res32 = tr16.flat_g.clone()
+    for n in tr16.names:
+        a, b, _ = tr16.slices[n]
+        if n.endswith('mlp.c_proj.bias') or n.endswith('attn.c_proj.bias'):
+            assert _rel(gb[a:b], g_res32[a:b]) < 2e-3, n
+        else:
+            assert torch.equal(gb[a:b], g_res32[a:b]), n
     tr16.fuse_gelu_backward = False
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
-    assert torch.equal(tr16.flat_g, gb)
+    assert torch.equal(tr16.flat_g, g_res32)
     tr16.fuse_gelu_backward = True
+    tr16.bf16_residual_gradient = True
     # gelu_bwd / the attention backward writing their gradients as bf16 (256-tile dX GEMMs, half the bytes through the TN kernel) vs fp32
     # gradients rounded by their consumers on load: the same GEMM operands up to the bf16 arm's fast gelu' (1.5e-7 from the library form
-    # the fp32 path keeps: a few of 59 M values round to the neighbouring bf16) -> gradients within 1e-4, except the two bias gradients
-    # that are now sums of the rounded values
+    # the fp32 path keeps: a few of 59 M values round to the neighbouring bf16) -> gradients within 2e-3 of the
+    # tensor's largest element (an order below the arm's stated tolerance); the layers' bias gradients are sums of the rounded values
     tr16.bf16_gradient_operands = False
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
     for n in tr16.names:
         a, b, _ = tr16.slices[n]
-        if n.endswith('mlp.c_fc.bias') or n.endswith('attn.c_attn.bias'):
+        if n.endswith('.bias') and n.startswith('h.'):
             assert _rel(gb[a:b], tr16.flat_g[a:b]) < 2e-3, n       # (sums of 19 200 values each rounded to 8 bits, many of them cancelling)
         elif float(tr16.flat_g[a:b].abs().max()) > 0:
-            assert _rel(gb[a:b], tr16.flat_g[a:b]) < 1e-4, n
+            # (measured worst: 7.9e-4 on wte.weight, in the LOC-token row — a cancelling sum over every row of the bottom gradient)
+            assert _rel(gb[a:b], tr16.flat_g[a:b]) < 2e-3, n
     tr16.bf16_gradient_operands = True
+    # the forward GELU inside c_fc's epilogue (fp32 u + bf16 gelu(u) from one launch; the inference arm's fast erf) vs the separate pass
+    # (library erff): 1.5e-7 apart in absolute terms before the bf16 rounding, so 0.2 % of the 59 M hidden values per layer (GELU's negative
+    # tail) land on the neighbouring bf16
+    tr16.fuse_gelu_forward = False
+    mb_nof = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    g_nof = tr16.flat_g.clone()
+    assert abs(float(mb_nof['loss']) - float(mb['loss'])) < 1e-4 * abs(float(mb['loss']))
+    worst_f = max(_rel(gb[a:b], g_nof[a:b]) for a, b, _ in (tr16.slices[n] for n in tr16.names) if float(g_nof[a:b].abs().max()) > 0)
+    print('full-size bf16 arm: GELU forward in the c_fc epilogue vs the separate pass, worst per-tensor gradient difference', worst_f)
+    assert worst_f < 5e-3, worst_f                            # (measured 2.8e-3; the arm's distance from the fp32-equivalent arm is 1.3e-2)
+    gb_fused, gb = gb, g_nof                                  # (the comparisons below run with the separate pass: the fp32-activation path has no fused form)
     # weight gradients straight from the row-major operands (csrc/gemm_tn_bf16.hip) vs transpose + pack + batched split-K GEMM + column
     # sums: the same bf16 products, another summation order
     tr16.tn_weight_gradient = False
@@ -121,8 +146,8 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
         if float(g_old[a:b].abs().max()) == 0:
             continue
         e = _rel(gb[a:b], g_old[a:b])
-        rounded_bias = n.endswith('mlp.c_fc.bias') or n.endswith('attn.c_attn.bias')       # (this path sums the fp32 gradient, see above)
-        assert e < (2e-3 if rounded_bias else 1e-4), (n, e)
+        rounded_bias = n.endswith('.bias') and n.startswith('h.')                          # (this path sums the fp32 gradient, see above)
+        assert e < 2e-3, (n, e)                               # (without the TN kernel the gradients are fp32 operands again: the comparison above applies)
         worst_t = max(worst_t, 0.0 if rounded_bias else e)
     print('full-size bf16 arm: TN weight-gradient kernel vs the transpose + pack path, worst per-tensor gradient difference', worst_t)
     # activations saved as bf16 by their producers (256-tile forward GEMMs) vs fp32 activations rounded by the GEMM on load: the same
@@ -132,6 +157,8 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     assert torch.equal(tr16.flat_g, g_old)
     tr16.bf16_saved_activations = True
     tr16.tn_weight_gradient = True
+    tr16.fuse_gelu_forward = True
+    gb = gb_fused
     # the exact-f32 attention kernels inside the bf16 arm: the bf16 attention stays within the arm's tolerance of them
     tr16.attention_arith = 'f32'
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)

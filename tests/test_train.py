@@ -666,3 +666,81 @@ def test_tn_weight_gradient_gemm(dev, M, K, N):
         old = torch.zeros((K, N), device=dev)
         ops.igemm(xt, ops.pack_dense_kn_bf16(dy), K, M, N, old, lda=M, bf16=True)
         assert ((old.double() - ref_w).abs().max() / ref_w.abs().max()).item() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [512, 640])         # whole 256-row tiles / a ragged last tile
+def test_gelu_backward_epilogue_of_the_256_tile_kernel(dev, M, monkeypatch):
+    """VF_EPI_GELU_BWD on the 256 x 256 LDS-DMA kernel (bf16 gradient in, bf16 d(pre-activation) out): the same bits as the 128-tile
+    kernel's epilogue (VF_GEMM_G256=0) and as the separate passes (fp32 dX, then gelu_bwd with a bf16 result)."""
+    from viewformer_amd import ops
+    from viewformer_amd import train_ops as T
+    K, N = 768, 3072                                                             # dy [M, K] @ W^T [K, N]
+    g = np.random.Generator(np.random.PCG64(M))
+    dy16 = torch.from_numpy((g.standard_normal((M, K)) * 0.1).astype(np.float32)).to(dev).to(torch.bfloat16)
+    u = torch.from_numpy((g.standard_normal((M, N)) * 1.5).astype(np.float32)).to(dev)
+    w = torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.igemm(dy16, wp, M, K, N, out, res=u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
+    monkeypatch.setenv('VF_GEMM_G256', '0')
+    out128 = torch.empty_like(out)
+    ops.igemm(dy16, wp, M, K, N, out128, res=u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
+    dx = torch.empty((M, N), device=dev)
+    ops.igemm(dy16, wp, M, K, N, dx, bf16=True, a16=True)
+    monkeypatch.delenv('VF_GEMM_G256')
+    assert torch.equal(out, out128)
+    assert torch.equal(out, T.gelu_bwd(u, dx, out_bf16=True))
+    ref = dy16.double() @ w.to(torch.bfloat16).double()
+    x = u.double()
+    gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5
+    err = ((out.double() - ref * gp).abs().max() / (ref * gp).abs().max()).item()
+    assert err < 6e-3, err                                                       # bf16 output rounding (2^-9) + the fast erf
+
+
+@pytest.mark.gpu
+def test_layernorm_backward_bf16_copy(dev):
+    from viewformer_amd import train_ops as T
+    M, d = 1000, 768
+    g = np.random.Generator(np.random.PCG64(5))
+    dy, x, res = (torch.from_numpy(g.standard_normal((M, d)).astype(np.float32)).to(dev) for _ in range(3))
+    gamma = torch.from_numpy(g.standard_normal(d).astype(np.float32)).to(dev)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dx = T.layernorm_bwd(dy, x, gamma, dg, db, M, d, res=res)
+    dg2, db2 = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dx2, dx16 = T.layernorm_bwd(dy, x, gamma, dg2, db2, M, d, res=res, also_bf16=True)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert torch.equal(dx16, dx.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [512, 640])
+def test_gelu_dual_epilogue_of_the_256_tile_kernel(dev, M):
+    """VF_EPI_GELU_DUAL: the fp32 pre-activation is the plain GEMM's (same bits) and the bf16 GELU beside it is the inference arm's fused
+    c_fc epilogue (bias + fast-erf GELU, bf16 store: same bits); against the library-erf pass a small fraction of outputs differ, by one bf16 step."""
+    from viewformer_amd import ops, _lib
+    from viewformer_amd import train_ops as T
+    K, N = 768, 3072
+    g = np.random.Generator(np.random.PCG64(M + 7))
+    x16 = torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    w = torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(g.standard_normal(N).astype(np.float32)).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    u = torch.empty((M, N), device=dev)
+    f = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.igemm(x16, wp, M, K, N, u, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, out_aux=f)
+    u0 = torch.empty_like(u)
+    ops.igemm(x16, wp, M, K, N, u0, bias=b, bf16=True, a16=True)
+    f0 = torch.empty_like(f)
+    ops.igemm(x16, wp, M, K, N, f0, bias=b, epilogue=ops.EPI_GELU, bf16=True, a16=True, o16=True)
+    assert torch.equal(u, u0) and torch.equal(f, f0)
+    fp = T.gelu(u, out_bf16=True)                                               # library erff
+    # (the fast erf is 1.5e-7 ABSOLUTE from erff: in GELU's negative tail, where the result is ~1e-3 and below, that moves a bf16 rounding
+    # often — 0.2 % of all outputs differ, each by one bf16 step)
+    ne = (f != fp)
+    assert float(ne.float().mean()) < 5e-3, float(ne.float().mean())
+    assert bool(((f.float() - fp.float()).abs() <= fp.float().abs() * 2 ** -7 + 2e-7).all())
+    with pytest.raises(_lib.VfError):                                           # the aux output needs its epilogue, and the reverse
+        ops.igemm(x16, wp, M, K, N, u, bias=b, bf16=True, a16=True, out_aux=f)
+    with pytest.raises(_lib.VfError):
+        ops.igemm(x16, wp, M, K, N, u, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True)

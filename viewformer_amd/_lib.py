@@ -24,6 +24,7 @@ class VfIgemmArgs(ctypes.Structure):
         ('lda', c_int32), ('ldc', c_int32), ('ldr', c_int32), ('batch', c_int32),
         ('stride_x', c_int64), ('stride_w', c_int64), ('stride_out', c_int64), ('stride_res', c_int64),
         ('gn_part', c_void_p), ('gn_slots', c_int32), ('reserved0', c_int32),
+        ('out_aux', c_void_p),
     ]
 
 
@@ -132,7 +133,7 @@ EXPORTS = {
     'vf_colsum_workspace_bytes': (c_size_t, [c_int]),
     'vf_colsum_f32': (c_int, [P, P, c_int64, c_int, c_int64, c_int, P, P]),
     'vf_layernorm_bwd_workspace_bytes': (c_size_t, [c_int64, c_int]),
-    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, P]),
+    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, P, P]),
     'vf_gelu_f32': (c_int, [P, P, c_int64, P]),
     'vf_gelu_bf16out_f32': (c_int, [P, P, c_int64, P]),
     'vf_gelu_bwd_bf16out_f32': (c_int, [P, P, P, c_int64, P]),

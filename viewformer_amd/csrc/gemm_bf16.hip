@@ -584,7 +584,13 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if (a.mode != VF_MODE_GEMM || a.pro_mean) return VF_ERR_UNSUPPORTED;
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.epilogue == VF_EPI_GELU_BWD && !(a.reserved0 & 2)) return VF_ERR_UNSUPPORTED;      // (bf16-output form only)
+    if ((a.epilogue == VF_EPI_GELU_DUAL) != (a.out_aux != nullptr)) return VF_ERR_BAD_ARG;
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
+    if (a.epilogue == VF_EPI_GELU_DUAL) {             // the 256-tile kernel's fp32 epilogue only: no other kernel of this file writes out_aux
+        if ((a.reserved0 & 3) != 1 || a.batch > 1 || a.Cin % (2 * CK) != 0) return VF_ERR_UNSUPPORTED;
+        const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
+        return rc;                                    // (VF_ERR_UNSUPPORTED for shapes that kernel does not tile: the caller runs the two passes)
+    }
     const size_t smem = (size_t)2 * (A_BYTES + B_BYTES);
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
     if (vf_attr_needed(&attr_devs)) {

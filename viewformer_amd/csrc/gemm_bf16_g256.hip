@@ -66,6 +66,8 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
                                                int wave_n, int half, int l31, bool full, bool gelu) {
     const long long ldc = p.ldc, ldr = p.ldr;
     const bool has_res = p.res != nullptr;
+    const bool dual = p.epilogue == VF_EPI_GELU_DUAL;
+    const int odd = l31 & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
@@ -103,6 +105,24 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
                     if (row < rows_left) o[(long long)row * ldc] = v[r];
                 }
             }
+            if (dual) {
+                // VF_EPI_GELU_DUAL: v is the pre-activation just stored; its GELU goes out as bf16 — lane pairs swap half of their rows so
+                // every lane stores two adjacent columns of one row (g256_store_bf16's scheme)
+                __builtin_amdgcn_sched_barrier(0);
+                __bf16* o16 = reinterpret_cast<__bf16*>(p.out_aux) + (size_t)(rows_left > 0 ? m0 : 0) * ldc + (n - odd);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = vf_gelu_erf_fast(v[r]);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float give = odd ? v[r] : v[r + 1];
+                    const float got = __shfl_xor(give, 1, 64);
+                    const int row = ((r + odd) & 3) + 8 * ((r + odd) >> 2);
+                    bf16x2_t h;
+                    h[0] = (__bf16)(odd ? got : v[r]);
+                    h[1] = (__bf16)(odd ? v[r + 1] : got);
+                    if (full || row < rows_left) *reinterpret_cast<bf16x2_t*>(o16 + (long long)row * ldc) = h;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);          // one tile at a time
         }
     }
@@ -110,7 +130,9 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
 
 // bf16 output (bias + optional GELU, no residual): neighbouring lanes hold neighbouring columns, so each lane pair swaps half of its
 // rows and every lane stores two adjacent columns of one row (4 bytes) — same scheme as gemm_bf16_direct_kernel
-template <bool GELU, bool FULL>
+// EPI: 0 = bias, 1 = bias + GELU (forward), 2 = VF_EPI_GELU_BWD: (acc + bias) * gelu'(u), u = p.res[m][n] the saved fp32 pre-activation —
+// gemm_bf16_direct_kernel's expression (vf_gelu_grad_fast, explicitly rounded): the same bits as that kernel and as the stand-alone pass
+template <int EPI, bool FULL>
 __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
                                                 int wave_n, int half, int l31) {
     __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
@@ -123,10 +145,33 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
         for (int i = 0; i < 4; ++i) {
             const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
             float t[16];
+            if (EPI == 2) {
+                // four values at a time, fenced: sixteen interleaved gelu' evaluations beside the 128 accumulator registers spill
+                // (u through an SGPR buffer resource based at the tile's first row: one 32-bit lane offset per (i, j), the row step in an SGPR —
+                // no 64-bit lane addresses)
+                // (the resource ends with the matrix's last row: rows of a ragged last tile beyond M read as zero instead of faulting)
+                const __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.res + (size_t)m_tile0 * p.ldr), 0, (int)min((long long)0x7fffffff, (long long)(p.M - m_tile0) * p.ldr * 4),
+                    0x00020000);
+                const unsigned voff = ((unsigned)(m0 - m_tile0) * (unsigned)p.ldr + (unsigned)n) * 4u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                t[r] = acc[i][j][r] + bias;
-                if (GELU) t[r] = vf_gelu_erf_fast(t[r]);
+                for (int q = 0; q < 4; ++q) {
+                    float uu[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned soff = (unsigned)(e + 8 * q) * (unsigned)p.ldr * 4u;
+                        uu[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, voff, soff, 0));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[4 * q + e] = __fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bias), vf_gelu_grad_fast(uu[e]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    t[r] = acc[i][j][r] + bias;
+                    if (EPI == 1) t[r] = vf_gelu_erf_fast(t[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -311,12 +356,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     const bool full = m_tile0 + GM <= p.M;
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
     if (O16) {
+        const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
         if (full) {
-            if (gelu) g256_store_bf16<true, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else g256_store_bf16<false, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            if (gbwd) g256_store_bf16<2, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else if (gelu) g256_store_bf16<1, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else g256_store_bf16<0, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
         } else {
-            if (gelu) g256_store_bf16<true, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else g256_store_bf16<false, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            if (gbwd) g256_store_bf16<2, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else if (gelu) g256_store_bf16<1, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else g256_store_bf16<0, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
         }
         return;
     }
@@ -428,12 +476,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p
         const bool full = em + GM <= p.M;
         const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
         if (O16) {
+            const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
             if (full) {
-                if (gelu) g256_store_bf16<true, true>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else g256_store_bf16<false, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+                if (gbwd) g256_store_bf16<2, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else if (gelu) g256_store_bf16<1, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else g256_store_bf16<0, true>(p, acc, em, en, wave_m, wave_n, half, l31);
             } else {
-                if (gelu) g256_store_bf16<true, false>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else g256_store_bf16<false, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+                if (gbwd) g256_store_bf16<2, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else if (gelu) g256_store_bf16<1, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else g256_store_bf16<0, false>(p, acc, em, en, wave_m, wave_n, half, l31);
             }
         } else {
             g256_store_f32(p, acc, em, en, wave_m, wave_n, half, l31, full, gelu);
@@ -449,7 +500,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p
 int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     const bool a16 = a.reserved0 & 1, o16 = a.reserved0 & 2;
     if (!a16 || a.batch > 1 || a.Cout % GN != 0 || a.Cin % GK != 0 || a.M < GM || (a.lda & 7)) return VF_ERR_UNSUPPORTED;
-    if (o16 && (a.res || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
+    if (o16 && ((a.res && a.epilogue != VF_EPI_GELU_BWD) || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (GELU_BWD: `res` carries the pre-activation)
+    if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res)) return VF_ERR_UNSUPPORTED;
+    if (a.epilogue == VF_EPI_GELU_DUAL && (o16 || a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
     if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
     if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
@@ -464,12 +517,12 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     // persistent form (G256_PERSIST): 256 workgroups (one per CU; a multiple of the 8 XCDs) walk the tiles; VF_GEMM_G256P=0 keeps one tile per workgroup
     const char* pe = getenv("VF_GEMM_G256P");
     if (G256_PERSIST && G256_BUFFER && !(pe && pe[0] == '0') && (a.Cin / GK) % 2 == 0 && mt * nb > G256_PERSIST) {
-        static bool attr_p = false;
-        if (!attr_p) {
+        static unsigned long long attr_p_devs = 0;
+        if (vf_attr_needed(&attr_p_devs)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
             if (e != hipSuccess) return (int)e;
-            attr_p = true;
+            vf_attr_done(&attr_p_devs);
         }
         const dim3 gp((unsigned)G256_PERSIST);
         if (o16) hipLaunchKernelGGL((gemm_bf16_g256p_kernel<true>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);

@@ -101,7 +101,7 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgb_part, long long rows, int d, float eps,
-                                                            int rows_per_block, const float* __restrict__ res) {
+                                                            int rows_per_block, const float* __restrict__ res, __bf16* __restrict__ dx16) {
     // each wave walks rows_per_block/4 rows and keeps per-lane dgamma/dbeta partials in registers
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -166,18 +166,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     for (int e = 0; e < 4; ++e) o[e] += rv[e];
                 }
                 *reinterpret_cast<f32x4*>(dx + row * d + c * 4) = o;
+                if (dx16) {                                     // a bf16 copy for the GEMMs that take this gradient as an operand
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    bf16x4_t h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
+                    *reinterpret_cast<bf16x4_t*>(dx16 + row * d + c * 4) = h;
+                }
             }
         }
     }
-    // partial[block][wave][2][d]
-    float* p = dgb_part + ((long long)blockIdx.x * 4 + wave) * 2 * d;
+    // the block's four waves combine through LDS in a fixed order, (w0 + w1) + (w2 + w3); partial[block][2][d].  (One slab per WAVE — the first
+    // form — made the partial matrix 4800 x 1536 floats at the training shape: 29 MB written and read again per call.)
+    __shared__ f32x4 red[3][2][MAXV * 64];
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            *reinterpret_cast<f32x4*>(p + c * 4) = dg[i];
-            *reinterpret_cast<f32x4*>(p + d + c * 4) = db[i];
+        for (int i = 0; i < MAXV; ++i) { red[wave - 1][0][lane + 64 * i] = dg[i]; red[wave - 1][1][lane + 64 * i] = db[i]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* p = dgb_part + (long long)blockIdx.x * 2 * d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = __fadd_rn(__fadd_rn(dg[i][e], red[0][0][c][e]), __fadd_rn(red[1][0][c][e], red[2][0][c][e]));
+                    b[e] = __fadd_rn(__fadd_rn(db[i][e], red[0][1][c][e]), __fadd_rn(red[1][1][c][e], red[2][1][c][e]));
+                }
+                *reinterpret_cast<f32x4*>(p + c * 4) = a;
+                *reinterpret_cast<f32x4*>(p + d + c * 4) = b;
+            }
         }
+    }
+}
+
+// column sums of the [prow][2d] partial matrix straight into dgamma (columns < d) and dbeta: 16 columns per block as four float4 lanes,
+// 64 row phases; phases combine by lane shuffles inside a wave and through LDS across the four waves — a fixed order
+__global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const float* __restrict__ part, long long prow, int d, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int accumulate) {
+    __shared__ f32x4 red[4][4];
+    const int tid = threadIdx.x, cl = tid & 3, ph = tid >> 2, wave = tid >> 6;
+    const int col = blockIdx.x * 16 + cl * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (col < 2 * d) {
+        long long r = ph;
+        for (; r + 64 < prow; r += 128) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(part + r * 2 * d + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(part + (r + 64) * 2 * d + col);
+            s0 += a;
+            s1 += b;
+        }
+        if (r < prow) s0 += *reinterpret_cast<const f32x4*>(part + r * 2 * d + col);
+    }
+    f32x4 s = s0 + s1;
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], off, 64);
+    }
+    if ((tid & 63) < 4) red[wave][cl] = s;
+    __syncthreads();
+    if (tid < 4 && col < 2 * d) {
+        const f32x4 t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float* o = col < d ? dgamma + col : dbeta + (col - d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = accumulate ? o[e] + t[e] : t[e];
     }
 }
 
@@ -539,31 +595,23 @@ constexpr int LN_BWD_RPB = 16;
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
     if (rows <= 0 || d <= 0) return 0;
     const int64_t blocks = (rows + LN_BWD_RPB - 1) / LN_BWD_RPB;
-    // [blocks*4][2d] per-wave partials + [64][2d] column-sum scratch + [2d] result
-    return ((size_t)blocks * 4 * 2 * d + (size_t)64 * 2 * d + (size_t)2 * d) * sizeof(float);
+    return (size_t)blocks * 2 * d * sizeof(float);      // [blocks][2d] per-block partials of dgamma | dbeta
 }
 
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                         int64_t rows, int d, float eps, int accumulate, const float* res, void* ws, void* stream) {
+                         int64_t rows, int d, float eps, int accumulate, const float* res, void* dx_bf16, void* ws, void* stream) {
     if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !ws || rows <= 0 || d <= 0) return VF_ERR_BAD_ARG;
     if ((d & 3) || d > 1024) return VF_ERR_UNSUPPORTED;
     const int rpb = LN_BWD_RPB;
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
-    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
-    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res);
+    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
     int st = vf_last_status();
     if (st) return st;
-    // partial layout [blocks*4][2][d]: reduce the (blocks*4) rows of the [.., 2d] matrix
-    const int64_t prow = (int64_t)blocks * 4;
-    // column sums of a [prow][2d] matrix -> [2d]; dgamma = first d, dbeta = second d.  Reuse colsum with a private tail of ws.
-    float* tmp = (float*)ws + (size_t)prow * 2 * d;    // caller sized ws via vf_layernorm_bwd_workspace_bytes + colsum ws
-    float* outv = tmp + (size_t)64 * 2 * d;
-    st = colsum_launch((const float*)ws, outv, prow, 2 * d, 2 * d, 0, tmp, 64, stream);     // tmp holds 64 split rows
-    if (st) return st;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv, dgamma, d, 1, accumulate);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, s, outv + d, dbeta, d, 1, accumulate);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((unsigned)((2 * d + 15) / 16)), dim3(256), 0, s, (const float*)ws, (long long)blocks, d, dgamma,
+                       dbeta, accumulate);
     return vf_last_status();
 }
 

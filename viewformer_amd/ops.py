@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import VfIgemmArgs, check
 
 MODE_GEMM, MODE_CONV3_S1, MODE_CONV3_S2PAD, MODE_CONV3_UP2 = 0, 1, 2, 3
-EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_GELU_DUAL = 0, 1, 2, 3
 
 
 def _stream():
@@ -264,13 +264,14 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
-          x3h=False, a16=False, o16=False):
+          x3h=False, a16=False, o16=False, out_aux=None):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
     split-bf16 kernel (vf_conv3_halo_x6).
     ``gn_part``: fp32 [Nimg][halo_gn_slots(Hout, Wout)][32][2] buffer that receives the GroupNorm partial statistics of the
-    output (halo kernels only; reduce with groupnorm_finalize)."""
+    output (halo kernels only; reduce with groupnorm_finalize).
+    ``out_aux`` (with ``epilogue=EPI_GELU_DUAL``, bf16 arm, bf16 x, fp32 out): bf16 [M][ldc] that receives gelu(out)."""
     lib = _lib.load()
     if not 0 <= M < 2 ** 31 or max(Cin, Cout, Hin, Win, Hout, Wout, batch) >= 2 ** 31:
         # vf_igemm_args carries 32-bit row / channel counts (byte offsets inside the kernels are 64-bit): refuse instead of wrapping
@@ -282,6 +283,11 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     a.bias = bias.data_ptr() if bias is not None else None
     a.res = res.data_ptr() if res is not None else None
     a.out = out.data_ptr()
+    if out_aux is not None:
+        _chk(out_aux, torch.bfloat16, 'out_aux')
+        if out_aux.shape != out.shape or not out_aux.is_contiguous():
+            raise _lib.VfError('out_aux must have the shape and row stride of out')
+        a.out_aux = out_aux.data_ptr()
     if pro is not None:
         mean_c, scale_c, beta = pro
         a.pro_mean, a.pro_scale, a.pro_beta = mean_c.data_ptr(), scale_c.data_ptr(), beta.data_ptr()

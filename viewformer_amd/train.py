@@ -274,9 +274,20 @@ class MIGTTrainer:
             ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
-    def _ln_bwd(self, name, dy, x, M, res=None):
+    def _ln_bwd(self, name, dy, x, M, res=None, also_bf16=False):
         d = self.cfg.d_model
-        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res)
+        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res, also_bf16=also_bf16)
+
+    fuse_gelu_forward = True          # bf16 arm: c_fc writes u (fp32, saved) and bf16 gelu(u) from one epilogue (VF_EPI_GELU_DUAL); the GELU there
+                                      # is the inference arm's vf_gelu_erf_fast (|err| 1.5e-7: a few outputs round to the neighbouring bf16)
+
+    def _gelu_dual_ok(self, M):
+        c = self.cfg
+        return M >= 256 and c.d_model % 128 == 0 and (4 * c.d_model) % 256 == 0
+
+    bf16_residual_gradient = True     # bf16 arm: the LayerNorm backward also writes its result as bf16 — the operand of the two projection
+                                      # layers' backward GEMMs, which then run on the 256-tile kernel (the rounding is the one the GEMM's operand
+                                      # load applied anyway; only the two bias gradients see it)
 
     one_launch_repack = True          # bf16 arm: all weight packings refreshed by one launch per step
     _pack16 = None
@@ -428,8 +439,15 @@ class MIGTTrainer:
             else:
                 h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
             n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d, out_bf16=act16)
-            u = self._linear(n2, p + '.mlp.c_fc', M)
-            f = T.gelu(u, out_bf16=act16)
+            if act16 and self.fuse_gelu_forward and self._gelu_dual_ok(M):
+                # c_fc keeps the fp32 pre-activation for the backward pass AND hands bf16 gelu(u) to mlp.c_proj from one epilogue
+                dn = m._dense[p + '.mlp.c_fc']
+                u = torch.empty((M, dn.n), dtype=torch.float32, device=dev)
+                f = torch.empty((M, dn.n), dtype=torch.bfloat16, device=dev)
+                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, out_aux=f)
+            else:
+                u = self._linear(n2, p + '.mlp.c_fc', M)
+                f = T.gelu(u, out_bf16=act16)
             if rate:                                                                 # MLP dropout, migt.py:72
                 y = self._linear(f, p + '.mlp.c_proj', M)
                 h_out = T.dropout_add(y, rate, seed, site_mlp(i), res=h_mid, out=y)
@@ -512,21 +530,24 @@ class MIGTTrainer:
             dup = T.gelu_bwd(up, dp1)
             dhl = self._linear_bwd('pose_criterion.pose_classifier.c_fc', hloc, dup, M1)
             dhf[:, 2] = dhl.view(B, S, L, d)
-        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M)
+        res16 = grad16 and self.bf16_residual_gradient and self.fuse_gelu_backward
+        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M, also_bf16=res16)
+        dh, dh16 = dh if res16 else (dh, None)
         handles = []
         overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
             if grad16 and self.fuse_gelu_backward:                                   # GELU backward in the epilogue of the dX GEMM that feeds it
-                du = self._linear_bwd(p + '.mlp.c_proj', f, dh, M, dx_bf16=True, gelu_bwd_u=u)
+                du = self._linear_bwd(p + '.mlp.c_proj', f, dh16 if res16 else dh, M, dx_bf16=True, gelu_bwd_u=u)
             else:
                 df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
                 du = T.gelu_bwd(u, df, out_bf16=grad16)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
-            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh)                  # (+ the residual branch's gradient, same pass)
-            datt = self._linear_bwd(p + '.attn.c_proj', att, T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid, M,
-                                    dx_bf16=attn16)
+            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh, also_bf16=res16)  # (+ the residual branch's gradient, same pass)
+            dh_mid, dh_mid16 = dh_mid if res16 else (dh_mid, None)
+            datt = self._linear_bwd(p + '.attn.c_proj', att,
+                                    dh_mid16 if res16 else (T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid), M, dx_bf16=attn16)
             if attn16:
                 dqkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if grad16 else torch.float32, device=dev)
                 T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
@@ -534,7 +555,8 @@ class MIGTTrainer:
             else:
                 dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
-            dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid)
+            dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid, also_bf16=res16 and i > 0)
+            dh, dh16 = dh if (res16 and i > 0) else (dh, None)
             saved[i] = None
             if overlap:                                                              # this layer's grads are final
                 handles.append(self._allreduce_range(*self.layer_ranges[i]))

@@ -45,14 +45,16 @@ def colsum(x, out, M, N, ld=None, accumulate=False):
     return out
 
 
-def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True, res=None):
-    """``res``: the residual branch's gradient, added to dx in the same pass (dx = LN'(dy) + res)"""
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True, res=None, also_bf16=False):
+    """``res``: the residual branch's gradient, added to dx in the same pass (dx = LN'(dy) + res); ``also_bf16``: returns (dx, bf16 copy)"""
     lib = _lib.load()
     dx = torch.empty_like(x)
+    dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if also_bf16 else None
     ws = _ws(int(lib.vf_layernorm_bwd_workspace_bytes(rows, d)), x.device, 'lnbwd')
     check(lib.vf_layernorm_bwd_f32(_p(_f32(dy)), _p(_f32(x)), _p(_f32(gamma)), _p(dx), _p(dgamma), _p(dbeta), rows, d, eps,
-                                   1 if accumulate else 0, _p(_f32(res)) if res is not None else None, _p(ws), _stream()), 'vf_layernorm_bwd_f32')
-    return dx
+                                   1 if accumulate else 0, _p(_f32(res)) if res is not None else None, _p(dx16), _p(ws), _stream()),
+          'vf_layernorm_bwd_f32')
+    return (dx, dx16) if also_bf16 else dx
 
 
 def gelu(u, out_bf16=False):
