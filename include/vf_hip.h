@@ -417,9 +417,12 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
 /* weight + bias gradient of a dense layer in the bf16 training arm (csrc/gemm_tn_bf16.hip): for split s of the M rows,
  * w_slabs[s][K][N] = sum_m x[m][k] * dy[m][n] and (b_slabs != NULL) b_slabs[s][N] = sum_m dy[m][n], with x a saved bf16 activation
  * [M][ldx] and dy the fp32 gradient [M][ldy], both read as they lie (no transposed copy, no packed copy, no separate column-sum pass).
- * Fold the slabs with vf_sum_slabs_f32 (fixed order).  K % 256 == N % 256 == M % 64 == 0; autograd of Conv1D.call (migt.py:89-96). */
+ * Fold the slabs with vf_sum_slabs_f32 (fixed order).  K % 256 == N % 256 == M % 64 == 0; autograd of Conv1D.call (migt.py:89-96).
+ * slab_stride (floats): 0 = the two arrays above; > 0 = split s writes its weight slab at w_slabs + s*slab_stride and its bias slab at
+ * b_slabs + s*slab_stride, so with b_slabs = w_slabs + K*N and a gradient buffer that holds the bias right after the weight ONE
+ * vf_sum_slabs_f32 over K*N + N floats folds both. */
 int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16, int ldy, int M, int K, int N, int splits, float* w_slabs,
-                    float* b_slabs, void* stream);      /* dy_is_bf16: the gradient arrives already rounded to bf16 (ldy in elements) */
+                    float* b_slabs, int64_t slab_stride, void* stream);      /* dy_is_bf16: the gradient arrives already rounded to bf16 (ldy in elements) */
 /* bf16 arm of the training step's attention (csrc/attention_dma.hip, attention_train_bf16.hip): bf16 q / k / v / out / dout in HBM
  * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views, no attention dropout — VF_ERR_UNSUPPORTED
  * otherwise (callers then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the

@@ -654,6 +654,9 @@ def test_tn_weight_gradient_gemm(dev, M, K, N):
     dw2, db2 = dw0.clone(), db0.clone()
     ops.gemm_tn_bf16(x16, dy, M, K, N, dw2, db2)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)                        # deterministic
+    flat = torch.cat([dw0.reshape(-1), db0])                                    # the trainer's layout (bias right behind the weight): ONE slab sum
+    ops.gemm_tn_bf16(x16, dy, M, K, N, flat[:K * N].view(K, N), flat[K * N:])
+    assert torch.equal(flat[:K * N].view(K, N), dw) and torch.equal(flat[K * N:], db)
     # the gradient arriving already rounded to bf16 (its producer wrote the rounding this kernel applies): the same products in the
     # same order -> the same dW bit for bit; db becomes the sum of the rounded values
     dw3, db3 = dw0.clone(), db0.clone()

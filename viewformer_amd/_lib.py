@@ -89,7 +89,7 @@ EXPORTS = {
     'vf_attn_bwd_prep_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
-    'vf_gemm_tn_bf16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    'vf_gemm_tn_bf16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
     'vf_attn_blockcausal_bf16_lse': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'vf_attn_bwd_prep_bf16': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_bf16': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

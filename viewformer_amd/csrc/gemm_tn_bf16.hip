@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 template <bool Y16>
 __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __restrict__ x, const void* __restrict__ dy_,
                                                               float* __restrict__ w_slabs, float* __restrict__ b_slabs, int M, int K, int N,
-                                                              int ldx, int ldy) {
+                                                              int ldx, int ldy, long long w_stride, long long b_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x (X image | dY image)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
     }
 
     // ---- the split's slab of dW: row k = 256 tk + 128 wk + 32 a + (r & 3) + 8 (r >> 2) + 4 half, column n = 256 tn + 64 wn + 32 b + l31
-    float* slab = w_slabs + (size_t)split * K * N + (size_t)(tk * TK + wk * 128) * N + tn * TN_ + wn * 64;
+    float* slab = w_slabs + (size_t)split * w_stride + (size_t)(tk * TK + wk * 128) * N + tn * TN_ + wn * 64;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += red[g * 256 + tid];
-            b_slabs[(size_t)split * N + tn * TN_ + tid] = s;
+            b_slabs[(size_t)split * b_stride + tn * TN_ + tid] = s;
         }
     }
 }
@@ -185,8 +185,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 extern "C" {
 
 int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16, int ldy, int M, int K, int N, int splits, float* w_slabs,
-                    float* b_slabs, void* stream) {
+                    float* b_slabs, int64_t slab_stride, void* stream) {
     if (!x_bf16 || !dy || !w_slabs || M <= 0 || K <= 0 || N <= 0 || splits < 1) return VF_ERR_BAD_ARG;
+    // slab_stride 0: weight slabs K*N apart, bias slabs N apart (two arrays); > 0: ONE array of `splits` records, the split's weight slab at
+    // w_slabs + s * slab_stride and its bias slab at b_slabs + s * slab_stride (b_slabs = w_slabs + K*N: one vf_sum_slabs_f32 folds both)
+    if (slab_stride != 0 && (slab_stride < (int64_t)K * N + (b_slabs ? N : 0) || (slab_stride & 3))) return VF_ERR_BAD_ARG;
+    const long long w_stride = slab_stride ? slab_stride : (long long)K * N, b_stride = slab_stride ? slab_stride : N;
     if (ldx < K || ldy < N) return VF_ERR_BAD_ARG;
     if (K % TK || N % TN_ || M % CM || (ldx & 7) || (ldy & (dy_is_bf16 ? 7 : 3)) || splits > M / CM) return VF_ERR_UNSUPPORTED;
     if (((uintptr_t)x_bf16 | (uintptr_t)dy | (uintptr_t)w_slabs) & 15) return VF_ERR_UNSUPPORTED;
@@ -201,10 +205,10 @@ int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16,
     const dim3 grid((unsigned)((K / TK) * (N / TN_)), (unsigned)splits);
     if (dy_is_bf16)
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
-                           w_slabs, b_slabs, M, K, N, ldx, ldy);
+                           w_slabs, b_slabs, M, K, N, ldx, ldy, w_stride, b_stride);
     else
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
-                           w_slabs, b_slabs, M, K, N, ldx, ldy);
+                           w_slabs, b_slabs, M, K, N, ldx, ldy, w_stride, b_stride);
     return vf_last_status();
 }
 

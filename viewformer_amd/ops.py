@@ -250,14 +250,21 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
     _chk(x16, torch.bfloat16, 'x16')
     tiles = (K // 256) * (N // 256)
     splits = max(1, min(M // 64, 256 // tiles if tiles <= 256 else 1))
-    ws = torch.empty((splits, K, N), dtype=torch.float32, device=dy.device)
-    bs = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if db is not None else None
+    # one array of `splits` records (weight slab | bias slab): where the gradient buffer holds the bias right behind the weight (the trainer's
+    # flat buffer does), ONE slab sum folds both
+    rec = K * N + (N if db is not None else 0)
+    ws = torch.empty((splits, rec), dtype=torch.float32, device=dy.device)
     y16 = dy.dtype == torch.bfloat16
-    check(lib.vf_gemm_tn_bf16(_p(x16), x16.stride(0), _p(dy if y16 else _f32(dy)), 1 if y16 else 0, dy.stride(0), M, K, N, splits, _p(ws), _p(bs),
-                              _stream()), 'vf_gemm_tn_bf16')
-    check(lib.vf_sum_slabs_f32(_p(ws), splits, K * N, K * N, _p(_f32(dw)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')
-    if db is not None:
-        check(lib.vf_sum_slabs_f32(_p(bs), splits, N, N, _p(_f32(db)), 1 if accumulate else 0, _stream()), 'vf_sum_slabs_f32')
+    check(lib.vf_gemm_tn_bf16(_p(x16), x16.stride(0), _p(dy if y16 else _f32(dy)), 1 if y16 else 0, dy.stride(0), M, K, N, splits, _p(ws),
+                              ws.data_ptr() + K * N * 4 if db is not None else None, rec, _stream()), 'vf_gemm_tn_bf16')
+    acc = 1 if accumulate else 0
+    _f32(dw)
+    if db is not None and _f32(db).data_ptr() == dw.data_ptr() + K * N * 4 and dw.is_contiguous():
+        check(lib.vf_sum_slabs_f32(_p(ws), splits, rec, rec, _p(dw), acc, _stream()), 'vf_sum_slabs_f32')
+    else:
+        check(lib.vf_sum_slabs_f32(_p(ws), splits, rec, K * N, _p(dw), acc, _stream()), 'vf_sum_slabs_f32')
+        if db is not None:
+            check(lib.vf_sum_slabs_f32(ws.data_ptr() + K * N * 4, splits, rec, N, _p(db), acc, _stream()), 'vf_sum_slabs_f32')
     return dw
 
 
