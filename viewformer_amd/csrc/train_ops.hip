@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __res
 
 // ------------------------------------------------------------------ LayerNorm backward (one wave per row)
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma/dbeta partials per row-block
-template <int MAXV>
+// R rows of a wave are in flight together (their loads issued back to back, their wave reductions interleaved): with one row at a time the
+// four dependent reductions of a row had nothing to overlap with (83 us for 265 MB at the training shape)
+template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgb_part, long long rows, int d, float eps,
@@ -109,69 +111,101 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) { dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (long long row = r0 + wave; row < min(rows, r0 + rows_per_block); row += 4) {
-        f32x4 xv[MAXV], gv[MAXV], dyv[MAXV];
-        float s = 0.f;
+    const long long rend = min(rows, r0 + rows_per_block);
+    for (long long rowb = r0 + wave; rowb < rend; rowb += 4 * R) {
+        f32x4 xv[R][MAXV], gv[R][MAXV], dyv[R][MAXV];
+        long long row[R];
+        bool live[R];
+        float s[R];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                xv[i] = *reinterpret_cast<const f32x4*>(x + row * d + c * 4);
-                dyv[i] = *reinterpret_cast<const f32x4*>(dy + row * d + c * 4);
-                s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-            }
-        }
-        const float mean = vf_wave_sum(s) / (float)d;
-        float q = 0.f;
+        for (int q = 0; q < R; ++q) {
+            live[q] = rowb + 4 * q < rend;
+            row[q] = live[q] ? rowb + 4 * q : rowb;             // (a dead slot re-reads the first row and stores nothing)
+            s[q] = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float t = xv[i][e] - mean; q += t * t; }
-            }
-        }
-        const float rstd = 1.0f / sqrtf(vf_wave_sum(q) / (float)d + eps);
-        float sg = 0.f, sgx = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (xv[i][e] - mean) * rstd;
-                    const float g = dyv[i][e] * gm[e];
-                    gv[i][e] = g;
-                    xv[i][e] = xh;
-                    sg += g;
-                    sgx += g * xh;
-                    dg[i][e] += dyv[i][e] * xh;
-                    db[i][e] += dyv[i][e];
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    xv[q][i] = *reinterpret_cast<const f32x4*>(x + row[q] * d + c * 4);
+                    dyv[q][i] = *reinterpret_cast<const f32x4*>(dy + row[q] * d + c * 4);
                 }
             }
         }
-        sg = vf_wave_sum(sg) / (float)d;
-        sgx = vf_wave_sum(sgx) / (float)d;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                f32x4 o;
+        for (int q = 0; q < R; ++q) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[i][e] - sg - xv[i][e] * sgx);
-                if (res) {                                      // the residual branch's gradient joins here (was a separate add pass)
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + row * d + c * 4);
+            for (int i = 0; i < MAXV; ++i)
+                if (lane + 64 * i < nv) s[q] += (xv[q][i][0] + xv[q][i][1]) + (xv[q][i][2] + xv[q][i][3]);
+        }
+        float mean[R], rstd[R], qq[R], sg[R], sgx[R];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        for (int q = 0; q < R; ++q) mean[q] = vf_wave_sum(s[q]) / (float)d;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            qq[q] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (lane + 64 * i < nv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = xv[q][i][e] - mean[q]; qq[q] += t * t; }
                 }
-                *reinterpret_cast<f32x4*>(dx + row * d + c * 4) = o;
-                if (dx16) {                                     // a bf16 copy for the GEMMs that take this gradient as an operand
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    bf16x4_t h;
+            }
+        }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
-                    *reinterpret_cast<bf16x4_t*>(dx16 + row * d + c * 4) = h;
+        for (int q = 0; q < R; ++q) rstd[q] = 1.0f / sqrtf(vf_wave_sum(qq[q]) / (float)d + eps);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            sg[q] = 0.f;
+            sgx[q] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[q][i][e] - mean[q]) * rstd[q];
+                        const float g = dyv[q][i][e] * gm[e];
+                        gv[q][i][e] = g;
+                        xv[q][i][e] = xh;
+                        sg[q] += g;
+                        sgx[q] += g * xh;
+                        if (live[q]) {
+                            dg[i][e] += dyv[q][i][e] * xh;
+                            db[i][e] += dyv[q][i][e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            sg[q] = vf_wave_sum(sg[q]) / (float)d;
+            sgx[q] = vf_wave_sum(sgx[q]) / (float)d;
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if (!live[q]) continue;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd[q] * (gv[q][i][e] - sg[q] - xv[q][i][e] * sgx[q]);
+                    if (res) {                                      // the residual branch's gradient joins here (was a separate add pass)
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(res + row[q] * d + c * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                    }
+                    *reinterpret_cast<f32x4*>(dx + row[q] * d + c * 4) = o;
+                    if (dx16) {                                     // a bf16 copy for the GEMMs that take this gradient as an operand
+                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                        bf16x4_t h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
+                        *reinterpret_cast<bf16x4_t*>(dx16 + row[q] * d + c * 4) = h;
+                    }
                 }
             }
         }
@@ -590,7 +624,10 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 }
 
 // rows per block of the backward kernel (4 per wave).  64 rows per block left the 19 200-row training matrices on 1200 waves — about one
-// per SIMD, each walking 16 rows whose four dependent wave reductions nothing overlapped: 76-105 us for 236 MB (2.2 TB/s)
+// per SIMD, each walking 16 rows whose four dependent wave reductions nothing overlapped: 76-105 us for 236 MB (2.2 TB/s).  Round 3, at
+// 19 200 x 768 with the residual and the bf16 copy (265 MB), kernel + finalize: 16 rows, one row at a time, four float4 slots per lane 89 us;
+// three slots (d = 768 exactly) 69-70 us; two rows in flight 62-64 us (4.2-4.3 TB/s); 8 rows per block 64-65, 4 rows 70-80
+// (tools/bench_ln_bwd.py)
 constexpr int LN_BWD_RPB = 16;
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
     if (rows <= 0 || d <= 0) return 0;
@@ -605,9 +642,16 @@ int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, fl
     const int rpb = LN_BWD_RPB;
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
-    if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
-    else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, (long long)rows, d, eps, rpb, res, reinterpret_cast<__bf16*>(dx_bf16));
+    __bf16* d16 = reinterpret_cast<__bf16*>(dx_bf16);
+    const char* r1 = getenv("VF_LN_BWD_R1");              // A/B switch: one row per wave at a time (the first form; the same bits)
+    const bool one = r1 && r1[0] == '1';
+#define VF_LN_BWD_LAUNCH(MV, RR) hipLaunchKernelGGL((layernorm_bwd_kernel<MV, RR>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, \
+                                                    (long long)rows, d, eps, rpb, res, d16)
+    if (d <= 256) { if (one) VF_LN_BWD_LAUNCH(1, 1); else VF_LN_BWD_LAUNCH(1, 2); }
+    else if (d <= 512) { if (one) VF_LN_BWD_LAUNCH(2, 1); else VF_LN_BWD_LAUNCH(2, 2); }
+    else if (d <= 768) { if (one) VF_LN_BWD_LAUNCH(3, 1); else VF_LN_BWD_LAUNCH(3, 2); }      // (d_model 768: three float4 per lane exactly)
+    else { if (one) VF_LN_BWD_LAUNCH(4, 1); else VF_LN_BWD_LAUNCH(4, 2); }
+#undef VF_LN_BWD_LAUNCH
     int st = vf_last_status();
     if (st) return st;
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((unsigned)((2 * d + 15) / 16)), dim3(256), 0, s, (const float*)ws, (long long)blocks, d, dgamma,
