@@ -62,8 +62,10 @@ enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1,
        VF_EPI_GELU_BWD = 2,     /* vf_gemm_bf16 with bf16 output only: out = bf16(acc * gelu'(res[m][n])) — `res` carries the saved fp32
                                    pre-activation, not a residual: the GELU backward of the training step inside the dX GEMM that
                                    produces its input (migt.py:70 under autograd) */
-       VF_EPI_GELU_DUAL = 3 };  /* vf_gemm_bf16, bf16 activations in, fp32 out, 256-aligned shapes only: out = acc + bias (fp32) AND
-                                   out_aux = bf16(gelu(out)) — see vf_igemm_args.out_aux */
+       VF_EPI_GELU_DUAL = 3 };  /* vf_gemm_bf16, bf16 activations in, 256-aligned shapes only: out = acc + bias (fp32, or bf16 with the
+                                   bf16-output flag) AND out_aux = bf16(gelu(acc + bias)) — see vf_igemm_args.out_aux.
+                                   vf_gemm_bf16's dtype flags live in reserved0: bit 0 bf16 activations in, bit 1 bf16 out, bit 2
+                                   (VF_EPI_GELU_BWD only) the pre-activation behind `res` is bf16 [M][ldr] */
 
 typedef struct vf_igemm_args {
     const float* x;          /* GEMM: [M][lda]; conv: NHWC [Nimg][Hin][Win][Cin] */
@@ -92,7 +94,7 @@ typedef struct vf_igemm_args {
     int32_t gn_slots;
     int32_t reserved0;       /* vf_gemm_x6 only: split-K count S > 1 -> S raw partial slabs at out + s*stride_out (no bias /
                               * residual / epilogue), to be summed by vf_sum_slabs_f32; 0 or 1 = off */
-    void* out_aux;           /* VF_EPI_GELU_DUAL only (vf_gemm_bf16, bf16 activations in, fp32 out): bf16 [M][ldc] that receives
+    void* out_aux;           /* VF_EPI_GELU_DUAL only (vf_gemm_bf16, bf16 activations in, fp32 or bf16 out): bf16 [M][ldc] that receives
                               * gelu(out) beside the fp32 pre-activation `out` — the training forward's c_fc keeps u for the backward
                               * pass and hands f to mlp.c_proj from ONE epilogue.  NULL otherwise (other entry points refuse it). */
 } vf_igemm_args;

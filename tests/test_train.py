@@ -743,6 +743,20 @@ def test_gelu_dual_epilogue_of_the_256_tile_kernel(dev, M):
     ne = (f != fp)
     assert float(ne.float().mean()) < 5e-3, float(ne.float().mean())
     assert bool(((f.float() - fp.float()).abs() <= fp.float().abs() * 2 ** -7 + 2e-7).all())
+    # the pre-activation itself as bf16 (the training arm's default): the rounded fp32 value; the GELU beside it is unchanged (it is taken
+    # from the fp32 accumulator, not from the rounded u)
+    u16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    f2 = torch.empty_like(f)
+    ops.igemm(x16, wp, M, K, N, u16, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=True, out_aux=f2)
+    assert torch.equal(u16, u.to(torch.bfloat16)) and torch.equal(f2, f)
+    # ... and the GELU-backward epilogue reading that bf16 u: the bits of the same epilogue on the widened copy
+    dy16 = torch.from_numpy((g.standard_normal((M, K)) * 0.1).astype(np.float32)).to(dev).to(torch.bfloat16)
+    wt = ops.pack_dense_kn_bf16(torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev))
+    du_a = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    du_b = torch.empty_like(du_a)
+    ops.igemm(dy16, wt, M, K, N, du_a, res=u16, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True)
+    ops.igemm(dy16, wt, M, K, N, du_b, res=u16.float(), epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
+    assert torch.equal(du_a, du_b)
     with pytest.raises(_lib.VfError):                                           # the aux output needs its epilogue, and the reverse
         ops.igemm(x16, wp, M, K, N, u, bias=b, bf16=True, a16=True, out_aux=f)
     with pytest.raises(_lib.VfError):

@@ -587,7 +587,7 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
     if ((a.epilogue == VF_EPI_GELU_DUAL) != (a.out_aux != nullptr)) return VF_ERR_BAD_ARG;
     if (a.lda < a.Cin || (a.lda & 3) || a.ldc < a.Cout || (a.res && a.ldr < a.Cout)) return VF_ERR_BAD_ARG;
     if (a.epilogue == VF_EPI_GELU_DUAL) {             // the 256-tile kernel's fp32 epilogue only: no other kernel of this file writes out_aux
-        if ((a.reserved0 & 3) != 1 || a.batch > 1 || a.Cin % (2 * CK) != 0) return VF_ERR_UNSUPPORTED;
+        if (!(a.reserved0 & 1) || a.batch > 1 || a.Cin % (2 * CK) != 0) return VF_ERR_UNSUPPORTED;      // (bf16 activations in; out fp32 or bf16)
         const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
         return rc;                                    // (VF_ERR_UNSUPPORTED for shapes that kernel does not tile: the caller runs the two passes)
     }
@@ -618,6 +618,10 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
         if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res && a.ldr >= a.Cout)) return VF_ERR_BAD_ARG;
         // large token matrices with 256-aligned widths: the 256 x 256 LDS-DMA kernel (bit-identical results; VF_GEMM_G256=0 keeps
         // the 128 x 128 kernel for A/B runs)
+        if (a.reserved0 & 4) {                                  // a bf16 pre-activation behind `res` (VF_EPI_GELU_BWD): the 256-tile kernel only
+            if (a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;
+            return vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
+        }
         const char* g256_env = getenv("VF_GEMM_G256");          // (read per call: the parity test flips it in-process)
         if (!(g256_env && g256_env[0] == '0')) {
             const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);

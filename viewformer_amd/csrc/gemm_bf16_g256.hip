@@ -146,24 +146,49 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
             const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
             float t[16];
             if (EPI == 2) {
-                // four values at a time, fenced: sixteen interleaved gelu' evaluations beside the 128 accumulator registers spill
-                // (u through an SGPR buffer resource based at the tile's first row: one 32-bit lane offset per (i, j), the row step in an SGPR —
-                // no 64-bit lane addresses)
-                // (the resource ends with the matrix's last row: rows of a ragged last tile beyond M read as zero instead of faulting)
+                // u through an SGPR buffer resource based at the tile's first row (32-bit lane offsets, no 64-bit lane addresses) that ends
+                // with the matrix's last row: rows of a ragged last tile beyond M read as zero instead of faulting.  All of a 32 x 32 block's
+                // loads are issued first; the gelu' evaluations then run four at a time, fenced (sixteen interleaved beside the 128
+                // accumulator registers spill; fencing the LOADS per four exposed their latency 32 times per tile: 196 us in the step).
+                // reserved0 bit 2: u was saved as bf16 — [M][ldr] 2-byte elements behind the same pointer
+                const bool u16 = p.reserved0 & 4;
+                const unsigned esz = u16 ? 2u : 4u;
                 const __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(p.res + (size_t)m_tile0 * p.ldr), 0, (int)min((long long)0x7fffffff, (long long)(p.M - m_tile0) * p.ldr * 4),
-                    0x00020000);
-                const unsigned voff = ((unsigned)(m0 - m_tile0) * (unsigned)p.ldr + (unsigned)n) * 4u;
+                    const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.res) + (size_t)m_tile0 * p.ldr * esz), 0,
+                    (int)min((long long)0x7fffffff, (long long)(p.M - m_tile0) * p.ldr * esz), 0x00020000);
+                float uu[16];
+                if (u16) {
+                    // bf16 u: lane pairs share dwords — the even lane fetches (n, n+1) of row r, the odd lane (n-1, n) of row r+1, and one
+                    // exchange hands each lane its own column of both rows (2-byte lane loads ran at a third of the dword rate)
+                    const unsigned voff = ((unsigned)(m0 - m_tile0) * (unsigned)p.ldr + (unsigned)(n - odd)) * 2u;
+                    unsigned w[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float uu[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned soff = (unsigned)(e + 8 * q) * (unsigned)p.ldr * 4u;
-                        uu[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, voff, soff, 0));
+                    for (int r = 0; r < 16; r += 2) {
+                        const int row = ((r + odd) & 3) + 8 * ((r + odd) >> 2);
+                        w[r >> 1] = __builtin_amdgcn_raw_buffer_load_b32(u_rs, voff + (unsigned)row * (unsigned)p.ldr * 2u, 0, 0);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[4 * q + e] = __fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bias), vf_gelu_grad_fast(uu[e]));
+                    for (int r = 0; r < 16; r += 2) {
+                        const unsigned mine = w[r >> 1];
+                        const unsigned give = odd ? (mine << 16) : (mine & 0xffff0000u);      // as fp32 bits: odd gives its low half, even its high half
+                        const unsigned got = (unsigned)__shfl_xor((int)give, 1, 64);
+                        uu[r] = __builtin_bit_cast(float, odd ? got : (mine << 16));
+                        uu[r + 1] = __builtin_bit_cast(float, odd ? (mine & 0xffff0000u) : got);
+                    }
+                } else {
+                    const unsigned voff = ((unsigned)(m0 - m_tile0) * (unsigned)p.ldr + (unsigned)n) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldr * 4u;
+                        uu[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, voff, soff, 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        t[4 * q + e] = __fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bias), vf_gelu_grad_fast(uu[4 * q + e]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -173,15 +198,26 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
                     if (EPI == 1) t[r] = vf_gelu_erf_fast(t[r]);
                 }
             }
+            // EPI 3 (VF_EPI_GELU_DUAL with a bf16 `out`): first the pre-activation as bf16 to `out`, then — from the fp32 value, not the
+            // rounded one — its GELU as bf16 to `out_aux`
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float give = odd ? t[r] : t[r + 1];
-                const float got = __shfl_xor(give, 1, 64);
-                const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
-                bf16x2_t v;
-                v[0] = (__bf16)(odd ? got : t[r]);
-                v[1] = (__bf16)(odd ? t[r + 1] : got);
-                if (FULL || m < p.M) *reinterpret_cast<bf16x2_t*>(O + (size_t)m * p.ldc + (n - odd)) = v;
+            for (int pass = 0; pass < (EPI == 3 ? 2 : 1); ++pass) {
+                __bf16* __restrict__ dst = pass == 0 ? O : reinterpret_cast<__bf16*>(p.out_aux);
+                if (pass == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = vf_gelu_erf_fast(t[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float give = odd ? t[r] : t[r + 1];
+                    const float got = __shfl_xor(give, 1, 64);
+                    const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
+                    bf16x2_t v;
+                    v[0] = (__bf16)(odd ? got : t[r]);
+                    v[1] = (__bf16)(odd ? t[r + 1] : got);
+                    if (FULL || m < p.M) *reinterpret_cast<bf16x2_t*>(dst + (size_t)m * p.ldc + (n - odd)) = v;
+                }
             }
         }
     }
@@ -357,7 +393,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
     if (O16) {
         const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
-        if (full) {
+        const bool dual16 = p.epilogue == VF_EPI_GELU_DUAL;
+        if (dual16) {
+            if (full) g256_store_bf16<3, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            else g256_store_bf16<3, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+        } else if (full) {
             if (gbwd) g256_store_bf16<2, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
             else if (gelu) g256_store_bf16<1, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
             else g256_store_bf16<0, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
@@ -477,7 +517,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p
         const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
         if (O16) {
             const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
-            if (full) {
+            const bool dual16 = p.epilogue == VF_EPI_GELU_DUAL;
+            if (dual16) {
+                if (full) g256_store_bf16<3, true>(p, acc, em, en, wave_m, wave_n, half, l31);
+                else g256_store_bf16<3, false>(p, acc, em, en, wave_m, wave_n, half, l31);
+            } else if (full) {
                 if (gbwd) g256_store_bf16<2, true>(p, acc, em, en, wave_m, wave_n, half, l31);
                 else if (gelu) g256_store_bf16<1, true>(p, acc, em, en, wave_m, wave_n, half, l31);
                 else g256_store_bf16<0, true>(p, acc, em, en, wave_m, wave_n, half, l31);
@@ -502,7 +546,8 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     if (!a16 || a.batch > 1 || a.Cout % GN != 0 || a.Cin % GK != 0 || a.M < GM || (a.lda & 7)) return VF_ERR_UNSUPPORTED;
     if (o16 && ((a.res && a.epilogue != VF_EPI_GELU_BWD) || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (GELU_BWD: `res` carries the pre-activation)
     if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res)) return VF_ERR_UNSUPPORTED;
-    if (a.epilogue == VF_EPI_GELU_DUAL && (o16 || a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;
+    if (a.epilogue == VF_EPI_GELU_DUAL && (a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (out fp32 or bf16)
+    if ((a.reserved0 & 4) && a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;                             // (bit 2: a bf16 u for GELU_BWD)
     if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
     if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)

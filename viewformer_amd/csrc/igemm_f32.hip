@@ -312,7 +312,7 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 
 extern "C" {
 
-int vf_abi_version(void) { return 14; }
+int vf_abi_version(void) { return 15; }
 const char* vf_build_arch(void) { return "gfx950"; }
 
 size_t vf_igemm_packed_floats(int K, int N, int taps) {

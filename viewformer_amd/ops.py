@@ -271,14 +271,15 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
-          x3h=False, a16=False, o16=False, out_aux=None):
+          x3h=False, a16=False, o16=False, out_aux=None, res16=False):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
     split-bf16 kernel (vf_conv3_halo_x6).
     ``gn_part``: fp32 [Nimg][halo_gn_slots(Hout, Wout)][32][2] buffer that receives the GroupNorm partial statistics of the
     output (halo kernels only; reduce with groupnorm_finalize).
-    ``out_aux`` (with ``epilogue=EPI_GELU_DUAL``, bf16 arm, bf16 x, fp32 out): bf16 [M][ldc] that receives gelu(out)."""
+    ``out_aux`` (with ``epilogue=EPI_GELU_DUAL``, bf16 arm, bf16 x, fp32 or bf16 out): bf16 [M][ldc] that receives gelu(out).
+    ``res16`` (with ``epilogue=EPI_GELU_BWD``): the pre-activation behind ``res`` was saved as bf16."""
     lib = _lib.load()
     if not 0 <= M < 2 ** 31 or max(Cin, Cout, Hin, Win, Hout, Wout, batch) >= 2 ** 31:
         # vf_igemm_args carries 32-bit row / channel counts (byte offsets inside the kernels are 64-bit): refuse instead of wrapping
@@ -318,7 +319,12 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
         _chk(x, torch.bfloat16 if a16 else torch.float32, 'x')
         _chk(out, torch.bfloat16 if o16 else torch.float32, 'out')
         a.reserved0 = (1 if a16 else 0) | (2 if o16 else 0)
-    for t in ((None if a16 else x), (None if o16 else out), bias, res):
+    if res16:
+        if not (a16 and o16 and epilogue == EPI_GELU_BWD and res is not None):
+            raise _lib.VfError('res16 is the bf16 pre-activation of EPI_GELU_BWD (bf16 in, bf16 out)')
+        _chk(res, torch.bfloat16, 'res')
+        a.reserved0 |= 4
+    for t in ((None if a16 else x), (None if o16 else out), bias, (None if res16 else res)):
         if t is not None:
             _f32(t)
     if x3h:                                   # w_packed = pack_conv3_x3h / pack_dense_*_x3h: the 3-product split-fp16 kernels

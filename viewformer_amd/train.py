@@ -262,7 +262,8 @@ class MIGTTrainer:
         if gelu_bwd_u is not None:
             if not (bf16 and dx_bf16 and res is None):
                 raise RuntimeError('the fused GELU backward needs the bf16 arm, a bf16 result and no residual')
-            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=gelu_bwd_u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=dy.dtype == torch.bfloat16, o16=True)
+            ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=gelu_bwd_u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=dy.dtype == torch.bfloat16, o16=True,
+                      res16=gelu_bwd_u.dtype == torch.bfloat16)
         elif bf16:
             ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, a16=dy.dtype == torch.bfloat16, o16=dx_bf16)   # (bf16 dY: the 256-tile kernel)
         elif x6:
@@ -278,6 +279,9 @@ class MIGTTrainer:
         d = self.cfg.d_model
         return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res, also_bf16=also_bf16)
 
+    bf16_preactivation = True         # bf16 arm, with both GELU fusions: c_fc's pre-activation u is SAVED as bf16 (the reference's mixed_float16 policy
+                                      # keeps every activation in half precision); gelu(u) is still taken from the fp32 accumulator, gelu'(u)
+                                      # in the backward epilogue from the rounded u.  False: u saved as fp32.
     fuse_gelu_forward = True          # bf16 arm: c_fc writes u (fp32, saved) and bf16 gelu(u) from one epilogue (VF_EPI_GELU_DUAL); the GELU there
                                       # is the inference arm's vf_gelu_erf_fast (|err| 1.5e-7: a few outputs round to the neighbouring bf16)
 
@@ -442,9 +446,11 @@ class MIGTTrainer:
             if act16 and self.fuse_gelu_forward and self._gelu_dual_ok(M):
                 # c_fc keeps the fp32 pre-activation for the backward pass AND hands bf16 gelu(u) to mlp.c_proj from one epilogue
                 dn = m._dense[p + '.mlp.c_fc']
-                u = torch.empty((M, dn.n), dtype=torch.float32, device=dev)
+                u16 = grad16 and self.fuse_gelu_backward and self.bf16_residual_gradient and self.bf16_preactivation      # (its only reader then: the
+                # GELU-backward epilogue of the 256-tile kernel, fed by the bf16 residual-stream gradient)
+                u = torch.empty((M, dn.n), dtype=torch.bfloat16 if u16 else torch.float32, device=dev)
                 f = torch.empty((M, dn.n), dtype=torch.bfloat16, device=dev)
-                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, out_aux=f)
+                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=u16, out_aux=f)
             else:
                 u = self._linear(n2, p + '.mlp.c_fc', M)
                 f = T.gelu(u, out_bf16=act16)
