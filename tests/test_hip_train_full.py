@@ -179,6 +179,15 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     print('full-size bf16 arm: bf16 attention vs exact-f32 attention, worst per-tensor gradient difference', worst_a)
     assert worst_a < BF16_GRAD_TOL, worst_a
     tr16.attention_arith = 'bf16'
+    # the tied LM head on the native f32 matrix pipe (as in rounds 1-2) vs the bf16 pipe
+    tr16.bf16_lm_head = False
+    m_lm = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    worst_l = max(_rel(gb[a:b], tr16.flat_g[a:b]) for a, b, _ in (tr16.slices[n] for n in tr16.names) if float(tr16.flat_g[a:b].abs().max()) > 0)
+    print('full-size bf16 arm: LM head on the bf16 pipe vs native f32, worst per-tensor gradient difference', worst_l,
+          'loss', float(mb['loss']), float(m_lm['loss']))
+    assert worst_l < 0.5 * BF16_GRAD_TOL, worst_l
+    assert abs(float(m_lm['loss']) - float(mb['loss'])) < 2e-3 * abs(float(mb['loss']))
+    tr16.bf16_lm_head = True
 
     # one-launch AdamWeightDecay == per-tensor launches, bit for bit; every tensor moves
     p0, m0, v0 = tr16.flat_p.clone(), tr16.flat_m.clone(), tr16.flat_v.clone()

@@ -167,6 +167,9 @@ class MIGTTrainer:
         m._lm_head6 = None                                  # the LM head / pose heads stay on the native kernel in training
         # bf16 arm: after the first call (which allocates the packings one by one) every layer's W and W^T packing is refreshed by ONE
         # launch over a descriptor table (96 pack launches per step before)
+        lm16 = bf16 and self.bf16_lm_head and d % 256 == 0 and nE % 256 == 0
+        if lm16 and self._lm16 is None:
+            self._pack16 = None                                  # (the LM-head packings join the descriptor table: rebuild it)
         if self._pack16 is not None:
             self._pack16()
         pack_items = []
@@ -194,10 +197,18 @@ class MIGTTrainer:
             if to6:
                 dn.wp6 = ops.pack_dense_kn_x3h(dn.w_raw) if x3h else ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
+        if lm16 and self._lm16 is None:                              # tied LM head on the bf16 pipe: logits = h @ wte^T, dH = dlogits @ wte
+            head = m._wte[:nE]
+            self._lm16 = (ops.pack_dense_nk_bf16(head), ops.pack_dense_kn_bf16(head))
+            pack_items += [(head, True, self._lm16[0]), (head, False, self._lm16[1])]
+        elif lm16 and self._pack16 is None:                          # (per-tensor refresh: one_launch_repack off)
+            head = m._wte[:nE]
+            self._lm16 = (ops.pack_dense_nk_bf16(head), ops.pack_dense_kn_bf16(head))
         if bf16 and self._pack16 is None and pack_items and self.one_launch_repack:
             self._pack16 = ops.pack_bf16_multi(pack_items)          # (re-packs once more; from now on the closure is the refresh)
-        m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T
-        self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
+        m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T (kept fresh for
+        if not lm16:                                                                                      # whoever reads the model afterwards)
+            self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
 
     # ------------------------------------------------------------------ building blocks
     def _linear(self, x, name, M, res=None):
@@ -293,6 +304,9 @@ class MIGTTrainer:
                                       # layers' backward GEMMs, which then run on the 256-tile kernel (the rounding is the one the GEMM's operand
                                       # load applied anyway; only the two bias gradients see it)
 
+    bf16_lm_head = True               # bf16 arm: the tied LM head (logits, dH, dwte) on the bf16 pipe like every other wide layer (the native-f32
+                                      # GEMMs it replaces were 0.8 ms of a 21 ms step); False: native f32 MFMA
+    _lm16 = None
     one_launch_repack = True          # bf16 arm: all weight packings refreshed by one launch per step
     _pack16 = None
     fuse_gelu_backward = True         # bf16 arm: d(pre-activation) = dX(mlp.c_proj) * gelu'(u) in that GEMM's epilogue (same bits as the two passes)
@@ -469,7 +483,11 @@ class MIGTTrainer:
         denom = float((S - skip) * L * B)
         hmask = hf[:, 1].contiguous().view(M1, d)
         logits = torch.empty((M1, nE), dtype=torch.float32, device=dev)
-        ops.igemm(hmask, m._lm_head, M1, d, nE, logits)
+        lm16 = self._lm16 is not None and m.precision == 'bf16' and self.bf16_lm_head and M1 % 64 == 0
+        if lm16:
+            ops.igemm(hmask, self._lm16[0], M1, d, nE, logits, bf16=True)
+        else:
+            ops.igemm(hmask, m._lm_head, M1, d, nE, logits)
         tgt = tok.reshape(M1).to(torch.int32).contiguous()
         w_ce = (view_ok * (c.image_generation_weight / denom)).contiguous()
         ce_rows, dlogits = T.softmax_ce(logits, tgt, w_ce, M1, nE, c.label_smoothing)        # :420-423
@@ -518,12 +536,19 @@ class MIGTTrainer:
         dhf = torch.zeros((B, NS, S, L, d), dtype=torch.float32, device=dev)
         # tied LM head: dH = dlogits @ wte[:nE];  dwte[:nE] = dlogits^T @ H
         dhm = torch.empty((M1, d), dtype=torch.float32, device=dev)
-        ops.igemm(dlogits, self.lm_T, M1, nE, d, dhm)
-        dhf[:, 1] = dhm.view(B, S, L, d)
-        dlt = T.transpose(dlogits, M1, nE)
-        hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
         gwte = self.g('wte.weight')
-        ops.igemm(dlt, hp, nE, M1, d, gwte)                                           # rows [0, nE) of the (zeroed) grad
+        if lm16:
+            ops.igemm(dlogits, self._lm16[1], M1, nE, d, dhm, bf16=True)
+            # dwte[:nE] = dlogits^T @ H straight from the row-major operands (the TN kernel: x = dlogits as bf16, dy = H)
+            ops.gemm_tn_bf16(dlogits.to(torch.bfloat16), hmask, M1, nE, d, gwte[:nE], None)
+        else:
+            if getattr(self, 'lm_T', None) is None:
+                self.repack()                                                         # (bf16_lm_head switched off after the last repack)
+            ops.igemm(dlogits, self.lm_T, M1, nE, d, dhm)
+            dlt = T.transpose(dlogits, M1, nE)
+            hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
+            ops.igemm(dlt, hp, nE, M1, d, gwte)                                       # rows [0, nE) of the (zeroed) grad
+        dhf[:, 1] = dhm.view(B, S, L, d)
         if use_loc:
             name = 'pose_criterion.pose_classifier.c_proj'
             dn = m._dense[name]
