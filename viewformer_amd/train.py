@@ -298,7 +298,7 @@ class MIGTTrainer:
 
     def _gelu_dual_ok(self, M):
         c = self.cfg
-        return M >= 256 and c.d_model % 128 == 0 and (4 * c.d_model) % 256 == 0
+        return M >= 256 and c.d_model % 128 == 0 and (4 * c.d_model) % 256 == 0 and M * 4 * c.d_model * 2 < 2 ** 31   # (the 256-tile kernel's limits)
 
     bf16_residual_gradient = True     # bf16 arm: the LayerNorm backward also writes its result as bf16 — the operand of the two projection
                                       # layers' backward GEMMs, which then run on the 256-tile kernel (the rounding is the one the GEMM's operand
