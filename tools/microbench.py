@@ -179,6 +179,12 @@ def g256_stamps(M=65536, K=3072, N=768):
         v = t[:, :, i] / ns
         print('  %-12s mean %7.0f   [%7.0f | %7.0f]   p10 %7.0f p90 %7.0f' % (name, v.mean(), v[:, :4].mean(), v[:, 4:].mean(), np.percentile(v, 10), np.percentile(v, 90)))
     print('  main loop total per wave: mean %.0f cycles = %.0f per stage' % (t[:, :, 5].mean(), t[:, :, 5].mean() / ns))
+    print('  epilogue per wave: issue mean %.0f cycles (p10 %.0f p90 %.0f), store drain mean %.0f (p10 %.0f p90 %.0f)' % (
+        t[:, :, 6].mean(), np.percentile(t[:, :, 6], 10), np.percentile(t[:, :, 6], 90), t[:, :, 7].mean(), np.percentile(t[:, :, 7], 10),
+        np.percentile(t[:, :, 7], 90)))
+    ms = timeit(lambda: _lib.check(_lib.load().vf_gemm_bf16(ctypes.byref(a), ops._stream()), 'vf_gemm_bf16'))
+    rounds = -(-nwg // 256)
+    print('  wall %.1f us = %.1f us per round of 256 tiles' % (ms * 1e3, ms * 1e3 / rounds))
 
 
 def vq(M=64 * 448):
@@ -298,7 +304,7 @@ ALL = dict(clockprobe=clockprobe,
            gemmbf16=lambda: gemm(16384, 768, 2304, arith='bf16'), gemmbf16_k3072=lambda: gemm(65536, 3072, 768, arith='bf16'),
            gemmbf16_big=lambda: gemm(65536, 768, 3072, 1, 'bf16'), gemmbf16_gelu=lambda: gemm(16384, 768, 3072, 1, 'bf16'),
            convin=convin, convin_x3h=lambda: convin(x3h=True), conv=conv, conv_nopro=lambda: conv(pro=False), gemm=gemm, gemm2=lambda: gemm(7168, 3072, 768),
-           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, x3h_stamps=x3h_stamps, convout=convout, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
+           gemm_gelu=lambda: gemm(epi=1), gemm_tf=gemm_tf, x3h_stamps=x3h_stamps, convout=convout, attnsp=attnsp, attnsp_mid=lambda: attnsp(896, 64, 512), gemm_1x1=gemm_1x1, gemm_1x1_nin=lambda: gemm_1x1(917504, 128, 256, 4096, pro=False), gemm_1x1_mid=lambda: gemm_1x1(57344, 512, 1536, 64), g256_stamps=g256_stamps, g256_stamps_k768=lambda: g256_stamps(K=768, N=3072), g256_stamps_k128=lambda: g256_stamps(K=128, N=3072), gemm_tf_proj=lambda: gemm_tf(only='mlp.c_proj'), gemm_tf_fc=lambda: gemm_tf(only='mlp.c_fc'), gemm_tf_attn=lambda: gemm_tf(only='c_attn'), vq=vq, vq_bench=lambda: vq(64 * 896), vqf=vqf, vqf_stamps=vqf_stamps, vqf_small=lambda: vqf(64 * 56), vqf_big=lambda: vqf(64 * 8192), attn=attn, gn=gn,
            conv64=lambda: conv(56, 128, 64), conv256=lambda: conv(56, 256, 32), conv512=lambda: conv(224, 512, 8),
            convx6=lambda: conv(x6=True), convx6_64=lambda: conv(56, 128, 64, x6=True), convx6_256=lambda: conv(56, 256, 32, x6=True),
            convx6_512=lambda: conv(224, 512, 8, x6=True),

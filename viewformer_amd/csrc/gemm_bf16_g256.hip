@@ -325,6 +325,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #else
 #define G256_STAMP(i)
 #endif
+    // (A first-round stagger — four groups of CUs 4 000-16 000 cycles apart, so that the 256 epilogues of a round do not reach the memory system
+    // together — was measured in round 3 and removed: 388 -> 397-400 us for c_fc at M = 65 536, the tail it adds outweighs what it spreads.)
     issue(0);
 #if G256_A_VIA_REGS
     a_fetch(0);
@@ -406,9 +408,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
             else if (gelu) g256_store_bf16<1, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
             else g256_store_bf16<0, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
         }
-        return;
+    } else {
+        g256_store_f32(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
     }
-    g256_store_f32(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
+#ifdef G256_STAMPS
+    {   // epilogue: [6] = bias / convert / store instructions issued, [7] = the stores drained (vmcnt 0)
+        unsigned long long te0, te1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1) :: "memory");
+        if (p.pro_beta && lane == 0) {
+            unsigned* o = reinterpret_cast<unsigned*>(const_cast<float*>(p.pro_beta)) + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[6] = (unsigned)(te0 - tt[3]);
+            o[7] = (unsigned)(te1 - te0);
+        }
+    }
+#endif
 }
 
 // ---- persistent form: one workgroup per CU walks the tiles (tile = blockIdx.x + k * gridDim.x, same XCD / panel order) and issues the
