@@ -101,15 +101,43 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
         }
         return kv == qv || min(kv, Vc) < min(qv, Vc);
     };
-    // in every mask mode a query sees no view index above its own: the workgroup walks key tiles 0 .. its last view
-    const int ntiles = min(nviews, q0 / KT + QT / KT);
+    // in every mask mode a query sees no view index above its own: the workgroup walks key tiles 0 .. its last view — those of them that
+    // at least one of its four query views sees (round 3: under the training step's 3-stream mask a workgroup of stream 1 / 2 walked every
+    // tile below it, 142 tile steps per (scene, head) for the 78 some wave needs).  `need` = bit kv set <=> some wave sees key view kv, from the
+    // closed forms of visible(); the issue and the consume pointer pop its bits in ascending order, ring slots go by SEQUENCE index.
+    const int nwalk = min(nviews, q0 / KT + QT / KT);
+    const bool dense = nwalk > 64;                          // (more than 64 key views: walk them all, as before)
+    unsigned long long need = 0;
+    if (!dense) {
+        for (int w = 0; w < QT / KT; ++w) {
+            const int qv = q0 / KT + w;
+            if (qv >= nviews) break;
+            int lim;                                        // this view sees key views [0, lim) and itself
+            if (Sv > 0) {
+                lim = qv % Sv;                              // stream 0: views 0 .. qi (qi is the view itself); streams >= 1: stream-0 views below qi
+            } else {
+                lim = min(qv, Vc);
+            }
+            need |= (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull)) | (1ull << qv);
+        }
+        need &= nwalk >= 64 ? ~0ull : ((1ull << nwalk) - 1ull);
+    }
+    const int ntiles = dense ? nwalk : __builtin_popcountll(need);            // tile STEPS of this workgroup
+    unsigned long long rem_issue = need, rem_use = need;
+    auto pop = [&](unsigned long long& rem, int seq) {
+        if (dense) return seq;
+        const int t = __builtin_ctzll(rem);
+        rem &= rem - 1ull;
+        return t;
+    };
 
     // ---- DMA.  Every 1 KB piece = 64 lanes x 16 B, lane-linear in LDS.
     // K piece (8 rows x 128 B): lane -> row (lane >> 3), LDS chunk c' = lane & 7 holds global chunk c' ^ ((row >> 1) & 7).
     // V piece (16 keys x 64 B of one feature half): lane -> key (lane >> 2), 16-byte chunk lane & 3.
     const int pr = lane >> 3, pc = lane & 7;
-    auto issue_tile = [&](int t) {
-        unsigned char* dst = smem + (t % RING) * TILE_BYTES;
+    auto issue_tile = [&](int seq) {
+        const int t = pop(rem_issue, seq);                           // (calls come in ascending sequence order)
+        unsigned char* dst = smem + (seq % RING) * TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
@@ -278,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void attn_dma_kernel(const __bf16* __restri
 #ifdef ADMA_X_NOCOMPUTE
         continue;
 #endif
-        const bool vis = active && visible(qview, kt);               // (masked for all 64 queries: the tile contributes exactly 0.0f)
+        const int tcur = pop(rem_use, kt);                           // the key view in ring slot kt % RING
+        const bool vis = active && visible(qview, tcur);             // (masked for all 64 queries: the tile contributes exactly 0.0f)
         if constexpr (!PIPE) {
             if (!vis) continue;
             f32x16 st[2][2];                                         // [query tile][key half]
