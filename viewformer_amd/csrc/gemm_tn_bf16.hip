@@ -51,9 +51,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int ntn = N / TN_;
-    const int tile = (int)blockIdx.x;
+    // 1-D grid of nsplit x tiles workgroups in XCD-contiguous logical order (vf_common.h), split-major: the ~32 workgroups an XCD runs are then
+    // (nearly) all tiles of ONE row range, whose X and dY chunks its L2 fetches once.  With (tile, split) as a 2-D grid the dispatcher dealt the
+    // tiles of a split round-robin over the 8 XCDs: FETCH_SIZE 217 MB per launch (x 2 per the guide's gfx950 note) for 118 MB of operands
+    // (profiles/r3_train_step_pmc.txt).
+    const int ntiles_kn = (K / TK) * ntn;
+    const int lbid = (int)vf_xcd_bid();
+    const int split = lbid / ntiles_kn, nsplit = (int)gridDim.x / ntiles_kn;
+    const int tile = lbid - split * ntiles_kn;
     const int tk = tile / ntn, tn = tile - tk * ntn;
-    const int split = blockIdx.y, nsplit = gridDim.y;
     const int nchunk_all = M / CM;
     const int c0 = (int)((long long)nchunk_all * split / nsplit), c1 = (int)((long long)nchunk_all * (split + 1) / nsplit);
 
@@ -202,7 +208,7 @@ int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16,
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
     }
-    const dim3 grid((unsigned)((K / TK) * (N / TN_)), (unsigned)splits);
+    const dim3 grid((unsigned)((K / TK) * (N / TN_) * splits));
     if (dy_is_bf16)
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(512), (size_t)2 * STAGE, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x_bf16), dy,
                            w_slabs, b_slabs, M, K, N, ldx, ldy, w_stride, b_stride);
