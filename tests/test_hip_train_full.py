@@ -222,13 +222,15 @@ def _full_worker(rank, world, port, q):
         g_local = tr.flat_g.clone()
         tr.train_step(poses, tok, reduce_gradients=True, apply_update=False)           # per-layer ranges, async, overlapped
         g_red = tr.flat_g.clone()
-        e_sum = rel(g_red, sum(_gather(g_local, dist, world)))
+        g_sum = sum(_gather(g_local, dist, world))
+        e_sum = rel(g_red, g_sum)
+        worst = max(((n, rel(g_red[a:b], g_sum[a:b])) for n, (a, b, _) in tr.slices.items() if float(g_sum[a:b].abs().max()) > 0), key=lambda t: t[1])
         allb = [_batch(B, S, 100 + r) for r in range(world)]
         tr.train_step(torch.cat([b[0] for b in allb]), torch.cat([b[1] for b in allb]), reduce_gradients=False, apply_update=False)
         e_cat = rel(g_red, tr.flat_g * world)
         tr.train_step(poses, tok)                                                      # one optimizer step: replicas stay identical
         params = _gather(tr.flat_p, dist, world)
-        q.put((rank, 'ok', dict(e_sum=e_sum, e_cat=e_cat, in_sync=all(torch.equal(params[0], p) for p in params[1:]),
+        q.put((rank, 'ok', dict(e_sum=e_sum, worst_sum=worst, e_cat=e_cat, in_sync=all(torch.equal(params[0], p) for p in params[1:]),
                                 backend=dist.get_backend())))
         dist.destroy_process_group()
     except Exception as e:      # noqa: BLE001
