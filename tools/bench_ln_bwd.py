@@ -1,4 +1,4 @@
-"""time vf_layernorm_bwd_f32 at the training shape (19 200 x 768, residual + bf16 copy) — A/B of the rows-in-flight forms (VF_LN_BWD_R2)"""
+"""time vf_layernorm_bwd_f32 at the training shape (19 200 x 768, residual + bf16 copy) — A/B of the rows-in-flight forms (VF_LN_BWD_R1)"""
 import os
 import sys
 import torch
@@ -11,8 +11,8 @@ g = torch.Generator(device='cpu').manual_seed(0)
 dy, x, res = (torch.randn((M, d), generator=g).to(dev) for _ in range(3))
 gamma = torch.randn(d, generator=g).to(dev)
 out = {}
-for r1 in ('0', '1'):
-    os.environ['VF_LN_BWD_R2'] = r1
+for r1 in ('1', '0'):
+    os.environ['VF_LN_BWD_R1'] = r1
     dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
     for _ in range(5):
         dx, dx16 = T.layernorm_bwd(dy, x, gamma, dg, db, M, d, res=res, also_bf16=True)
@@ -27,5 +27,5 @@ for r1 in ('0', '1'):
     dx, dx16 = T.layernorm_bwd(dy, x, gamma, dg2, db2, M, d, res=res, also_bf16=True)
     out[r1] = (dx.clone(),)
     us = e0.elapsed_time(e1) * 1000 / 50
-    print(f'VF_LN_BWD_R2={r1}: {us:.1f} us per call (kernel + finalize), {265.4e6 / us / 1e6:.2f} TB/s of 265 MB')
+    print(f'VF_LN_BWD_R1={r1}: {us:.1f} us per call (kernel + finalize), {265.4e6 / us / 1e6:.2f} TB/s of 265 MB')
 print('same bits:', all(torch.equal(a, b) for a, b in zip(out['1'], out['0'])))

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         float mean[R], rstd[R], qq[R], sg[R], sgx[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) mean[q] = vf_wave_sum(s[q]) / (float)d;
+        for (int q = 0; q < R; ++q) mean[q] = vf_wave_sum_dpp(s[q]) / (float)d;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             qq[q] = 0.f;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) rstd[q] = 1.0f / sqrtf(vf_wave_sum(qq[q]) / (float)d + eps);
+        for (int q = 0; q < R; ++q) rstd[q] = 1.0f / sqrtf(vf_wave_sum_dpp(qq[q]) / (float)d + eps);
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             sg[q] = 0.f;
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            sg[q] = vf_wave_sum(sg[q]) / (float)d;
-            sgx[q] = vf_wave_sum(sgx[q]) / (float)d;
+            sg[q] = vf_wave_sum_dpp(sg[q]) / (float)d;
+            sgx[q] = vf_wave_sum_dpp(sgx[q]) / (float)d;
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -626,8 +626,8 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 // rows per block of the backward kernel (4 per wave).  64 rows per block left the 19 200-row training matrices on 1200 waves — about one
 // per SIMD, each walking 16 rows whose four dependent wave reductions nothing overlapped: 76-105 us for 236 MB (2.2 TB/s).  Round 3, at
 // 19 200 x 768 with the residual and the bf16 copy (265 MB), kernel + finalize: 16 rows, one row at a time, four float4 slots per lane 89 us;
-// three slots (d = 768 exactly) 69-70 us (the shipped form); two rows in flight 62-64 us (4.2-4.3 TB/s; opt-in, see the launcher);
-// 8 rows per block 64-65, 4 rows 70-80 (tools/bench_ln_bwd.py)
+// three slots (d = 768 exactly) 69-70 us; two rows in flight 62-64 us (4.2-4.3 TB/s; the shipped form, see the launcher for its history);
+// 8 rows per block 64-65, 4 rows 70-80; wave sums by DPP adds instead of ds_bpermute: 67.5 / 61.2 us (tools/bench_ln_bwd.py)
 constexpr int LN_BWD_RPB = 16;
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
     if (rows <= 0 || d <= 0) return 0;
@@ -643,14 +643,14 @@ int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, fl
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
     __bf16* d16 = reinterpret_cast<__bf16*>(dx_bf16);
-    // DEFAULT: one row per wave at a time.  The two-rows-in-flight form (VF_LN_BWD_R2=1; 62-64 us against 69-70 at the training shape) is
-    // bit-identical to it in a process that has the GPU to itself — and was found NOT bit-reproducible when a second process shares the GPU
-    // (the 2-rank gloo test on one device: about one call in 75 returned dx with a few rows off by 1e-4 relative, on identical inputs;
-    // tools/flaky_probe2.py located it, 0 of 6 000 calls with this form, 0 of 800 in isolation with either).  Cause not found: the two
-    // forms execute the same instruction kinds.  Determinism is a stated property of the step (tests/test_hip_train_full.py), so the slower
-    // form ships and the faster one stays an opt-in record.
-    const char* r2 = getenv("VF_LN_BWD_R2");
-    const bool one = !(r2 && r2[0] == '1');
+    // Two rows of a wave in flight (62 us against 68-70 for one row at the training shape; VF_LN_BWD_R1=1 selects the one-row form, same bits).
+    // History of this switch (round 3): with the wave sums on ds_bpermute (vf_wave_sum) the two-row form was bit-identical in a process that
+    // owns the GPU but NOT bit-reproducible when a second process shared the device — the 2-rank gloo test on one GPU failed every other
+    // run; tools/flaky_probe2.py traced it to ~1 call in 75 returning a few rows of dx ~1e-4 off on identical inputs (0 of 6 000 calls with
+    // the one-row form).  With the sums on DPP adds (vf_wave_sum_dpp) both forms are reproducible there (0 of 5 000 calls): two interleaved
+    // ds_bpermute chains do not survive the context switches of a shared GPU; nothing else in the library interleaves them.
+    const char* r1 = getenv("VF_LN_BWD_R1");
+    const bool one = r1 && r1[0] == '1';
 #define VF_LN_BWD_LAUNCH(MV, RR) hipLaunchKernelGGL((layernorm_bwd_kernel<MV, RR>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, \
                                                     (long long)rows, d, eps, rpb, res, d16)
     if (d <= 256) { if (one) VF_LN_BWD_LAUNCH(1, 1); else VF_LN_BWD_LAUNCH(1, 2); }

@@ -101,6 +101,22 @@ __device__ __forceinline__ float vf_wave_sum(float v) {
     return v;
 }
 
+// wave sum on the vector ALU's data-parallel primitives instead of six ds_bpermute round trips (each a trip through the LDS pipeline, ~100+
+// cycles of latency that a one-row-per-wave kernel cannot hide): prefix adds inside each row of 16 lanes (row_shr 1 / 2 / 4 / 8), row 0 -> 1 and
+// row 2 -> 3 (row_bcast:15), rows 0-1 -> 2-3 (row_bcast:31); lane 63 then holds the total, broadcast through an SGPR.  A FIXED order, different
+// from vf_wave_sum's butterfly: use one or the other consistently where bits matter.
+__device__ __forceinline__ float vf_wave_sum_dpp(float v) {
+#define VF_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+    VF_DPP_ADD(0x111, 0xF);      // row_shr:1
+    VF_DPP_ADD(0x112, 0xF);      // row_shr:2
+    VF_DPP_ADD(0x114, 0xF);      // row_shr:4
+    VF_DPP_ADD(0x118, 0xF);      // row_shr:8   -> lane 15 of every row: the row's sum
+    VF_DPP_ADD(0x142, 0xA);      // row_bcast:15 -> rows 1, 3
+    VF_DPP_ADD(0x143, 0xC);      // row_bcast:31 -> rows 2, 3
+#undef VF_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float vf_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
