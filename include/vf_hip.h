@@ -40,6 +40,8 @@ extern "C" {
 
 /* library / device introspection (host) */
 int vf_abi_version(void);                 /* bumps when a signature changes */
+size_t vf_sizeof_igemm_args(void);        /* sizeof(vf_igemm_args) / sizeof(vf_pack_desc) as this library was built: a binding compares */
+size_t vf_sizeof_pack_desc(void);         /* its mirror of the two structs with them before the first call */
 const char* vf_build_arch(void);          /* "gfx950" */
 /* developer switches compiled into this library (ablation / cycle-stamp builds of the kernels, csrc/vf_common.h): the count and
  * the i-th macro name.  A product build returns 0; tests/test_abi.py asserts it of the shipped library. */

@@ -32,7 +32,12 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_queries(lib):
-    assert lib.vf_abi_version() == 15
+    assert lib.vf_abi_version() == 16
+    # the struct mirrors of the binding have the library's layout (checked again at load time: a mismatch raises)
+    import ctypes
+    from viewformer_amd import _lib as L
+    assert int(lib.vf_sizeof_igemm_args()) == ctypes.sizeof(L.VfIgemmArgs)
+    assert int(lib.vf_sizeof_pack_desc()) == L.PACK_DESC_BYTES
     assert lib.vf_build_arch() == b'gfx950'
     # [chunks=4][taps=9][nblk=1][32][128]
     assert lib.vf_igemm_packed_floats(128, 128, 9) == 4 * 9 * 32 * 128

@@ -28,10 +28,13 @@ class VfIgemmArgs(ctypes.Structure):
     ]
 
 
+PACK_DESC_BYTES = 40          # vf_pack_desc (ops.pack_bf16_multi builds the table as a numpy record array of this item size)
 P = c_void_p
 # name -> (restype, argtypes)
 EXPORTS = {
     'vf_abi_version': (c_int, []),
+    'vf_sizeof_igemm_args': (c_size_t, []),
+    'vf_sizeof_pack_desc': (c_size_t, []),
     'vf_build_arch': (c_char_p, []),
     'vf_build_flags': (c_int, []),
     'vf_build_flag_name': (c_char_p, [c_int]),
@@ -173,6 +176,12 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # the two structs that cross the boundary by pointer: this module's mirrors must have the library's layout
+    if int(lib.vf_sizeof_igemm_args()) != ctypes.sizeof(VfIgemmArgs):
+        raise VfError(f'vf_igemm_args is {int(lib.vf_sizeof_igemm_args())} bytes in {LIB_PATH} and {ctypes.sizeof(VfIgemmArgs)} in '
+                      'viewformer_amd/_lib.py: rebuild the library or update the mirror')
+    if int(lib.vf_sizeof_pack_desc()) != PACK_DESC_BYTES:
+        raise VfError(f'vf_pack_desc is {int(lib.vf_sizeof_pack_desc())} bytes in {LIB_PATH}, {PACK_DESC_BYTES} expected')
     _lib = lib
     return lib
 

@@ -312,7 +312,10 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 
 extern "C" {
 
-int vf_abi_version(void) { return 15; }
+int vf_abi_version(void) { return 16; }
+// sizes of the structs that cross the boundary by pointer: a binding checks its mirror against them (a silent mismatch would be memory corruption)
+size_t vf_sizeof_igemm_args(void) { return sizeof(vf_igemm_args); }
+size_t vf_sizeof_pack_desc(void) { return sizeof(vf_pack_desc); }
 const char* vf_build_arch(void) { return "gfx950"; }
 
 size_t vf_igemm_packed_floats(int K, int N, int taps) {

@@ -95,7 +95,7 @@ def pack_bf16_multi(items):
     import numpy as np
     lib = _lib.load()
     dt = np.dtype([('src', '<u8'), ('dst', '<u8'), ('K', '<i4'), ('N', '<i4'), ('sk', '<i8'), ('sn', '<i8')])
-    assert dt.itemsize == 40
+    assert dt.itemsize == _lib.PACK_DESC_BYTES
     a = np.zeros(len(items), dtype=dt)
     for i, (w, tr, out) in enumerate(items):
         _f32(w); _chk(out, torch.bfloat16)
