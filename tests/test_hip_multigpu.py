@@ -43,6 +43,7 @@ def _launch(extra, n=2, timeout=420, backend=None):
 
 
 @two_gpus
+@pytest.mark.timeout(1500, method='thread')          # (launches of up to 420 s each: above conftest's 600 s default for GPU tests)
 def test_views_workload_two_gpus_scene_shards():
     one = _launch(['--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-f32-arm'], n=1)
     two = _launch(['--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-f32-arm'], n=2)
@@ -51,6 +52,7 @@ def test_views_workload_two_gpus_scene_shards():
 
 
 @two_gpus
+@pytest.mark.timeout(1500, method='thread')          # (launches of up to 420 s each: above conftest's 600 s default for GPU tests)
 def test_train_workload_two_gpus_rccl_allreduce():
     line = _launch(['--workload', 'train', '--steps', '3', '--warmup', '1'], n=2)
     assert line['n_gpus'] == 2 and line['value'] > 0
@@ -61,6 +63,7 @@ def test_train_workload_two_gpus_rccl_allreduce():
     assert half['config']['collective']['gradient_dtype_on_the_links'] == 'bf16' and half['value'] > 0
 
 
+@pytest.mark.timeout(1500, method='thread')          # (launches of up to 420 s each: above conftest's 600 s default for GPU tests)
 def test_two_rank_launch_line_on_one_gpu_over_gloo():
     """the same launch line with two ranks on whatever GPUs the box has (VF_DIST_BACKEND=gloo: ranks share cuda:0 on a 1-GPU box and the
     collectives carry device tensors over gloo): bench.py's N > 1 branches — scene shards summed over ranks, max-over-ranks time, one JSON
