@@ -135,8 +135,8 @@ class OpTimer:
                 pairs = S * (S + 1) // 2
             arm = 'fp8' if kw.get('fp8') else 'bf16' if kw.get('bf16') else 'x6' if kw.get('x6') else 'f32'
             io16 = q.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
-            dma = (arm == 'bf16' and io16 and L == 64 and T % 64 == 0 and os.environ.get('VF_ATTN_DMA', '1') != '0'
-                   and os.environ.get('VF_ATTN_BF16_V1') != '1')
+            from viewformer_amd import _lib as _vl
+            dma = arm == 'bf16' and io16 and L == 64 and T % 64 == 0 and bool(_vl.load().vf_selected(_vl.SEL_ATTN_DMA))
             by = B * T * H * 64 * (3 * q.element_size() + out.element_size())             # q, k, v read once, o written once
             t.attn.append((e0, e1, 4.0 * H * 64 * L * L * pairs * B, arm, (B, H, T, L, twin_view), dma, by))
             return r
@@ -190,8 +190,6 @@ class OpTimer:
                 'f32': 'attn_blockcausal_kernel'}[arm]
         if dma:
             name = 'attn_dma_kernel (bf16 q/k/v tiles by LDS-DMA, 3 in flight)'
-            if 64 < shape[2] <= 512 and os.environ.get('VF_ATTN_RES') == '1':
-                name = 'attn_res_kernel (K / V of a (scene, head) resident in LDS by LDS-DMA, equal work per wave, one barrier)'
         return {'kernel': name, 'bound': 'mfma', 'launches': len(self.attn),
                 'B_H_T_L_twin': list(shape), 'avg_launch_us': round(ms / len(self.attn) * 1e3, 1),
                 'achieved': round(fl / ms / 1e9, 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s (useful: visible tile pairs only)',
@@ -305,6 +303,9 @@ def run_train(args, rank, local, world, dev):
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'streams': 3, 'tokens_per_scene': 3 * S * 64,
                        'parallelism': f'dp{world}: per-replica mean loss, gradients SUMmed (migt.py:471-476,488), all-reduce per layer range '
                                       'overlapped with the backward pass', 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
+                       'dropout_note': 'the reference trains with MIGTConfig.dropout = 0.1 (models/config.py:66) at four sites (migt.py:72,216,403, '
+                                       'branching_attention.py:15-17); counter-based masks recomputed in the backward pass, inside the GEMM '
+                                       'epilogues / LayerNorm backward / flash attention kernels of the bf16 arm',
                        'precision': ('fp32 master weights, bf16-MFMA dense GEMMs (the reference trains with --fp16)' if arm == 'bf16' else
                                      'fp32-equivalent: x3h forward GEMMs, x6 backward GEMMs, x6 / f32 attention'),
                        'weights': 'random-init MIGT 88.4M', 'loss': float(met['loss']), 'collective': comm},
@@ -384,7 +385,9 @@ def main():
                     help='mixed arm: keep LayerNorm / GELU / attention outputs fp32 in HBM (A/B of the bf16 activation chain; same results)')
     ap.add_argument('--encoder-chunk', type=int, default=1024, help='images per encoder / decoder launch chunk (VQGAN max_images_per_call)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
-    ap.add_argument('--dropout', type=float, default=0.0, help='train: dropout rate (the reference default is 0.1)')
+    ap.add_argument('--dropout', type=float, default=0.1,
+                    help='train: dropout rate — default 0.1 = MIGTConfig.dropout of the reference (viewformer/models/config.py:66), which the CO3D '
+                         'finetune command does not override (README.md:250-264): embedding, attention-weight, residual and MLP sites')
     ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
                     help='train: dtype of the gradient buckets on the links (bf16 halves the 354 MB all-reduce; default f32 like the reference)')
     ap.add_argument('--batch-sweep', default=None,

@@ -47,6 +47,15 @@ const char* vf_build_arch(void);          /* "gfx950" */
  * the i-th macro name.  A product build returns 0; tests/test_abi.py asserts it of the shipped library. */
 int vf_build_flags(void);
 const char* vf_build_flag_name(int i);
+/* Kernel selection for A/B runs and parity tests.  The library reads NO environment variable; the only run-time switches are these, and each
+ * chooses between two kernels whose results the tests assert bit-identical (tests/test_hip_bf16.py, tests/test_train.py) — no switch changes a
+ * result.  Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}, all default to 1. */
+enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA ring kernel where it applies, 0 = register-staged kernel */
+       VF_SEL_GEMM_G256 = 1,         /* vf_gemm_bf16: 1 = 256-tile LDS-DMA kernel where it applies, 0 = 128-tile kernel */
+       VF_SEL_LN_BWD_TWO_ROWS = 2,   /* vf_layernorm_bwd_f32: 1 = two rows of a wave in flight, 0 = one */
+       VF_SEL_COUNT = 3 };
+int vf_select(int which, int value);
+int vf_selected(int which);
 
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM family: conv3x3 (stride 1 / stride-2 with (0,1,0,1) pad / nearest-x2
@@ -99,6 +108,15 @@ typedef struct vf_igemm_args {
     void* out_aux;           /* VF_EPI_GELU_DUAL only (vf_gemm_bf16, bf16 activations in, fp32 or bf16 out): bf16 [M][ldc] that receives
                               * gelu(out) beside the fp32 pre-activation `out` — the training forward's c_fc keeps u for the backward
                               * pass and hands f to mlp.c_proj from ONE epilogue.  NULL otherwise (other entry points refuse it). */
+    /* fused OUTPUT dropout of the training step (resid_dropout migt.py:216, the MLP's migt.py:72): vf_gemm_bf16 only, bf16 activations in,
+     * fp32 out, VF_EPI_NONE, shapes of the 256-tile kernel (VF_ERR_UNSUPPORTED otherwise: run the GEMM, then vf_dropout_add_f32):
+     *     out[m][n] = keep(m, n) ? (acc + bias[n]) / (1 - drop_rate) : 0   (+ res[m][n]),
+     * keep as vf_dropout_add_f32 with cols = Cout and row0 = drop_row0 (mask group ((m + drop_row0) >> 2) * Cout + n, position m & 3:
+     * csrc/vf_common.h; drop_row0 % 4 == 0 — the first row's index in the GLOBAL batch of a data-parallel step).  drop_rate 0 = off;
+     * every other entry point refuses a non-zero rate. */
+    float drop_rate;
+    uint32_t drop_seed, drop_site;
+    int32_t drop_row0;
 } vf_igemm_args;
 
 /* floats needed for the packed form of a [taps][K][N] weight (K,N padded to the tile) */
@@ -200,14 +218,12 @@ int vf_codebook_gather_f32(const float* E /* [D][Kc] */, const int64_t* idx, flo
 int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, float* out,
                             int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
                             float scale, int skip_masked, int twin_view, void* stream);
-/* same contract on the bf16 matrix pipe (Q, K, V and the probabilities rounded to bf16, fp32 sums and softmax): the
- * tolerance-bounded transformer arm.  fp32 tensors in, fp32 out. */
-int vf_attn_blockcausal_bf16(const void* q, const void* k, const void* v, int in_bf16 /* 0: fp32 q/k/v, 1: bf16 (ld* in elements, % 8) */,
-                            void* out, int out_bf16 /* 0: fp32 out, 1: bf16 out (ldo in elements) for a bf16-GEMM consumer */, int B,
-                            int H, int T, int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
-                            void* stream);
-/* the bf16 arm's current kernel (csrc/attention_lp.hip): same contract and rounding points as vf_attn_blockcausal_bf16; a wave owns 64
- * queries as two MFMA tiles sharing every K / V fragment, 5 instead of 8 VALU per score in the softmax */
+/* same contract on the bf16 matrix pipe (Q, K, V and the probabilities rounded to bf16, fp32 sums and softmax): the tolerance-bounded
+ * transformer arm (csrc/attention_lp.hip; with bf16 q / k / v / out, 64-token views and skip_masked the LDS-DMA ring kernel of
+ * csrc/attention_dma.hip, bit-identical).  in_bf16: 0 = fp32 q/k/v, 1 = bf16 (ld* in elements, % 8); out_bf16: 0 = fp32 out, 1 = bf16 out
+ * (ldo in elements) for a bf16-GEMM consumer.  A wave owns 64 queries as two MFMA tiles sharing every K / V fragment, 5 VALU per score in
+ * the softmax.  (The "_v2" is historical: round 1's first kernel, vf_attn_blockcausal_bf16, left the library in round 4 —
+ * tools/variants/attention_bf16_record.hip.) */
 int vf_attn_blockcausal_bf16_v2(const void* q, const void* k, const void* v, int in_bf16, void* out, int out_bf16, int B, int H, int T, int L,
                                 int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view, void* stream);
 /* the same kernel with OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 (BASELINE configs[4] "fp8 MFMA attention"): Q, K, V clamped to
@@ -407,17 +423,19 @@ int vf_lpips_head_bwd_f32(const float* f0, const float* f1, const float* w, floa
  *   prep:  D[B][H][T] = rowsum(dOut * Out)
  *   bwd:   dq, dk, dv [B*T][ld*] (any column offsets / strides: the (V,Q,K) thirds of one buffer are fine)
  *   dropout (attn_dropout, branching_attention.py:15-17): drop_rate in [0, 1); element (b, h, q, k) of softmax(w) is kept iff
- *   vf_dropout_hash(drop_seed, drop_site, ((b*H + h)*T + q)*T + k) >= floor(rate * 2^32) (csrc/vf_common.h) and scaled by 1/(1-rate);
- *   the backward recomputes the same mask.  rate 0 = off. */
+ *   vf_dropout_keep(word, k & 3, floor(rate * 2^32)) with word = the mask word of group q * ceil(T/4) + (k >> 2) in plane b*H + h of
+ *   (drop_seed, drop_site) (csrc/vf_common.h: four consecutive keys of a query share one hashed word), and scaled by 1/(1-rate); the
+ *   backward recomputes the same mask.  rate 0 = off.  drop_plane0: the mask plane of (b = 0, h = 0) — first scene's index in the GLOBAL
+ *   batch times H — so that a data-parallel step draws the masks of the concatenated batch whatever the world size. */
 int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                                 int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
                                 float scale, int skip_masked, int twin_view, float drop_rate, uint32_t drop_seed,
-                                uint32_t drop_site, void* stream);
+                                uint32_t drop_site, uint32_t drop_plane0, void* stream);
 int vf_attn_bwd_prep_f32(const float* dout, const float* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
 int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* D,
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo,
                     int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
-                    uint32_t drop_site, void* stream);
+                    uint32_t drop_site, uint32_t drop_plane0, void* stream);
 /* weight + bias gradient of a dense layer in the bf16 training arm (csrc/gemm_tn_bf16.hip): for split s of the M rows,
  * w_slabs[s][K][N] = sum_m x[m][k] * dy[m][n] and (b_slabs != NULL) b_slabs[s][N] = sum_m dy[m][n], with x a saved bf16 activation
  * [M][ldx] and dy the fp32 gradient [M][ldy], both read as they lie (no transposed copy, no packed copy, no separate column-sum pass).
@@ -428,20 +446,26 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
 int vf_gemm_tn_bf16(const void* x_bf16, int ldx, const void* dy, int dy_is_bf16, int ldy, int M, int K, int N, int splits, float* w_slabs,
                     float* b_slabs, int64_t slab_stride, void* stream);      /* dy_is_bf16: the gradient arrives already rounded to bf16 (ldy in elements) */
 /* bf16 arm of the training step's attention (csrc/attention_dma.hip, attention_train_bf16.hip): bf16 q / k / v / out / dout in HBM
- * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views, no attention dropout — VF_ERR_UNSUPPORTED
- * otherwise (callers then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the
- * per-query log-sum-exp; backward = bf16-MFMA flash kernels (P and dS rounded to bf16 as operands, fp32 sums).  Same masks
- * (twin_view) and the same no-scale convention as the f32 forms; autograd of branching_attention.py:5-18,82-126 under
- * mixed_float16 (migt.py:464-505 with --fp16). */
+ * (ld* in ELEMENTS), fp32 lse, D and gradients; 64-token views, T % 64 == 0, <= 64 views — VF_ERR_UNSUPPORTED otherwise (callers
+ * then take the f32 kernels above).  Forward = vf_attn_blockcausal_bf16_v2's LDS-DMA kernel also writing the per-query
+ * log-sum-exp; backward = bf16-MFMA flash kernels (P and dS rounded to bf16 as operands, fp32 sums).  Same masks (twin_view), the
+ * same no-scale convention and the same attention dropout (drop_rate / drop_seed / drop_site: identical masks, applied to the
+ * bf16-rounded probabilities, 1 / (1 - rate) folded into the output normalisation; rate 0 = off) as the f32 forms; autograd of
+ * branching_attention.py:5-18,82-126 under mixed_float16 (migt.py:464-505 with --fp16). */
 int vf_attn_blockcausal_bf16_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int T, int L,
-                                 int ldq, int ldk, int ldv, int ldo, float scale, int twin_view, void* stream);
+                                 int ldq, int ldk, int ldv, int ldo, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
+                                 uint32_t drop_site, uint32_t drop_plane0, void* stream);
 int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, int H, int T, int lddo, int ldo, void* stream);
 int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, void* dq, void* dk,
                      void* dv, int out_bf16 /* gradients written as bf16 (ldd* in elements) instead of fp32 */, int B, int H, int T, int L,
-                     int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale, int twin_view, void* stream);
-/* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403): out = keep ? x/(1-rate) : 0 [+ res],
- * keep = vf_dropout_hash(seed, site, flat index) >= floor(rate * 2^32); applying it to a gradient gives the backward */
-int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
+                     int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate,
+                     uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, void* stream);
+/* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403) on x [rows][cols] row-major:
+ * out = keep ? x/(1-rate) : 0 [+ res], keep(m, n) = vf_dropout_keep(word of mask group (m' >> 2) * cols + n, m' & 3, floor(rate * 2^32)),
+ * m' = m + row0 (row0: the first row's index in the global batch of a data-parallel step, 0 otherwise) (csrc/vf_common.h: four
+ * consecutive rows of a column share one hashed word — what a lane of a GEMM epilogue holds, so vf_igemm_args.drop_rate applies the
+ * same mask for free); applying it to a gradient gives the backward */
+int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t rows, int cols, int64_t row0, float rate, uint32_t seed, uint32_t site,
                        void* stream);
 
 /* dst[c][r] = src[r][c], `batch` matrices with strides (floats) */
@@ -457,7 +481,10 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d);
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
                          int64_t rows, int d, float eps, int accumulate, const float* res /* NULL or [rows][d]: dx += res */,
-                         void* dx_bf16 /* NULL or [rows][d] bf16: a rounded copy of dx for GEMM consumers */, void* ws, void* stream);
+                         void* dx_bf16 /* NULL or [rows][d] bf16: a rounded copy of dx for GEMM consumers */,
+                         float drop_rate, uint32_t drop_seed, uint32_t drop_site, int64_t drop_row0 /* rate > 0 (needs dx_bf16): the bf16 copy
+                         is vf_dropout_add_f32(dx, cols = d, row0 = drop_row0) of that site — the dY of a layer whose output went through
+                         dropout; dx itself, the residual path's gradient, is not masked */, void* ws, void* stream);
 /* exact-erf GELU (tf.nn.gelu, migt.py:13,70) forward on a saved pre-activation, and its backward */
 int vf_gelu_f32(const float* u, float* f, int64_t n, void* stream);
 /* the same value rounded to bf16 on the way out (the bf16 training arm saves the MLP hidden as its next GEMM reads it) */

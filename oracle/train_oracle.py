@@ -118,19 +118,48 @@ def dropout_hash(seed, site, idx):
     return h.astype(np.uint32)
 
 
-class DropoutMasks:
-    """the masks MIGTTrainer applies (train.py: SITE_EMBED, site_attn/resid/mlp; element index conventions of the kernels) in the
-    shapes the restated forward of migt_oracle needs.  Hidden states are [B, V = NS*S, L, d] row-major in the build, a list of
-    NS tensors [B, S, L, d] here; attention weights are indexed by absolute (query, key) token positions in the V*L sequence."""
+def lowbias32(x):
+    """numpy restatement of vf_lowbias32 (csrc/vf_common.h): uint32 arithmetic with wrap-around"""
+    M = np.uint64(0xFFFFFFFF)
+    x = np.asarray(x, dtype=np.uint64) & M
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7FEB352D)) & M
+    x = x ^ (x >> np.uint64(15))
+    x = (x * np.uint64(0x846CA68B)) & M
+    x = x ^ (x >> np.uint64(16))
+    return x
 
-    def __init__(self, rate, seed, B, NS, S, L, d, H, dtype=torch.float64):
+
+def dropout_keep(seed, site, group, sub, thresh):
+    """numpy restatement of vf_dropout_keep (csrc/vf_common.h): the four elements of 64-bit group index ``group`` share
+    word = lowbias32(lo32(group) ^ vf_dropout_hash(seed, site, hi32(group))); element ``sub`` (0..3) is kept iff rotl32(word, 8 sub) >= thresh"""
+    M = np.uint64(0xFFFFFFFF)
+    g = np.asarray(group, dtype=np.uint64)
+    hi = g >> np.uint64(32)
+    key = np.zeros(g.shape, dtype=np.uint64)
+    for h in np.unique(hi).tolist():                          # (one key per plane)
+        key[hi == np.uint64(h)] = np.uint64(int(dropout_hash(seed, site, np.asarray([h], dtype=np.uint64))[0]))
+    w = lowbias32((g & M) ^ key)
+    sh = (np.asarray(sub, dtype=np.uint64) & np.uint64(3)) * np.uint64(8)
+    rot = np.where(sh == 0, w, ((w << sh) | (w >> (np.uint64(32) - sh))) & M)
+    return rot >= np.uint64(thresh)
+
+
+class DropoutMasks:
+    """the masks MIGTTrainer applies (train.py: SITE_EMBED, site_attn/resid/mlp; group / position conventions of csrc/vf_common.h) in the
+    shapes the restated forward of migt_oracle needs.  Hidden states are [M = B*V*L][d] row-major in the build (V = NS*S), a list of
+    NS tensors [B, S, L, d] here: element (row m, column c) sits in group (m >> 2) * d + c at position m & 3.  Attention weights are indexed
+    by absolute (query, key) token positions in the T = V*L sequence: plane b*H + h, group q * ceil(T/4) + (k >> 2), position k & 3."""
+
+    def __init__(self, rate, seed, B, NS, S, L, d, H, dtype=torch.float64, b0=0):
         self.rate, self.seed, self.B, self.NS, self.S, self.L, self.d, self.H, self.dtype = rate, seed, B, NS, S, L, d, H, dtype
+        self.b0 = b0                                               # index of the first scene in the global batch (MIGTTrainer.scene_offset)
         self.thresh = int(rate * 4294967296.0)
         self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))      # fp32 like the kernels
         self._attn_cache = {}
 
-    def _mask(self, site, idx):
-        keep = dropout_hash(self.seed, site, idx) >= np.uint32(self.thresh)
+    def _mask(self, site, group, sub):
+        keep = dropout_keep(self.seed, site, group, sub, self.thresh)
         return torch.from_numpy(keep.astype(np.float64) * self.scale).to(self.dtype)
 
     def elem(self, kind, layer, stream, x):
@@ -138,16 +167,18 @@ class DropoutMasks:
         B, S, L, d = self.B, self.S, self.L, self.d
         V = self.NS * S
         b, i, t, c = np.meshgrid(np.arange(B), np.arange(S), np.arange(L), np.arange(d), indexing='ij')
-        idx = ((b.astype(np.uint64) * V + stream * S + i) * L + t) * d + c
-        return self._mask(site, idx).reshape(x.shape)
+        m = (((b.astype(np.uint64) + np.uint64(self.b0)) * np.uint64(V) + np.uint64(stream * S) + i.astype(np.uint64)) * np.uint64(L)
+             + t.astype(np.uint64))
+        return self._mask(site, (m >> np.uint64(2)) * np.uint64(d) + c.astype(np.uint64), m & np.uint64(3)).reshape(x.shape)
 
     def _full(self, layer):
         if layer not in self._attn_cache:
             B, H = self.B, self.H
             T = self.NS * self.S * self.L
             b, h, q, k = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing='ij')
-            idx = ((b.astype(np.uint64) * H + h) * T + q) * T + k
-            self._attn_cache = {layer: self._mask(16 + 4 * layer, idx)}
+            k = k.astype(np.uint64)
+            group = (((b.astype(np.uint64) + np.uint64(self.b0)) * np.uint64(H) + h.astype(np.uint64)) << np.uint64(32)) | (q.astype(np.uint64) * np.uint64((T + 3) // 4) + (k >> np.uint64(2)))
+            self._attn_cache = {layer: self._mask(16 + 4 * layer, group, k & np.uint64(3))}
         return self._attn_cache[layer]
 
     def attn(self, layer, stream, kind):

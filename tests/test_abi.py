@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_queries(lib):
-    assert lib.vf_abi_version() == 16
+    assert lib.vf_abi_version() == 17
     # the struct mirrors of the binding have the library's layout (checked again at load time: a mismatch raises)
     import ctypes
     from viewformer_amd import _lib as L
@@ -65,6 +65,25 @@ def test_shipped_library_has_no_developer_switch_compiled_in(lib):
     assert used <= known, used - known
 
 
+def test_library_reads_no_environment_and_its_switches_are_explicit(lib):
+    """No run-time knob can change a result behind the caller's back: libvf_hip.so does not import getenv / secure_getenv at all (round 3
+    shipped several per-launch getenv calls, one of which selected a kernel with wrong results); the only run-time switches are
+    vf_select's, each between two kernels the GPU tests assert bit-identical, and they validate their arguments."""
+    import subprocess
+    from viewformer_amd import _lib
+    syms = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in syms, [l for l in syms.splitlines() if 'getenv' in l]
+    csrc = os.path.join(REPO, 'viewformer_amd', 'csrc')
+    for f in os.listdir(csrc):
+        assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+    n = 3
+    for which in range(n):
+        assert lib.vf_selected(which) == 1                                   # defaults: the faster kernel of each pair
+        assert lib.vf_select(which, 0) == 1 and lib.vf_selected(which) == 0
+        assert lib.vf_select(which, 1) == 0 and lib.vf_selected(which) == 1
+    assert lib.vf_select(n, 1) == -1 and lib.vf_select(-1, 1) == -1 and lib.vf_select(0, 2) == -1 and lib.vf_selected(n) == -1
+
+
 def test_argument_validation_without_gpu(lib):
     from viewformer_amd._lib import VfIgemmArgs
     P = ctypes.c_void_p
@@ -87,6 +106,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.vf_attn_blockcausal_f32(d, d, d, d, 1, 2, 64, 64, 64, 128, 128, 128, 1.0, 1, -1, None) == -1   # ldq < H*64
     assert lib.vf_dense_small_k_gelu_f32(d, d, d, d, 4, 32, 8, 1, None) == -2
     assert lib.vf_conv_in_u8_f32(None, None, d, d, d, 1, 8, 8, 32, None) == -1
+    # fused output dropout (vf_igemm_args.drop_rate): vf_gemm_bf16's 256-tile shapes only — refused elsewhere, never ignored
+    a = VfIgemmArgs()
+    a.x = a.w_packed = a.out = 4096
+    a.M, a.Cin, a.Cout, a.lda, a.ldc, a.drop_rate = 512, 256, 256, 256, 256, 0.1
+    assert lib.vf_igemm_f32(ctypes.byref(a), None) == -2
+    assert lib.vf_gemm_x6(ctypes.byref(a), None) == -2 and lib.vf_gemm_x3h(ctypes.byref(a), None) == -2
+    assert lib.vf_gemm_bf16(ctypes.byref(a), None) == -2                      # fp32 activations in: no fused form
+    a.reserved0, a.drop_row0 = 1, 2
+    assert lib.vf_gemm_bf16(ctypes.byref(a), None) == -2                      # drop_row0 % 4 != 0
+    assert lib.vf_dropout_add_f32(d, None, d, 4, 0, 0, 0.1, 1, 1, None) == -1  # cols <= 0
+    assert lib.vf_dropout_add_f32(d, None, d, 0, 8, 0, 0.1, 1, 1, None) == 0   # empty
+    assert lib.vf_dropout_add_f32(d, None, d, 4, 8, 0, 1.0, 1, 1, None) == -1  # rate must be < 1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

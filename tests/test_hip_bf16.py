@@ -187,9 +187,9 @@ def test_attention_bf16_all_mask_modes(dev, B, H, S, L, mode):
 
 @pytest.mark.parametrize('B,H,S,mode', [(1, 12, 7, 'causal'), (2, 3, 8, 'twin'), (1, 2, 3, 'streams'), (3, 2, 1, 'causal'), (2, 2, 5, 'twin'),
                                         (1, 2, 21, 'twin')])
-def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev, B, H, S, mode, monkeypatch):
+def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev, B, H, S, mode):
     """bf16 q/k/v in, bf16 out, 64-token views: the LDS-DMA ring kernel (attention_dma.hip) against attention_lp.hip on the same
-    inputs (VF_ATTN_DMA=0) — same MFMAs in the same key order, same softmax: identical bits; and within ATTN_TOL of the exact fp32
+    inputs (vf_select(VF_SEL_ATTN_DMA, 0)) — same MFMAs in the same key order, same softmax: identical bits; and within ATTN_TOL of the exact fp32
     kernel.  Covers one-view sequences, sequences that do not fill the last 4-view workgroup, and 21-view sequences (S = 20 + twin)."""
     from viewformer_amd import ops
     L, d = 64, H * 64
@@ -201,10 +201,14 @@ def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev
     ref = torch.empty((B * T, d), device=dev)
     ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], ref, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec)
     outs = {}
+    from viewformer_amd import _lib
     for flag in ('1', '0'):
-        monkeypatch.setenv('VF_ATTN_DMA', flag)
-        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
-        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        prev = _lib.select(_lib.SEL_ATTN_DMA, flag == '1')
+        try:
+            out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
+            ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
+        finally:
+            _lib.select(_lib.SEL_ATTN_DMA, prev)
         outs[flag] = out
     assert not torch.isnan(outs['1'].float()).any()
     assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
@@ -212,70 +216,8 @@ def test_attention_dma_kernel_is_bit_identical_to_the_register_staged_kernel(dev
     assert err < ATTN_TOL, err
 
 
-@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 10, 'streams'), (1, 3, 9, 'causal'), (2, 1, 17, 'causal'), (1, 2, 21, 'twin')])
-def test_attention_dma_8_wave_form_is_bit_identical_to_the_4_wave_form(dev, B, H, S, mode, monkeypatch):
-    """the 8-wave workgroup (8 query views, 8-slot ring: every K / V tile of a (scene, head) fetched once per 8 views; taken for more than
-    4 views) against the 4-wave workgroup it replaces there (VF_ATTN_DMA8=0): per-wave arithmetic is the same, so are the bits.  Covers the
-    bench shape (8 views), workgroups whose last waves have no view, > 8 key views (ring slots recycled) and the training mask."""
-    from viewformer_amd import ops
-    L, d = 64, H * 64
-    NS = 3 if mode == 'streams' else 1
-    T = NS * S * L
-    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
-    q16 = _rand((B * T, 3 * d), 93, 0.35).to(dev).to(torch.bfloat16)
-    outs = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('VF_ATTN_DMA8', flag)
-        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
-        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
-        outs[flag] = out
-    assert not torch.isnan(outs['1'].float()).any()
-    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
-
-
-@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 8, 'causal'), (1, 3, 7, 'causal'), (2, 1, 2, 'causal'), (1, 2, 3, 'twin'), (2, 2, 5, 'twin'),
-                                        (1, 1, 2, 'streams'), (4, 12, 8, 'twin')])
-def test_attention_resident_form_is_bit_identical_to_the_ring_kernel(dev, B, H, S, mode, monkeypatch):
-    """the resident kernel (attn_res_kernel: K / V of a (scene, head) in LDS behind one barrier, wave = 32 queries of view p and of view
-    nviews - 1 - p; opt-in, VF_ATTN_RES=1, for 2 .. 8 views — measured slower than the ring kernel) against the 4-wave ring kernel (VF_ATTN_RES=0): the same per-query arithmetic, the same bits.
-    Even and odd view counts (the middle view of an odd count has no partner), every mask mode that fits 8 views, the bench's twin shape."""
-    from viewformer_amd import ops
-    L, d = 64, H * 64
-    NS = 3 if mode == 'streams' else 1
-    T = NS * S * L
-    assert T <= 512
-    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
-    q16 = _rand((B * T, 3 * d), 95, 0.35).to(dev).to(torch.bfloat16)
-    outs = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('VF_ATTN_RES', flag)
-        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
-        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
-        outs[flag] = out
-    assert not torch.isnan(outs['1'].float()).any()
-    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
-
-
-@pytest.mark.parametrize('B,H,S,mode', [(3, 4, 8, 'twin'), (2, 2, 10, 'streams'), (1, 3, 7, 'causal'), (2, 1, 1, 'causal'), (1, 2, 21, 'twin'), (2, 2, 3, 'streams')])
-def test_attention_ring_kernel_software_pipelined_form_is_bit_identical(dev, B, H, S, mode, monkeypatch):
-    """attn_dma_kernel<5, true> (tile t's S MFMAs issued before tile t - 1's softmax + P.V, five ring slots; opt-in, VF_ATTN_PIPE=1: measured
-    slower — it spills) against <4, false>: the same
-    per-query arithmetic in the same order — identical bits — in every mask mode, with masked tiles in between (streams), one-view and
-    21-view sequences"""
-    from viewformer_amd import ops
-    L, d = 64, H * 64
-    NS = 3 if mode == 'streams' else 1
-    T = NS * S * L
-    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
-    q16 = _rand((B * T, 3 * d), 97, 0.35).to(dev).to(torch.bfloat16)
-    outs = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('VF_ATTN_PIPE', flag)
-        out = torch.full((B * T, d), float('nan'), dtype=torch.bfloat16, device=dev)
-        ops.attn_blockcausal(q16[:, d:2 * d], q16[:, 2 * d:], q16[:, :d], out, B, H, T, L, 3 * d, 3 * d, 3 * d, d, 0.7, True, spec, bf16=True)
-        outs[flag] = out
-    assert not torch.isnan(outs['1'].float()).any()
-    assert torch.equal(outs['1'], outs['0']), (outs['1'].float() - outs['0'].float()).abs().max().item()
+# (The bit-identity tests of round 3's three slower forms of this kernel — 8-wave, resident, software-pipelined — left with the kernels:
+# tools/variants/attention_dma_r3_records.hip; they passed on MI355X at commit 7e8c4c4, GPUTEST_r03.json.)
 
 
 def test_bf16_activation_chain_is_bit_identical(dev):
@@ -331,9 +273,9 @@ def test_bf16_activation_chain_is_bit_identical(dev):
 
 @pytest.mark.parametrize('M,K,N', [(512, 128, 256), (1000, 768, 768), (2048, 768, 2304), (1290, 3072, 768), (4096, 768, 3072), (770, 256, 1280),
                                    (1536, 256, 512), (2048, 128, 2048)])
-def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N, monkeypatch):
+def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N):
     """the 256 x 256 LDS-DMA kernel (gemm_bf16_g256.hip, taken for bf16 activations and 256-aligned widths) against the 128 x 128 kernel
-    (VF_GEMM_G256=0): same MFMA, same k order, fp32 epilogue -> the same bits; ragged last row tile, residual, GELU, bf16 output;
+    (vf_select(VF_SEL_GEMM_G256, 0)): same MFMA, same k order, fp32 epilogue -> the same bits; ragged last row tile, residual, GELU, bf16 output;
     and against the fp64 reference on the bf16-rounded operands"""
     from viewformer_amd import ops
     x = _rand((M, K), 71).to(dev).to(torch.bfloat16)
@@ -347,13 +289,15 @@ def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N, monkey
         return out
     for epi, res, o16 in ((ops.EPI_NONE, None, False), (ops.EPI_NONE, r, False), (ops.EPI_GELU, None, True), (ops.EPI_NONE, None, True),
                           (ops.EPI_GELU, r, False)):
-        monkeypatch.setenv('VF_GEMM_G256', '1')
+        from viewformer_amd import _lib
         new = run(epi, res, o16)
-        monkeypatch.setenv('VF_GEMM_G256', '0')
-        old = run(epi, res, o16)
+        prev = _lib.select(_lib.SEL_GEMM_G256, 0)
+        try:
+            old = run(epi, res, o16)
+        finally:
+            _lib.select(_lib.SEL_GEMM_G256, prev)
         assert not torch.isnan(new.float()).any()
         assert torch.equal(new, old), (epi, res is not None, o16, (new.float() - old.float()).abs().max().item())
-    monkeypatch.setenv('VF_GEMM_G256', '1')
     plain = run(ops.EPI_NONE, None, False)
     assert _rel(plain, ref64) < 2e-6
 

@@ -212,12 +212,87 @@ def test_full_size_step_is_finite_deterministic_and_bf16_tracks_the_fp32_arm(dev
     assert traj[-1] < float(mb['loss']) - 0.05, (float(mb['loss']), traj)
 
 
-def _full_worker(rank, world, port, q):
+def test_full_size_step_at_the_reference_dropout(dev):
+    """configs[3] as the reference trains it: MIGTConfig.dropout = 0.1 (models/config.py:66; four sites, migt.py:72,216,403 and
+    branching_attention.py:15-17) in the bf16 arm — where since round 4 the masks live inside the projection GEMMs' epilogues, the LayerNorm
+    backward's bf16 copy and the bf16 flash kernels.  Size-independent checks: the fast kernels are the ones that run; finite; bit-
+    deterministic for a fixed seed and different for another; the fused forms equal the separate dropout passes (loss bit for bit,
+    gradients bit for bit except the two projection layers' bias gradients, sums of rounded values); within BF16_GRAD_TOL of the
+    fp32-equivalent arm under the SAME masks."""
+    from viewformer_amd import ops
+    from viewformer_amd import train_ops as T
+    cfg = _cfg(dropout=0.1)
+    B, S = 4, 10
+    poses, tokens = _batch(B, S, seed=7)
+    tr16 = _trainer(cfg, dev, 'bf16')
+    tr16.dropout_seed = 5
+    tr16.bf16_preactivation = False                       # (the bit-level comparison with the unfused form below reads an fp32 u in both)
+    calls = dict(attn=0, drop_gemm=0, ln_drop=0, drop_pass=0)
+    o_attn, o_igemm, o_ln, o_da = T.attn_bwd_bf16, ops.igemm, T.layernorm_bwd, T.dropout_add
+
+    def count(key, fn, pred):
+        def wrapped(*a, **k):
+            calls[key] += 1 if pred(k) else 0
+            return fn(*a, **k)
+        return wrapped
+    T.attn_bwd_bf16 = count('attn', o_attn, lambda k: k.get('drop', (0,))[0] > 0)
+    ops.igemm = count('drop_gemm', o_igemm, lambda k: k.get('drop') is not None and k['drop'][0] > 0)
+    T.layernorm_bwd = count('ln_drop', o_ln, lambda k: k.get('drop', (0,))[0] > 0 and k.get('also_bf16'))
+    T.dropout_add = count('drop_pass', o_da, lambda k: True)
+    try:
+        m1 = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    finally:
+        T.attn_bwd_bf16, ops.igemm, T.layernorm_bwd, T.dropout_add = o_attn, o_igemm, o_ln, o_da
+    # 12 flash backward launches with dropout, 24 projection GEMMs with the mask in their epilogue, 24 LayerNorm backward copies under a
+    # mask (ln_f + ln_2 of every layer + ln_1 of layers 1..11), and only the embedding's two passes left as passes
+    assert calls == dict(attn=cfg.n_layer, drop_gemm=2 * cfg.n_layer, ln_drop=2 * cfg.n_layer, drop_pass=2), calls
+    g1 = tr16.flat_g.clone()
+    assert np.isfinite(float(m1['loss'])) and bool(torch.isfinite(g1).all())
+    m2 = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(tr16.flat_g, g1) and float(m2['loss']) == float(m1['loss'])           # deterministic for a fixed seed
+    tr16.dropout_seed = 6
+    m3 = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert float(m3['loss']) != float(m1['loss']) and not torch.equal(tr16.flat_g, g1)       # another seed, other masks
+    tr16.dropout_seed = 5
+    # the separate passes (round 3's form of the same step): same masks, same fp32 operations in the forward -> the same loss bits
+    tr16.fuse_dropout = False
+    mu = tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert float(mu['loss']) == float(m1['loss'])
+    for n in tr16.names:
+        a, b, _ = tr16.slices[n]
+        if n.endswith('mlp.c_proj.bias') or n.endswith('attn.c_proj.bias'):
+            assert _rel(g1[a:b], tr16.flat_g[a:b]) < 2e-3, n                                 # (sums of the bf16-rounded vs the fp32 masked gradient)
+        else:
+            assert torch.equal(g1[a:b], tr16.flat_g[a:b]), n
+    tr16.fuse_dropout = True
+    # the fp32-equivalent arm under the same masks
+    tr32 = _trainer(cfg, dev, 'f32')
+    tr32.dropout_seed = 5
+    m32 = tr32.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert abs(float(m1['loss']) - float(m32['loss'])) < 2e-2 * max(1.0, abs(float(m32['loss'])))
+    worst = ('', 0.0)
+    for n in tr16.names:
+        ref = tr32.g(n)
+        if float(ref.abs().max()) == 0:
+            continue
+        a, b, _ = tr16.slices[n]
+        e = _rel(g1[a:b].view(-1), ref.reshape(-1))
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < BF16_GRAD_TOL, (n, e)
+    print('full-size bf16 arm vs fp32-equivalent arm at dropout 0.1 (same masks): worst per-tensor gradient error', worst)
+    # dropout is really on: the no-dropout loss of the same batch differs
+    tr0 = _trainer(_cfg(dropout=0.0), dev, 'bf16')
+    m0 = tr0.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert abs(float(m0['loss']) - float(m1['loss'])) > 1e-4
+
+
+def _full_worker(rank, world, port, q, dropout=0.0):
     try:
         from test_hip_multirank import _init, _gather, _rel as rel
         dev, dist = _init(rank, world, port)
-        cfg = _cfg()
+        cfg = _cfg(dropout=dropout)
         tr = _trainer(cfg, dev, 'bf16')
+        tr.dropout_seed = 9
         B, S = 2, 10
         poses, tok = _batch(B, S, 100 + rank)
         tr.train_step(poses, tok, reduce_gradients=False, apply_update=False)
@@ -228,7 +303,9 @@ def _full_worker(rank, world, port, q):
         e_sum = rel(g_red, g_sum)
         worst = max(((n, rel(g_red[a:b], g_sum[a:b])) for n, (a, b, _) in tr.slices.items() if float(g_sum[a:b].abs().max()) > 0), key=lambda t: t[1])
         allb = [_batch(B, S, 100 + r) for r in range(world)]
+        tr.scene_offset = 0                                                            # one process, the whole global batch: its scenes are 0 .. world B - 1
         tr.train_step(torch.cat([b[0] for b in allb]), torch.cat([b[1] for b in allb]), reduce_gradients=False, apply_update=False)
+        tr.scene_offset = None                                                         # (back to rank x local batch)
         e_cat = rel(g_red, tr.flat_g * world)
         tr.train_step(poses, tok)                                                      # one optimizer step: replicas stay identical
         params = _gather(tr.flat_p, dist, world)
@@ -240,9 +317,16 @@ def _full_worker(rank, world, port, q):
         q.put((rank, 'err', traceback.format_exc() + repr(e)))
 
 
-def test_full_size_two_ranks_equal_the_concatenated_batch():
+def _full_worker_dropout(rank, world, port, q):
+    _full_worker(rank, world, port, q, dropout=0.1)
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_full_size_two_ranks_equal_the_concatenated_batch(dropout):
+    """with dropout the equality needs what round 4 added: every mask is a function of the GLOBAL scene index (MIGTTrainer.scene_offset =
+    rank x local batch), so two ranks draw exactly the masks one process draws on the concatenated batch — and not the same mask twice"""
     from test_hip_multirank import _run
-    res = _run(_full_worker)
+    res = _run(_full_worker_dropout if dropout else _full_worker)
     print(res)
     for r, m in res.items():
         assert m['e_sum'] < 1e-6, m

@@ -357,7 +357,7 @@ def test_bf16_training_step_gradients_within_stated_tolerance(dev):
 
 
 def test_dropout_hash_restatement_statistics():
-    """CPU: the numpy restatement of the counter-based mask behaves like a uniform generator and is index-sensitive"""
+    """CPU: the numpy restatement of the counter hash behaves like a uniform generator and is index-sensitive"""
     from oracle import train_oracle as to
     idx = np.arange(1 << 18, dtype=np.uint64)
     h = to.dropout_hash(123, 17, idx)
@@ -372,13 +372,51 @@ def test_dropout_hash_restatement_statistics():
     assert abs(bits - 0.5) < 2e-3
 
 
+def test_dropout_mask_definition_statistics():
+    """CPU: the MASK definition (csrc/vf_common.h: four elements share one lowbias32 word, element j keeps iff rotl(word, 8 j) >= thresh):
+    the oracle's restatement and the host module's agree; every position of a group has the nominal keep rate; the four decisions of a
+    group, neighbouring groups, sites, seeds and mask planes are uncorrelated; the number of dropped elements per group is binomial."""
+    from oracle import train_oracle as to
+    from viewformer_amd import _hash as hh
+    rate, M, N = 0.1, 2048, 768
+    thresh = int(rate * 4294967296.0)
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
+    g, j = hh.elem_group(m, n, N)
+    k = to.dropout_keep(123, 17, g, j, thresh)
+    assert np.array_equal(k, hh.dropout_keep(123, 17, g, j, rate))
+    sig = np.sqrt(rate * (1 - rate) / k.size)
+    assert abs(k.mean() - (1 - thresh / 2 ** 32)) < 4 * sig
+    for pos in range(4):                                                           # (a rotation of a uniform word is uniform)
+        assert abs(k[pos::4].mean() - 0.9) < 4 * sig * 2
+    d = k - k.mean()
+    corr = lambda a, b: float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))      # noqa: E731
+    lim = 5.0 / np.sqrt(k.size / 4)
+    for pos in (1, 2, 3):
+        assert abs(corr(d[0::4], d[pos::4])) < lim                                 # inside a group
+    assert abs(corr(d[:, :-1], d[:, 1:])) < lim and abs(corr(d[:-4], d[4:])) < lim  # neighbouring groups (next column, next row block)
+    for other in (to.dropout_keep(123, 18, g, j, thresh), to.dropout_keep(124, 17, g, j, thresh),
+                  to.dropout_keep(123, 17, g + (np.uint64(1) << np.uint64(32)), j, thresh)):   # site, seed, plane (high word)
+        assert abs(corr(d, other - other.mean())) < lim
+    import math
+    nd = (~k.reshape(M // 4, 4, N)).sum(1)
+    for c in range(4):
+        want = math.comb(4, c) * rate ** c * (1 - rate) ** (4 - c)
+        assert abs((nd == c).mean() - want) < 5 * np.sqrt(want / nd.size) + 1e-5, c
+    # attention convention: plane (b, h) in the high word, four consecutive keys of a query per group
+    ga, ja = hh.attn_group(3, np.arange(130)[:, None], np.arange(130)[None, :], 130)
+    assert int(ga[5, 7] >> np.uint64(32)) == 3 and int(ga[5, 7] & np.uint64(0xFFFFFFFF)) == 5 * 33 + 1 and int(ja[5, 7]) == 3
+    assert np.array_equal(to.dropout_keep(9, 16, ga, ja, thresh), hh.dropout_keep(9, 16, ga, ja, rate))
+
+
 @pytest.mark.gpu
-def test_dropout_kernels_use_the_restated_mask(dev):
+@pytest.mark.parametrize('rows,cols', [(1303, 77), (4096, 768), (37, 64)])
+def test_dropout_kernels_use_the_restated_mask(dev, rows, cols):
     from oracle import train_oracle as to
     from viewformer_amd import train_ops as T
-    n, rate, seed, site = 100003, 0.25, 0xDEADBEEF, 21
-    x, r = _rand((n,), 1), _rand((n,), 2)
-    keep = to.dropout_hash(seed, site, np.arange(n, dtype=np.uint64)) >= np.uint32(int(rate * 4294967296.0))
+    rate, seed, site = 0.25, 0xDEADBEEF, 21
+    x, r = _rand((rows, cols), 1), _rand((rows, cols), 2)
+    m, n = np.meshgrid(np.arange(rows, dtype=np.uint64), np.arange(cols, dtype=np.uint64), indexing='ij')
+    keep = to.dropout_keep(seed, site, (m >> np.uint64(2)) * np.uint64(cols) + n, m & np.uint64(3), int(rate * 4294967296.0))
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
     want = np.where(keep, x.numpy() * scale, np.float32(0)) + r.numpy()
     got = T.dropout_add(x.to(dev), rate, seed, site, res=r.to(dev))
@@ -386,6 +424,53 @@ def test_dropout_kernels_use_the_restated_mask(dev):
     xd = x.to(dev).clone()
     T.dropout_add(xd, rate, seed, site, out=xd)                                    # in place, no residual
     assert np.array_equal(xd.cpu().numpy(), np.where(keep, x.numpy() * scale, np.float32(0)).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N', [(1024, 768, 768), (19200, 3072, 768), (1000, 256, 256)])
+def test_fused_output_dropout_of_the_projection_gemm(dev, M, K, N):
+    """igemm(drop=...): res + dropout(x @ W + b) from ONE epilogue (csrc/gemm_bf16_g256.hip) == the GEMM followed by dropout_add, bit for
+    bit (the same accumulator, the same mask, the same fp32 operations in the same order)"""
+    from viewformer_amd import ops
+    from viewformer_amd import train_ops as T
+    g = np.random.Generator(np.random.PCG64(M + N))
+    x16 = torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    w = torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(g.standard_normal((N,)).astype(np.float32)).to(dev)
+    res = torch.from_numpy(g.standard_normal((M, N)).astype(np.float32)).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    drop = (0.1, 4242, 18)
+    assert ops.gemm_drop_supported(M, K, N)
+    y = torch.empty((M, N), device=dev)
+    ops.igemm(x16, wp, M, K, N, y, bias=b, bf16=True, a16=True)
+    want = T.dropout_add(y, *drop, res=res)
+    got = torch.full((M, N), float('nan'), device=dev)
+    ops.igemm(x16, wp, M, K, N, got, bias=b, res=res, bf16=True, a16=True, drop=drop)
+    assert torch.equal(got, want)
+    dropped = (got == res).float().mean().item()
+    assert abs(dropped - 0.1) < 0.01, dropped
+    with pytest.raises(Exception):                                                 # a shape outside the 256-tile kernel is refused, not mis-served
+        ops.igemm(x16[:, :64].contiguous(), ops.pack_dense_kn_bf16(w[:64, :128].contiguous()), M, 64, 128, torch.empty((M, 128), device=dev),
+                  bf16=True, a16=True, drop=drop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,d', [(1920, 768), (19200, 768), (515, 256)])
+def test_layernorm_backward_masked_bf16_copy(dev, rows, d):
+    """layernorm_bwd(also_bf16=True, drop=...): the bf16 copy == bf16(dropout_add(dx)) of that site, while dx, dgamma, dbeta keep their bits"""
+    from viewformer_amd import train_ops as T
+    g = np.random.Generator(np.random.PCG64(rows))
+    dy, x, res = (torch.from_numpy(g.standard_normal((rows, d)).astype(np.float32)).to(dev) for _ in range(3))
+    gamma = torch.from_numpy((1 + 0.1 * g.standard_normal(d)).astype(np.float32)).to(dev)
+    outs = []
+    for drop in ((0.0, 0, 0), (0.1, 99, 17)):
+        dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        dx, dx16 = T.layernorm_bwd(dy, x, gamma, dg, db, rows, d, res=res, also_bf16=True, drop=drop)
+        outs.append((dx, dx16, dg, db))
+    (dx0, c0, dg0, db0), (dx1, c1, dg1, db1) = outs
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(c0, dx0.to(torch.bfloat16))
+    assert torch.equal(c1, T.dropout_add(dx0, 0.1, 99, 17).to(torch.bfloat16))
 
 
 @pytest.mark.gpu
@@ -589,6 +674,68 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,H,S,mode', [(2, 2, 4, 'causal'), (2, 2, 3, 'streams'), (1, 2, 10, 'streams'), (3, 1, 5, 'twin')])
+def test_bf16_flash_attention_with_dropout(dev, B, H, S, mode):
+    """attention dropout inside the bf16 forward / dQ / dK-dV kernels (round 4): the SAME masks as the exact-f32 kernels — which
+    test_flash_attention_with_dropout_matches_autograd pins to fp64 autograd with the masks restated in numpy — so on the same
+    bf16-rounded operands the two arms agree within the bf16 arm's own tolerance; the log-sum-exp is over the undropped weights, i.e.
+    bit-identical to the no-dropout call; the fraction of exactly-zero probabilities is the rate (checked through P.V with V = I)."""
+    from viewformer_amd import train_ops as T
+    L, d = 64, H * 64
+    NS = 3 if mode == 'streams' else 1
+    Tn = NS * S * L
+    spec = {'causal': -1, 'twin': max(S - 2, 0), 'streams': -S}[mode]
+    drop = (0.1, 31337, 24)
+    g = np.random.Generator(np.random.PCG64(23))
+    qkv16 = torch.from_numpy((g.standard_normal((B * Tn, 3 * d)) * 0.4).astype(np.float32)).to(dev).to(torch.bfloat16)
+    do16 = torch.from_numpy(g.standard_normal((B * Tn, d)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    qkv32, do32 = qkv16.float(), do16.float()
+    att32 = torch.empty((B * Tn, d), device=dev)
+    lse32 = T.attn_fwd_lse(qkv32[:, d:2 * d], qkv32[:, 2 * d:], qkv32[:, :d], att32, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec, drop=drop)
+    ref = torch.empty((B * Tn, 3 * d), device=dev)
+    T.attn_bwd(qkv32[:, d:2 * d], qkv32[:, 2 * d:], qkv32[:, :d], att32, do32, lse32, ref[:, d:2 * d], ref[:, 2 * d:], ref[:, :d],
+               B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec, drop=drop)
+    att16 = torch.full((B * Tn, d), float('nan'), dtype=torch.bfloat16, device=dev)
+    lse16 = T.attn_fwd_lse_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec, drop=drop)
+    att_nd = torch.empty_like(att16)
+    lse_nd = T.attn_fwd_lse_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att_nd, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec)
+    assert torch.equal(lse16, lse_nd) and not torch.equal(att16, att_nd)
+    e_fwd = ((att16.float() - att32).abs().max() / att32.abs().max()).item()
+    assert e_fwd < ATTN_BF16_FWD_TOL, e_fwd
+    got = torch.full((B * Tn, 3 * d), float('nan'), device=dev)
+    T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got[:, d:2 * d], got[:, 2 * d:], got[:, :d],
+                    B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec, drop=drop)
+    assert not torch.isnan(got).any()
+    errs = {}
+    for name, sl in (('dv', slice(0, d)), ('dq', slice(d, 2 * d)), ('dk', slice(2 * d, 3 * d))):
+        errs[name] = ((got[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max()).item()
+        assert errs[name] < ATTN_BF16_BWD_TOL, (name, errs)
+    print(f'bf16 training attention with dropout {mode} B={B} H={H} S={S}: fwd {e_fwd:.2e} bwd {errs}')
+    got2 = torch.empty_like(got)
+    T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got2[:, d:2 * d], got2[:, 2 * d:], got2[:, :d],
+                    B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec, drop=drop)
+    assert torch.equal(got, got2)                                                  # deterministic
+    # the mask itself: q = k = 0 makes every visible weight equal, V = one-hot(key position within its view) -> the output of query i is
+    # (1 / (1 - rate)) / (visible keys) * (kept keys at each position): exactly-zero entries of a single-view causal call mark dropped keys
+    if mode == 'causal' and S == 4:
+        from oracle import train_oracle as to
+        z = torch.zeros((B * Tn, 3 * d), dtype=torch.bfloat16, device=dev)
+        eye = torch.eye(64, dtype=torch.bfloat16, device=dev).repeat(B * S, H)      # V[t][h*64 + c] = (t % 64 == c)
+        z[:, :d] = eye
+        o = torch.empty((B * Tn, d), dtype=torch.bfloat16, device=dev)
+        T.attn_fwd_lse_bf16(z[:, d:2 * d], z[:, 2 * d:], z[:, :d], o, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec, drop=drop)
+        o = o.float().view(B, Tn, H, 64).cpu().numpy()
+        thresh = int(drop[0] * 4294967296.0)
+        for b in range(B):
+            for h in range(H):
+                q = np.arange(64)                                                  # queries of view 0 see exactly the 64 keys of view 0
+                qq, kk = np.meshgrid(q, np.arange(64), indexing='ij')
+                grp = (np.uint64(b * H + h) << np.uint64(32)) | (qq.astype(np.uint64) * np.uint64(Tn // 4) + (kk.astype(np.uint64) >> np.uint64(2)))
+                keep = to.dropout_keep(drop[1], drop[2], grp, kk.astype(np.uint64) & np.uint64(3), thresh)
+                assert np.array_equal(o[b, :64, h] != 0, keep), (b, h)
+
+
+@pytest.mark.gpu
 def test_bf16_attention_is_what_the_bf16_training_arm_runs_at_full_width(dev):
     """head dim 64, 64-token views, no dropout: the trainer takes the bf16 attention kernels; with attention_arith='f32' the exact-f32
     ones — gradients of the two agree within the bf16 arm's own tolerance"""
@@ -673,9 +820,9 @@ def test_tn_weight_gradient_gemm(dev, M, K, N):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('M', [512, 640])         # whole 256-row tiles / a ragged last tile
-def test_gelu_backward_epilogue_of_the_256_tile_kernel(dev, M, monkeypatch):
+def test_gelu_backward_epilogue_of_the_256_tile_kernel(dev, M):
     """VF_EPI_GELU_BWD on the 256 x 256 LDS-DMA kernel (bf16 gradient in, bf16 d(pre-activation) out): the same bits as the 128-tile
-    kernel's epilogue (VF_GEMM_G256=0) and as the separate passes (fp32 dX, then gelu_bwd with a bf16 result)."""
+    kernel's epilogue (vf_select(VF_SEL_GEMM_G256, 0)) and as the separate passes (fp32 dX, then gelu_bwd with a bf16 result)."""
     from viewformer_amd import ops
     from viewformer_amd import train_ops as T
     K, N = 768, 3072                                                             # dy [M, K] @ W^T [K, N]
@@ -686,12 +833,15 @@ def test_gelu_backward_epilogue_of_the_256_tile_kernel(dev, M, monkeypatch):
     wp = ops.pack_dense_kn_bf16(w)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     ops.igemm(dy16, wp, M, K, N, out, res=u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
-    monkeypatch.setenv('VF_GEMM_G256', '0')
-    out128 = torch.empty_like(out)
-    ops.igemm(dy16, wp, M, K, N, out128, res=u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
-    dx = torch.empty((M, N), device=dev)
-    ops.igemm(dy16, wp, M, K, N, dx, bf16=True, a16=True)
-    monkeypatch.delenv('VF_GEMM_G256')
+    from viewformer_amd import _lib
+    prev = _lib.select(_lib.SEL_GEMM_G256, 0)
+    try:
+        out128 = torch.empty_like(out)
+        ops.igemm(dy16, wp, M, K, N, out128, res=u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True)
+        dx = torch.empty((M, N), device=dev)
+        ops.igemm(dy16, wp, M, K, N, dx, bf16=True, a16=True)
+    finally:
+        _lib.select(_lib.SEL_GEMM_G256, prev)
     assert torch.equal(out, out128)
     assert torch.equal(out, T.gelu_bwd(u, dx, out_bf16=True))
     ref = dy16.double() @ w.to(torch.bfloat16).double()

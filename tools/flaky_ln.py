@@ -33,7 +33,7 @@ def worker(rank, n_iter):
             if bad <= 6:
                 print(f'rank {rank} iter {it}: differs dx={diff[0]} dx16={diff[1]} dgamma={diff[2]} dbeta={diff[3]}; dx rows {rows[:12]} ({len(rows)}), dx16 rows {rows16[:12]} ({len(rows16)})',
                       flush=True)
-    print(f'rank {rank}: {bad} of {n_iter} calls differ (VF_LN_BWD_R1={os.environ.get("VF_LN_BWD_R1")})', flush=True)
+    print(f'rank {rank}: {bad} of {n_iter} calls differ (two rows in flight: {os.environ.get("VF_LN_BWD_TWO_ROWS", "1")})', flush=True)
 
 
 if __name__ == '__main__':

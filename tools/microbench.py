@@ -244,12 +244,13 @@ def attn(B=128, H=12, S=8, L=64, bf16=False, x6=False, fp8=False, twin=6, a16=Fa
         qkv = qkv.to(torch.bfloat16)
     out = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16 if a16 else torch.float32)
     if a16:
-        arm_dma = os.environ.get('VF_ATTN_DMA', '1') != '0'
+        from viewformer_amd import _lib as _vl
+        arm_dma = bool(_vl.load().vf_selected(_vl.SEL_ATTN_DMA))      # (VF_ATTN_DMA=0 in the environment is applied once, at load)
     ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
                                              3 * d, d, 1.0, True, twin, bf16=bf16, x6=x6, fp8=fp8), iters=20)
     pairs = S * (S + 1) // 2 if twin < 0 else (twin * (twin + 1) // 2 + (S - twin) * (twin + 1))
     useful = 4.0 * H * 64 * L * L * pairs * B
-    arm = 'fp8' if fp8 else 'bf16' + ('/v1' if os.environ.get('VF_ATTN_BF16_V1') == '1' else '') if bf16 else 'x6' if x6 else 'f32'
+    arm = 'fp8' if fp8 else 'bf16' if bf16 else 'x6' if x6 else 'f32'
     peak = 2500.0 if (bf16 or fp8) else 2500.0 / 6 if x6 else 157.3
     print(f'attn[{arm}{(",bf16 io, dma ring" if arm_dma else ",bf16 io") if a16 else ""}] B={B} H={H} T={T} twin={twin}: {ms * 1e3:.1f} us  {useful / ms / 1e9:.1f} TF useful = '
           f'{useful / ms / 1e9 / peak * 100:.1f} % of {peak:.0f}')

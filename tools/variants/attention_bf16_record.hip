@@ -1,3 +1,5 @@
+// RECORD, not part of libvf_hip.so since round 4: the FIRST bf16 attention kernel (round 1/2; 297 us at the bench shape against 253 us for attention_lp.hip and 117-131 us for attention_dma.hip) - was reachable through vf_attn_blockcausal_bf16 / VF_ATTN_BF16_V1=1.
+// Kept as the source the measurements in DESIGN.md refer to; builds against the round-3 C-ABI (git show 7e8c4c4:include/vf_hip.h).
 // bf16-MFMA sibling of attention_f32.hip for the reduced-precision (tolerance-bounded) transformer arm, gfx950.
 // Same semantics (un-scaled q.k^T, "w*m - 1e4*(1-m)" block mask incl. twin views and streams, softmax, .v), same
 // workgroup shape (128 queries sharing 64-key K/V tiles through LDS, masked tiles skipped wave-uniformly), same
@@ -9,7 +11,7 @@
 //     the B operand fixes the k-index -> key map to kappa(half, e) = 16*ks + 8*(e>>2) + 4*half + (e&3), and the A operand
 //     (V^T from LDS, [d][key] bf16, 136-byte rows) is read with the same map: two 8-byte reads per fragment.  No LDS
 //     round trip or permute for P.
-#include "vf_common.h"
+#include "../../viewformer_amd/csrc/vf_common.h"
 #include "../../include/vf_hip.h"
 
 namespace {

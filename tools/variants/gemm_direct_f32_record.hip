@@ -1,3 +1,5 @@
+// RECORD, not part of libvf_hip.so since round 4: the LDS-free "direct" f32 GEMM (A and B fragments L2 -> VGPR, no barrier): 118 TF asymptotic vs 123 TF for the LDS-staged igemm kernel, 97 vs 102 TF at K = 768 - was opt-in behind VF_ENABLE_DIRECT=1, with an MFMA-only calibration switch (VF_GEMM_NOLOAD=1, wrong results by construction).
+// Kept as the source the measurements in DESIGN.md refer to; builds against the round-3 C-ABI (git show 7e8c4c4:include/vf_hip.h).
 // Dense / 1x1-conv GEMM on exact-f32 MFMA with NO LDS and NO workgroup barrier (gfx950).
 //
 //   out[m][n] = epi( sum_k A[m][k] * W[k][n] + bias[n] ) + res[m][n]
@@ -14,8 +16,8 @@
 // Replaces Conv1D.call (migt.py:89-96) incl. gelu (:70) / residual (:233,237), SharedEmbeddings._linear
 // (:51-56), and the 1x1 convs of vqgan_th.py:72-76,114-118,332-333; igemm_f32.hip stays the fallback
 // (GroupNorm prologue, Cout % 128 != 0).
-#include "vf_common.h"
-#include "epilogue.h"
+#include "../../viewformer_amd/csrc/vf_common.h"
+#include "../../viewformer_amd/csrc/epilogue.h"
 #include "../../include/vf_hip.h"
 #include <stdlib.h>
 

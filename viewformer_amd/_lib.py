@@ -25,8 +25,15 @@ class VfIgemmArgs(ctypes.Structure):
         ('stride_x', c_int64), ('stride_w', c_int64), ('stride_out', c_int64), ('stride_res', c_int64),
         ('gn_part', c_void_p), ('gn_slots', c_int32), ('reserved0', c_int32),
         ('out_aux', c_void_p),
+        ('drop_rate', c_float), ('drop_seed', ctypes.c_uint32), ('drop_site', ctypes.c_uint32), ('drop_row0', c_int32),
     ]
 
+
+# kernel-selection switches (include/vf_hip.h: vf_select): each chooses between two kernels with bit-identical results
+SEL_ATTN_DMA, SEL_GEMM_G256, SEL_LN_BWD_TWO_ROWS = 0, 1, 2
+# developer convenience: these environment variables are translated into vf_select calls ONCE, when the library is loaded (the library
+# itself reads no environment variable)
+_ENV_SELECT = {'VF_ATTN_DMA': SEL_ATTN_DMA, 'VF_GEMM_G256': SEL_GEMM_G256, 'VF_LN_BWD_TWO_ROWS': SEL_LN_BWD_TWO_ROWS}
 
 PACK_DESC_BYTES = 40          # vf_pack_desc (ops.pack_bf16_multi builds the table as a numpy record array of this item size)
 P = c_void_p
@@ -38,6 +45,8 @@ EXPORTS = {
     'vf_build_arch': (c_char_p, []),
     'vf_build_flags': (c_int, []),
     'vf_build_flag_name': (c_char_p, [c_int]),
+    'vf_select': (c_int, [c_int, c_int]),
+    'vf_selected': (c_int, [c_int]),
     'vf_igemm_packed_floats': (c_size_t, [c_int, c_int, c_int]),
     'vf_igemm_pack_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int64, P]),
     'vf_igemm_f32': (c_int, [POINTER(VfIgemmArgs), P]),
@@ -81,22 +90,22 @@ EXPORTS = {
     'vf_codebook_gather_f32': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     'vf_attn_blockcausal_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, P]),
-    'vf_attn_blockcausal_bf16': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_bf16_v2': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_fp8': (c_int, [P, P, P, c_int, P, c_int] + [c_int] * 8 + [c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_x6': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_int, c_int, P]),
     'vf_attn_blockcausal_lse_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                            c_float, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
-    'vf_dropout_add_f32': (c_int, [P, P, P, c_int64, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
+                                            c_float, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P]),
+    'vf_dropout_add_f32': (c_int, [P, P, P, c_int64, c_int, c_int64, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_attn_bwd_prep_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_f32': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, P]),
+                                c_int, c_int, c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_gemm_tn_bf16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
-    'vf_attn_blockcausal_bf16_lse': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'vf_attn_blockcausal_bf16_lse': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                             c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_attn_bwd_prep_bf16': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_attn_bwd_bf16': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_float, c_int, P]),
+                                 c_float, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P]),
     'vf_attn_spatial_f32': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
     'vf_attn_spatial_x3h': (c_int, [P, P, c_int, c_int, c_int, c_int64, c_int64, c_float, P]),
     'vf_softmax_rows_f32': (c_int, [P, c_int64, c_int, c_float, P]),
@@ -136,7 +145,7 @@ EXPORTS = {
     'vf_colsum_workspace_bytes': (c_size_t, [c_int]),
     'vf_colsum_f32': (c_int, [P, P, c_int64, c_int, c_int64, c_int, P, P]),
     'vf_layernorm_bwd_workspace_bytes': (c_size_t, [c_int64, c_int]),
-    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, P, P]),
+    'vf_layernorm_bwd_f32': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, c_float, ctypes.c_uint32, ctypes.c_uint32, c_int64, P, P]),
     'vf_gelu_f32': (c_int, [P, P, c_int64, P]),
     'vf_gelu_bf16out_f32': (c_int, [P, P, c_int64, P]),
     'vf_gelu_bwd_bf16out_f32': (c_int, [P, P, P, c_int64, P]),
@@ -182,8 +191,19 @@ def load():
                       'viewformer_amd/_lib.py: rebuild the library or update the mirror')
     if int(lib.vf_sizeof_pack_desc()) != PACK_DESC_BYTES:
         raise VfError(f'vf_pack_desc is {int(lib.vf_sizeof_pack_desc())} bytes in {LIB_PATH}, {PACK_DESC_BYTES} expected')
+    for env, which in _ENV_SELECT.items():
+        if os.environ.get(env) in ('0', '1'):
+            lib.vf_select(which, int(os.environ[env]))
     _lib = lib
     return lib
+
+
+def select(which, value):
+    """vf_select: switch between two bit-identical kernels (A/B runs, parity tests); returns the previous value"""
+    prev = load().vf_select(int(which), 1 if value else 0)
+    if prev < 0:
+        raise VfError(f'vf_select({which}, {value}): bad argument')
+    return prev
 
 
 def check(status: int, what: str):

@@ -36,6 +36,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    stems = {os.path.basename(s)[:-4] for s in sources()}
+    for f in os.listdir(os.path.join(HERE, 'build')):              # objects of sources that have left csrc/ must not linger
+        if f.endswith('.o') and f[:-2] not in stems:
+            os.remove(os.path.join(HERE, 'build', f))
     for src in sources():
         obj = os.path.join(HERE, 'build', os.path.basename(src)[:-4] + '.o')
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
                                                              const float* __restrict__ lse, const float* __restrict__ Dv,
                                                              float* __restrict__ dq, int T, int L, int ldq, int ldk, int ldv,
                                                              int lddo, int lddq, float scale, int twin, uint32_t drop_thresh,
-                                                             float drop_scale, uint32_t drop_seed, uint32_t drop_site) {
+                                                             float drop_scale, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0) {
     __shared__ __attribute__((aligned(16))) float Ks[TT * LD];
     __shared__ __attribute__((aligned(16))) float Vs[TT * LD];
     __shared__ __attribute__((aligned(16))) float Kt[DH * LD];
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
     }
     const size_t stat = ((size_t)b * H + h) * T + (qvalid ? qrow : 0);
     const float lse_q = lse[stat], D_q = Dv[stat];
+    const uint32_t drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * H + h));               // mask plane = (global scene, head)
     const Vis visible = make_vis(twin);
     const int qview = (L > 0) ? qrow / L : 0;
     const bool uniform_views = L > 0 && (L % TT) == 0;
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
                 float dpr = dp[r];
                 if (drop_thresh) {                                         // d(dropped P)/dP = mask * scale
                     const int key = kt * TT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const uint64_t e = (((uint64_t)b * H + h) * T + qrow) * (uint64_t)T + key;
-                    dpr = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh ? dpr * drop_scale : 0.f;
+                    const uint32_t w = vf_dropout_word(drop_key, (uint32_t)qrow * (uint32_t)((T + 3) >> 2) + (uint32_t)(key >> 2));
+                    dpr = vf_dropout_keep(w, key & 3, drop_thresh) ? dpr * drop_scale : 0.f;
                 }
                 st[r] = p * (dpr - D_q) * scale;                           // dS^T (d/dS of the scaled score)
             }
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
                                                               float* __restrict__ dk, float* __restrict__ dv, int T, int L,
                                                               int ldq, int ldk, int ldv, int lddo, int lddk, int lddv,
                                                               float scale, int twin, uint32_t drop_thresh, float drop_scale,
-                                                              uint32_t drop_seed, uint32_t drop_site) {
+                                                              uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0) {
     extern __shared__ __attribute__((aligned(16))) float smem_a[];
     float* Qs = smem_a;                 // [TT][LD]   queries of the tile, row-major
     float* Os = Qs + TT * LD;           // [TT][LD]   dO rows
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 
     const int krow = k0 + wave * 32 + l31;              // this lane's key
     const bool kvalid = krow < T;
+    const uint32_t drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * H + h));               // mask plane = (global scene, head)
     float kreg[32], vreg[32];
     {
         const float* s0 = kb + (size_t)(kvalid ? krow : 0) * ldk + 4 * half;
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
                 const float p = __builtin_amdgcn_exp2f((sc - Ls[ql]) * LOG2E);
                 float pd = p, dpr = dp[r];
                 if (drop_thresh) {
-                    const uint64_t e = (((uint64_t)b * H + h) * T + (qt * TT + ql)) * (uint64_t)T + krow;
-                    const bool keep = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh;
+                    const uint32_t w = vf_dropout_word(drop_key, (uint32_t)(qt * TT + ql) * (uint32_t)((T + 3) >> 2) + (uint32_t)(krow >> 2));
+                    const bool keep = vf_dropout_keep(w, krow & 3, drop_thresh);
                     pd = keep ? p * drop_scale : 0.f;                      // the forward multiplied V by the dropped P
                     dpr = keep ? dpr * drop_scale : 0.f;
                 }
@@ -376,18 +378,18 @@ int vf_attn_bwd_prep_f32(const float* dout, const float* out, float* D, int B, i
 int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* D,
                     float* dq, float* dk, float* dv, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq,
                     int lddk, int lddv, float scale, int twin_view, float drop_rate, uint32_t drop_seed,
-                    uint32_t drop_site, void* stream) {
+                    uint32_t drop_site, uint32_t drop_plane0, void* stream) {
     if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     const int w = H * DH;
     if (ldq < w || ldk < w || ldv < w || lddo < w || lddq < w || lddk < w || lddv < w) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return VF_ERR_BAD_ARG;
     if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
-    const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
+    const uint32_t thresh = vf_dropout_thresh(drop_rate);
     const float dscale = 1.0f / (1.0f - drop_rate);
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, q, k, v, dout, lse, D, dq, T, L, ldq, ldk, ldv, lddo, lddq,
-                       scale, twin_view, thresh, dscale, drop_seed, drop_site);
+                       scale, twin_view, thresh, dscale, drop_seed, drop_site, drop_plane0);
     int st = vf_last_status();
     if (st) return st;
     const size_t smem = (size_t)(2 * TT * LD + 2 * DH * LD + 2 * TT) * sizeof(float);
@@ -399,7 +401,7 @@ int vf_attn_bwd_f32(const float* q, const float* k, const float* v, const float*
         vf_attr_done(&attr_devs);
     }
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), smem, s, q, k, v, dout, lse, D, dk, dv, T, L, ldq, ldk, ldv, lddo,
-                       lddk, lddv, scale, twin_view, thresh, dscale, drop_seed, drop_site);
+                       lddk, lddv, scale, twin_view, thresh, dscale, drop_seed, drop_site, drop_plane0);
     return vf_last_status();
 }
 

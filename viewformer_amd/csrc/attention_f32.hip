@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
                                                                   int T, int L, int ldq, int ldk, int ldv, int ldo,
                                                                   float scale, int skip_masked, int twin, float* __restrict__ lse,
                                                                   uint32_t drop_thresh, float drop_scale, uint32_t drop_seed,
-                                                                  uint32_t drop_site) {
+                                                                  uint32_t drop_site, uint32_t drop_plane0) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vt[DH * VT_LD];
 
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
     // ---- Q fragment: qreg[g*4+e] = Q[qrow][8g + 4*half + e] ---------------------------------
     const int qrow = q0 + wave * 32 + l31;
     const bool qvalid = qrow < T;
+    const uint32_t drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * gridDim.x + h));       // mask plane = (global scene, head)
     float qreg[32];
     {
         const float* src = qb + (size_t)(qvalid ? qrow : 0) * ldq + 4 * half;
@@ -203,9 +204,10 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
                 float p = __builtin_amdgcn_exp2f((st[t2][r] - m_new) * LOG2E);
                 psum += p;                                   // the softmax normaliser is over the undropped weights
                 if (drop_thresh) {                           // attn_dropout (branching_attention.py:15-17): applied to softmax(w)
+                    // mask group of (query, keys 4 g .. 4 g + 3): registers r & 3 = 0..3 of a lane are one group (vf_common.h)
                     const int key = kt * KT + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const uint64_t e = (((uint64_t)b * gridDim.x + h) * T + qrow) * (uint64_t)T + key;
-                    p = vf_dropout_hash(drop_seed, drop_site, e) >= drop_thresh ? p * drop_scale : 0.f;
+                    const uint32_t w = vf_dropout_word(drop_key, (uint32_t)qrow * (uint32_t)((T + 3) >> 2) + (uint32_t)(key >> 2));
+                    p = vf_dropout_keep(w, key & 3, drop_thresh) ? p * drop_scale : 0.f;
                 }
                 st[t2][r] = p;
             }
@@ -264,21 +266,21 @@ int vf_attn_blockcausal_f32(const float* q, const float* k, const float* v, floa
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr, 0u, 1.0f, 0u, 0u);
+                       ldv, ldo, scale, skip_masked, twin_view, (float*)nullptr, 0u, 1.0f, 0u, 0u, 0u);
     return vf_last_status();
 }
 
 int vf_attn_blockcausal_lse_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int T,
                                 int L, int ldq, int ldk, int ldv, int ldo, float scale, int skip_masked, int twin_view,
-                                float drop_rate, uint32_t drop_seed, uint32_t drop_site, void* stream) {
+                                float drop_rate, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, void* stream) {
     if (!q || !k || !v || !out || !lse || B <= 0 || H <= 0 || T <= 0 || L < 0) return VF_ERR_BAD_ARG;
     if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
-    const uint32_t thresh = (uint32_t)((double)drop_rate * 4294967296.0);
+    const uint32_t thresh = vf_dropout_thresh(drop_rate);
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || ldo < H * DH) return VF_ERR_BAD_ARG;
     if ((ldq | ldk | ldv | ldo) & 3) return VF_ERR_BAD_ARG;
     dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     hipLaunchKernelGGL(attn_blockcausal_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, L, ldq, ldk,
-                       ldv, ldo, scale, skip_masked, twin_view, lse, thresh, 1.0f / (1.0f - drop_rate), drop_seed, drop_site);
+                       ldv, ldo, scale, skip_masked, twin_view, lse, thresh, 1.0f / (1.0f - drop_rate), drop_seed, drop_site, drop_plane0);
     return vf_last_status();
 }
 

@@ -388,7 +388,8 @@ int launch_lp(const void* q, const void* k, const void* v, int in_bf16, void* ou
 }  // namespace
 
 int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int L, int ldq, int ldk, int ldv, int ldo,
-                       float scale, int twin_view, hipStream_t stream, float* lse_out = nullptr);        // attention_dma.hip: bf16 in / out, 64-token views, LDS-DMA ring
+                       float scale, int twin_view, hipStream_t stream, float* lse_out = nullptr, float drop_rate = 0.f, uint32_t drop_seed = 0,
+                       uint32_t drop_site = 0, uint32_t drop_plane0 = 0);        // attention_dma.hip: bf16 in / out, 64-token views, LDS-DMA ring
 
 extern "C" {
 
@@ -398,8 +399,7 @@ int vf_attn_blockcausal_bf16_v2(const void* q, const void* k, const void* v, int
         ldo >= H * DH) {
         // the DMA kernel always skips masked tiles (their weights are exactly 0.0f, so the result equals the dense form bit for bit); a caller
         // asking for skip_masked = 0 gets the dense register-staged kernel, so that A/B and parity runs measure what they ask for
-        const char* e = getenv("VF_ATTN_DMA");                       // VF_ATTN_DMA=0: keep the register-staged kernel (A/B runs, parity test)
-        if (!(e && e[0] == '0')) {
+        if (vf_selected(VF_SEL_ATTN_DMA)) {                          // (0: keep the register-staged kernel — A/B runs, the parity test)
             const int rc = vf_attn_dma_launch(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale, twin_view, (hipStream_t)stream);
             if (rc != VF_ERR_UNSUPPORTED) return rc;
         }

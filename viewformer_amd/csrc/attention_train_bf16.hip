@@ -16,9 +16,15 @@
 //   dKV kernel, per (wave = 32 keys, visible query tile):  S = Q.K^T, dP = dO.V^T, dV^T += dO^T.P, dK^T += Q^T.dS                        (32 MFMAs)
 // with P = exp(S scale - lse), D = rowsum(dO * O) (vf_attn_bwd_prep_bf16).  P and dS are rounded to bf16 as MFMA operands; sums, the
 // exponent and D stay fp32; dQ / dK / dV are written as fp32 rows (transposed through LDS, whole 256-byte rows).
-// 64-token views only (every (wave, tile) pair is entirely visible or entirely masked), T a multiple of 64, no attention dropout: the
-// trainer takes attention_bwd_f32.hip otherwise.  Reference: autograd of compute_attention / compute_causal_block_multiend_attention
+// 64-token views only (every (wave, tile) pair is entirely visible or entirely masked), T a multiple of 64: the trainer takes
+// attention_bwd_f32.hip otherwise.
+// DROP (round 4): attention dropout (branching_attention.py:15-17) — both kernels re-materialise the forward's mask (vf_common.h: one
+// hashed word per four consecutive keys of a query).  With keep in {0, 1} and c = 1 / (1 - rate):  dP gets keep * c before the D term,
+// dV accumulates keep * P and is scaled by c once at the end.  The dQ kernel's lanes hold four keys of a query per register group (one
+// hash per four elements); the dK / dV kernel's lanes hold four QUERIES of a key, i.e. four groups: one hash per element there.
+// Reference: autograd of compute_attention / compute_causal_block_multiend_attention
 // (viewformer/models/branching_attention.py:5-18,82-126) inside MIGT.train_step (migt.py:464-505) under mixed_float16.
+#include <type_traits>
 #include "vf_common.h"
 #include "../../include/vf_hip.h"
 
@@ -159,12 +165,13 @@ __device__ __forceinline__ void store_transposed_bf16(const f32x16 (&acc)[2], un
 // ---------------------------------------------------------------------------------------------------------------- dQ
 constexpr int DQ_SLOT = 3 * IMG, DQ_RING = 3, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
 
-template <bool O16>
+template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                   const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ Dv,
                                                                   void* __restrict__ dq, int H, int T, int ldq, int ldk, int ldv, int lddo,
-                                                                  int lddq, float scale, int twin) {
+                                                                  int lddq, float scale, int twin, uint32_t drop_thresh, float drop_scale,
+                                                                  uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -197,6 +204,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
     const size_t stat = ((size_t)b * H + h) * T + qrow;
     const float lse2 = lse[stat] * LOG2E, D_q = Dv[stat];
     const float c2 = scale * LOG2E;
+    // attention dropout: mask plane (scene, head), group q * (T / 4) + (key >> 2); this lane's keys of a tile are + 4 half + ...
+    uint32_t drop_key = 0u, drop_q = 0u;
+    if constexpr (DROP) {
+        drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * H + h));
+        drop_q = (uint32_t)qrow * (uint32_t)(T >> 2) + (uint32_t)half;
+    }
 
     // key tiles some wave of this workgroup (two query views) sees
     const int va = q0 / KT, vb2 = va + 1;
@@ -258,13 +271,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2)
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                uint32_t w[2] = {0u, 0u};                            // registers 8 ks2 + 0..3 / + 4..7: keys 64 kt + 32 t2 + 16 ks2 + 4 half + {0..3} / {8..11}
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) w[g] = vf_dropout_word(drop_key, drop_q + (uint32_t)(kt * 16 + t2 * 8 + ks2 * 4 + g * 2));
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = ks2 * 8 + e;
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t2][r], c2, -lse2));
-                    ds[t2][ks2][e] = (__bf16)(p * (dp[t2][r] - D_q) * scale);
+                    float dpr = dp[t2][r];
+                    if constexpr (DROP) dpr = vf_dropout_keep(w[e >> 2], e & 3, drop_thresh) ? dpr * drop_scale : 0.f;      // d(dropped P)/dP
+                    ds[t2][ks2][e] = (__bf16)(p * (dpr - D_q) * scale);
                 }
+            }
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -285,12 +306,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
 constexpr int KV_SLOT = 4 * IMG + 512, KV_RING = 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
 
-template <bool O16>
+template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                    const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dv,
                                                                    void* __restrict__ dk, void* __restrict__ dv, int H, int T, int ldq, int ldk,
-                                                                   int ldv, int lddo, int lddk, int lddv, float scale, int twin) {
+                                                                   int ldv, int lddo, int lddk, int lddv, float scale, int twin,
+                                                                   uint32_t drop_thresh, float drop_scale, uint32_t drop_seed, uint32_t drop_site,
+                                                                   uint32_t drop_plane0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -325,6 +348,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
         }
     }
     const float c2 = scale * LOG2E;
+    // attention dropout: this lane's key is element krow & 3 of group (krow >> 2) of every query's row of groups
+    uint32_t drop_key = 0u, drop_k = 0u;
+    const int drop_j = krow & 3;
+    if constexpr (DROP) {
+        drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * H + h));
+        drop_k = (uint32_t)(krow >> 2) + (uint32_t)(4 * half) * (uint32_t)(T >> 2);
+    }
 
     // query tiles that see a key view of this workgroup
     const int va = k0 / KT, vb2 = va + 1;
@@ -397,8 +427,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * j + e;
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e] * LOG2E));
-                    pf[r >> 3][r & 7] = (__bf16)p;
-                    sf[r >> 3][r & 7] = (__bf16)(p * (dp[r] - d4[e]) * scale);
+                    float dpr = dp[r];
+                    bool keep = true;
+                    if constexpr (DROP) {                            // accumulator row r = query 64 qt + 32 u + 8 j + e + 4 half
+                        const uint32_t w = vf_dropout_word(drop_key, drop_k + (uint32_t)(qt * 64 + 32 * u + 8 * j + e) * (uint32_t)(T >> 2));
+                        keep = vf_dropout_keep(w, drop_j, drop_thresh);
+                        dpr = keep ? dpr * drop_scale : 0.f;
+                    }
+                    pf[r >> 3][r & 7] = keep ? (__bf16)p : (__bf16)0.f;          // (its 1 / (1 - rate) joins dV at the end)
+                    sf[r >> 3][r & 7] = (__bf16)(p * (dpr - d4[e]) * scale);
                 }
             }
 #pragma unroll
@@ -417,6 +454,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     __builtin_amdgcn_s_barrier();
     if (!active) return;
     unsigned char* Os = smem + wave * 8192;
+    if constexpr (DROP) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dvacc[d][r] *= drop_scale;
+    }
     if constexpr (O16) {
         store_transposed_bf16(dkacc, Os, reinterpret_cast<__bf16*>(dk) + (b * (size_t)T + kw0) * lddk + h * DH, lddk, lane);
         store_transposed_bf16(dvacc, Os, reinterpret_cast<__bf16*>(dv) + (b * (size_t)T + kw0) * lddv + h * DH, lddv, lane);
@@ -441,39 +484,42 @@ int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, in
 
 int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, void* dq, void* dk,
                      void* dv, int out_bf16, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv,
-                     float scale, int twin_view, void* stream) {
+                     float scale, int twin_view, float drop_rate, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, void* stream) {
     if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
+    if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
     if (L != KT || T % KT != 0 || T / KT > 64) return VF_ERR_UNSUPPORTED;                     // 64-token views, at most 64 of them (tile bit masks)
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || lddo < H * DH || lddq < H * DH || lddk < H * DH || lddv < H * DH) return VF_ERR_BAD_ARG;
     if (((ldq | ldk | ldv | lddo) & 7) || ((lddq | lddk | lddv) & (out_bf16 ? 7 : 3))) return VF_ERR_BAD_ARG;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) return VF_ERR_UNSUPPORTED;
     const size_t ldmax = (size_t)(ldq > ldk ? ldq : ldk) > (size_t)(ldv > lddo ? ldv : lddo) ? (size_t)(ldq > ldk ? ldq : ldk) : (size_t)(ldv > lddo ? ldv : lddo);
     if ((size_t)T * ldmax * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;                     // 32-bit buffer offsets per (scene, head)
-    static unsigned long long attr_devs = 0;
-    if (vf_attr_needed(&attr_devs)) {
-        hipError_t e = hipSuccess;
-        for (const void* f : {reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<false>), reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<true>)})
-            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
-        for (const void* f : {reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<false>), reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<true>)})
-            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
-        if (e != hipSuccess) return (int)e;
-        vf_attr_done(&attr_devs);
-    }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
     const __bf16 *q_ = reinterpret_cast<const __bf16*>(q), *k_ = reinterpret_cast<const __bf16*>(k), *v_ = reinterpret_cast<const __bf16*>(v),
                  *do_ = reinterpret_cast<const __bf16*>(dout);
-    if (out_bf16) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<true>, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
-                                     ldv, lddo, lddq, scale, twin_view);
-    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<false>, grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk, ldv,
-                            lddo, lddq, scale, twin_view);
-    int st = vf_last_status();
-    if (st) return st;
-    if (out_bf16) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<true>, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
-                                     ldk, ldv, lddo, lddk, lddv, scale, twin_view);
-    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<false>, grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq, ldk,
-                            ldv, lddo, lddk, lddv, scale, twin_view);
-    return vf_last_status();
+    const uint32_t thr = vf_dropout_thresh(drop_rate);
+    const float dsc = 1.0f / (1.0f - drop_rate);
+    auto launch = [&](auto o16, auto drop) -> int {
+        constexpr bool O16 = decltype(o16)::value, DROP = decltype(drop)::value;
+        static unsigned long long attr_devs = 0;                   // (one flag per instantiation pair)
+        if (vf_attr_needed(&attr_devs)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<O16, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<O16, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(&attr_devs);
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
+                           ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
+        const int st = vf_last_status();
+        if (st) return st;
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
+                           ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
+        return vf_last_status();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (drop_rate > 0.f) return out_bf16 ? launch(T_{}, T_{}) : launch(F_{}, T_{});
+    return out_bf16 ? launch(T_{}, F_{}) : launch(F_{}, F_{});
 }
 
 }  // extern "C"

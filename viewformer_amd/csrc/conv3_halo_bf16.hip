@@ -297,6 +297,7 @@ int vf_conv3_halo_bf16(const vf_igemm_args* args, void* stream) {
     if (!args) return VF_ERR_BAD_ARG;
     const vf_igemm_args& a = *args;
     if (!a.x || !a.w_packed || !a.out || a.M <= 0) return VF_ERR_BAD_ARG;
+    if (a.drop_rate != 0.f || a.out_aux) return VF_ERR_UNSUPPORTED;      // fused output dropout / second output: vf_gemm_bf16 only
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
     const bool pair = a.mode == VF_MODE_CONV3_S1 && a.Hout == 8 && a.Wout == 8;     // two 8x8 images per tile
     if (a.Cout % BN != 0 || a.Cin % CK != 0 || (!pair && (a.Hout % TH != 0 || a.Wout % TW != 0))) return VF_ERR_UNSUPPORTED;

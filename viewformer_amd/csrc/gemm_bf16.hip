@@ -591,6 +591,10 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
         const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
         return rc;                                    // (VF_ERR_UNSUPPORTED for shapes that kernel does not tile: the caller runs the two passes)
     }
+    if (a.drop_rate != 0.f) {                         // fused output dropout: the 256-tile kernel's fp32 epilogue only
+        if (!(a.reserved0 & 1) || (a.reserved0 & 2) || a.batch > 1 || a.Cin % (2 * CK) != 0) return VF_ERR_UNSUPPORTED;
+        return vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);      // (VF_ERR_UNSUPPORTED for shapes it does not tile: GEMM, then vf_dropout_add_f32)
+    }
     const size_t smem = (size_t)2 * (A_BYTES + B_BYTES);
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
     if (vf_attr_needed(&attr_devs)) {
@@ -616,14 +620,13 @@ int vf_gemm_bf16(const vf_igemm_args* args, void* stream) {
         if (a.Cin % (2 * CK) != 0 || a.batch > 1) return VF_ERR_UNSUPPORTED;
         if ((a16 && (a.lda & 7)) || (o16 && a.res && a.epilogue != VF_EPI_GELU_BWD)) return VF_ERR_BAD_ARG;
         if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res && a.ldr >= a.Cout)) return VF_ERR_BAD_ARG;
-        // large token matrices with 256-aligned widths: the 256 x 256 LDS-DMA kernel (bit-identical results; VF_GEMM_G256=0 keeps
-        // the 128 x 128 kernel for A/B runs)
+        // large token matrices with 256-aligned widths: the 256 x 256 LDS-DMA kernel (bit-identical results; vf_select(VF_SEL_GEMM_G256, 0)
+        // keeps the 128 x 128 kernel for A/B runs)
         if (a.reserved0 & 4) {                                  // a bf16 pre-activation behind `res` (VF_EPI_GELU_BWD): the 256-tile kernel only
             if (a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;
             return vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
         }
-        const char* g256_env = getenv("VF_GEMM_G256");          // (read per call: the parity test flips it in-process)
-        if (!(g256_env && g256_env[0] == '0')) {
+        if (vf_selected(VF_SEL_GEMM_G256)) {                    // (0: the 128-tile kernel — the parity test flips it in-process)
             const int rc = vf_gemm_bf16_g256_launch(a, (hipStream_t)stream);
             if (rc != VF_ERR_UNSUPPORTED) return rc;
         }

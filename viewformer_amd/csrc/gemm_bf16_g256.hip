@@ -62,19 +62,25 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // fp32 output: bias, optional GELU, optional residual.  One code path with wave-uniform flags (eight template instantiations of the
 // unrolled 8-tile store made the compiler hoist every tile's addresses and spill 350 registers around the 128 accumulators); a tile is
 // still handled as ONE block of 16 back-to-back loads / stores (epilogue.h).
+template <bool DROP>
 __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
                                                int wave_n, int half, int l31, bool full, bool gelu) {
     const long long ldc = p.ldc, ldr = p.ldr;
     const bool has_res = p.res != nullptr;
     const bool dual = p.epilogue == VF_EPI_GELU_DUAL;
     const int odd = l31 & 1;
+    const uint32_t drop_thresh = vf_dropout_thresh(p.drop_rate), drop_key = vf_dropout_key(p.drop_seed, p.drop_site, 0u);
+    const float drop_scale = 1.0f / (1.0f - p.drop_rate);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+            int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+            // (DROP instantiation: the tile's row index passes through an opaque asm, so the eight tiles' addresses and mask words are
+            // formed tile by tile — hoisted together beside the 128 accumulators they cost 43 spilled registers)
+            if constexpr (DROP) asm volatile("" : "+v"(m0) :: "memory");
             const int rows_left = p.M - m0;
             float* o = p.out + (size_t)(rows_left > 0 ? m0 : 0) * ldc + n;
             float v[16];
@@ -83,6 +89,16 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
             if (gelu) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = vf_gelu_erf_fast(v[r]);
+            }
+            if constexpr (DROP) {      // (its own kernel instantiation: as a wave-uniform branch of the common epilogue it cost 47 spilled registers)
+                // residual / MLP dropout of the training step (migt.py:216,72) on the layer's output, before the residual joins: registers
+                // 4 g .. 4 g + 3 of a lane are rows m0 + 8 g .. + 3 of column n = ONE mask group (vf_common.h): one hash per four values
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t w = vf_dropout_word(drop_key, (uint32_t)(((m0 + p.drop_row0) >> 2) + 2 * g) * (uint32_t)p.Cout + (uint32_t)n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = vf_dropout_keep(w, e, drop_thresh) ? v[4 * g + e] * drop_scale : 0.f;
+                }
             }
             if (has_res) {
                 const float* rs = p.res + (size_t)(rows_left > 0 ? m0 : 0) * ldr + n;
@@ -223,7 +239,7 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
     }
 }
 
-template <bool O16>
+template <bool O16, bool DROP = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
 
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
             else g256_store_bf16<0, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
         }
     } else {
-        g256_store_f32(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
+        g256_store_f32<DROP>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
     }
 #ifdef G256_STAMPS
     {   // epilogue: [6] = bias / convert / store instructions issued, [7] = the stores drained (vmcnt 0)
@@ -426,6 +442,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #endif
 }
 
+#if G256_PERSIST
 // ---- persistent form: one workgroup per CU walks the tiles (tile = blockIdx.x + k * gridDim.x, same XCD / panel order) and issues the
 // NEXT tile's first stage before its epilogue: the DMA's flight (~3500 cycles, a whole stage-time for which a fresh workgroup sits idle)
 // passes under the bias / GELU / store work of the tile that just finished.  Buffer-resource DMA only; needs an even stage count (the
@@ -546,11 +563,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p
                 else g256_store_bf16<0, false>(p, acc, em, en, wave_m, wave_n, half, l31);
             }
         } else {
-            g256_store_f32(p, acc, em, en, wave_m, wave_n, half, l31, full, gelu);
+            g256_store_f32<false>(p, acc, em, en, wave_m, wave_n, half, l31, full, gelu);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+#endif  // G256_PERSIST
 
 }  // namespace
 
@@ -564,19 +583,24 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     if (a.epilogue == VF_EPI_GELU_DUAL && (a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (out fp32 or bf16)
     if ((a.reserved0 & 4) && a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;                             // (bit 2: a bf16 u for GELU_BWD)
     if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
+    // fused output dropout (drop_rate > 0): the fp32-output path with no epilogue function; mask group indices are 32-bit here
+    if (a.drop_rate != 0.f && (!(a.drop_rate > 0.f && a.drop_rate < 1.f) || o16 || a.epilogue != VF_EPI_NONE || a.drop_row0 < 0 || (a.drop_row0 & 3) ||
+                               (((unsigned long long)a.M + (unsigned long long)a.drop_row0 + 3) / 4) * (unsigned long long)a.Cout >= (1ull << 32)))
+        return VF_ERR_UNSUPPORTED;
     if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
     if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
         if (e != hipSuccess) return (int)e;
         vf_attr_done(&attr_devs);
     }
     const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
     const dim3 g((unsigned)(mt * nb));
-    // persistent form (G256_PERSIST): 256 workgroups (one per CU; a multiple of the 8 XCDs) walk the tiles; VF_GEMM_G256P=0 keeps one tile per workgroup
-    const char* pe = getenv("VF_GEMM_G256P");
-    if (G256_PERSIST && G256_BUFFER && !(pe && pe[0] == '0') && (a.Cin / GK) % 2 == 0 && mt * nb > G256_PERSIST) {
+#if G256_PERSIST
+    // persistent form (developer build -DG256_PERSIST=256): that many workgroups (one per CU; a multiple of the 8 XCDs) walk the tiles
+    if (G256_BUFFER && (a.Cin / GK) % 2 == 0 && mt * nb > G256_PERSIST && a.drop_rate == 0.f) {
         static unsigned long long attr_p_devs = 0;
         if (vf_attr_needed(&attr_p_devs)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
@@ -589,7 +613,9 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
         else hipLaunchKernelGGL((gemm_bf16_g256p_kernel<false>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);
         return vf_last_status();
     }
+#endif
     if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
+    else if (a.drop_rate > 0.f) hipLaunchKernelGGL((gemm_bf16_g256_kernel<false, true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
     else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
     return vf_last_status();
 }

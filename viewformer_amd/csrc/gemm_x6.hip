@@ -489,6 +489,7 @@ int vf_gemm_x6(const vf_igemm_args* args, void* stream) {
     if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
     if (a.epilogue != VF_EPI_NONE && a.epilogue != VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;      // (VF_EPI_GELU_BWD: vf_gemm_bf16 only)
     if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
+    if (a.drop_rate != 0.f || a.out_aux) return VF_ERR_UNSUPPORTED;      // fused output dropout / second output: vf_gemm_bf16 only
     if (a.mode != VF_MODE_GEMM || a.batch > 1) return VF_ERR_UNSUPPORTED;
     if (a.Cin % 64 != 0) return VF_ERR_UNSUPPORTED;  // two 32-deep chunks per pipeline round
     if (a.reserved0 > 1 && (a.bias || a.res || a.epilogue != VF_EPI_NONE || a.pro_mean || a.stride_out < (int64_t)a.M * a.ldc))

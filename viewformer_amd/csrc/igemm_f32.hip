@@ -21,7 +21,6 @@
 #include <stdlib.h>
 
 int vf_conv3_halo_try(const vf_igemm_args& a, hipStream_t stream, int* status);   // conv3_halo_f32.hip
-int vf_gemm_direct_try(const vf_igemm_args& a, hipStream_t stream, int* status);  // gemm_direct_f32.hip
 
 namespace {
 
@@ -312,7 +311,20 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 
 extern "C" {
 
-int vf_abi_version(void) { return 16; }
+int vf_abi_version(void) { return 17; }
+
+// ---- kernel selection (include/vf_hip.h): process-wide switches between kernels whose results the tests assert BIT-IDENTICAL.  The library
+// reads no environment variable (tests/test_abi.py checks that it does not even import the libc call); a host that wants an environment override
+// translates it into vf_select calls (viewformer_amd/_lib.py does, once, at load).
+static int g_vf_select[VF_SEL_COUNT] = {1, 1, 1};
+int vf_select(int which, int value) {
+    if (which < 0 || which >= VF_SEL_COUNT || (value != 0 && value != 1)) return VF_ERR_BAD_ARG;
+    return __atomic_exchange_n(&g_vf_select[which], value, __ATOMIC_RELAXED);
+}
+int vf_selected(int which) {
+    if (which < 0 || which >= VF_SEL_COUNT) return VF_ERR_BAD_ARG;
+    return __atomic_load_n(&g_vf_select[which], __ATOMIC_RELAXED);
+}
 // sizes of the structs that cross the boundary by pointer: a binding checks its mirror against them (a silent mismatch would be memory corruption)
 size_t vf_sizeof_igemm_args(void) { return sizeof(vf_igemm_args); }
 size_t vf_sizeof_pack_desc(void) { return sizeof(vf_pack_desc); }
@@ -338,6 +350,7 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
     if (!a.x || !a.w_packed || !a.out || a.M <= 0 || a.Cin <= 0 || a.Cout <= 0) return VF_ERR_BAD_ARG;
     if (a.epilogue != VF_EPI_NONE && a.epilogue != VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;      // (VF_EPI_GELU_BWD: vf_gemm_bf16 only)
     if (a.gn_part) return VF_ERR_UNSUPPORTED;        // fused GroupNorm statistics: halo-tile kernels only
+    if (a.drop_rate != 0.f || a.out_aux) return VF_ERR_UNSUPPORTED;      // fused output dropout / second output: vf_gemm_bf16 only
     if (a.Cin % CK != 0) return VF_ERR_UNSUPPORTED;
     if (a.mode < VF_MODE_GEMM || a.mode > VF_MODE_CONV3_UP2) return VF_ERR_BAD_ARG;
     if (a.mode != VF_MODE_GEMM) {
@@ -355,16 +368,9 @@ int vf_igemm_f32(const vf_igemm_args* args, void* stream) {
     if (pro && a.mode == VF_MODE_GEMM && a.pro_rows_per_img <= 0) return VF_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     {
-        // 3x3 stride-1 / upsample layers with wide channels go to the halo-tile kernel (conv3_halo_f32.hip);
-        // VF_DISABLE_HALO=1 keeps everything on this generic per-tap kernel (A/B timing, debugging).
-        static const bool halo_off = [] { const char* e = getenv("VF_DISABLE_HALO"); return e && e[0] == '1'; }();
+        // 3x3 stride-1 / upsample layers with wide channels go to the halo-tile kernel (conv3_halo_f32.hip)
         int st = 0;
-        if (!halo_off && vf_conv3_halo_try(a, s, &st) == 0) return st;
-        // A/B arm: the LDS-free streaming GEMM (gemm_direct_f32.hip).  Measured on MI355X it ties this
-        // LDS-staged kernel in the K loop (118 vs 123 TF asymptotic) and loses ~4 % end to end at K = 768
-        // (DESIGN.md §5), so it is opt-in: VF_ENABLE_DIRECT=1.
-        static const bool direct_on = [] { const char* e = getenv("VF_ENABLE_DIRECT"); return e && e[0] == '1'; }();
-        if (direct_on && vf_gemm_direct_try(a, s, &st) == 0) return st;
+        if (vf_conv3_halo_try(a, s, &st) == 0) return st;
     }
     const int BN = bn_for(a.Cout);
     if (BN == 128) {

@@ -103,7 +103,8 @@ template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgb_part, long long rows, int d, float eps,
-                                                            int rows_per_block, const float* __restrict__ res, __bf16* __restrict__ dx16) {
+                                                            int rows_per_block, const float* __restrict__ res, __bf16* __restrict__ dx16,
+                                                            uint32_t drop_thresh, float drop_scale, uint32_t drop_key, long long drop_row0) {
     // each wave walks rows_per_block/4 rows and keeps per-lane dgamma/dbeta partials in registers
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int c = lane + 64 * i;
+                xv[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};             // (slots beyond the row stay defined: nothing reads them, but no register
+                dyv[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};            // of this kernel holds an undefined value)
                 if (c < nv) {
                     xv[q][i] = *reinterpret_cast<const f32x4*>(x + row[q] * d + c * 4);
                     dyv[q][i] = *reinterpret_cast<const f32x4*>(dy + row[q] * d + c * 4);
@@ -202,6 +205,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     if (dx16) {                                     // a bf16 copy for the GEMMs that take this gradient as an operand
                         typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
                         bf16x4_t h;
+                        if (drop_thresh) {
+                            // the copy's consumer is the backward of a layer whose OUTPUT went through dropout (resid_dropout / the MLP's,
+                            // migt.py:216,72): its dY is this gradient under the forward's mask — element (row, col) of mask group
+                            // (row >> 2) * d + col, position row & 3 (vf_common.h; the fp32 dx, the residual path's gradient, stays unmasked)
+                            const uint32_t g0 = (uint32_t)((row[q] + drop_row0) >> 2) * (uint32_t)d + (uint32_t)(c * 4);
+                            const int j = (int)((row[q] + drop_row0) & 3);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = vf_dropout_keep(vf_dropout_word(drop_key, g0 + e), j, drop_thresh) ? o[e] * drop_scale : 0.f;
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
                         *reinterpret_cast<bf16x4_t*>(dx16 + row[q] * d + c * 4) = h;
@@ -538,11 +550,40 @@ __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict
 }
 
 // ------------------------------------------------------------------ dropout: out = x * keep / (1 - rate) [+ res]
+// x [rows][cols] row-major; element (m, n) belongs to mask group (m >> 2) * cols + n at position m & 3 (vf_common.h)
 __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
-                                   long long n, uint32_t thresh, float scale, uint32_t seed, uint32_t site) {
+                                   long long rows, int cols, long long row0, uint32_t thresh, float scale, uint32_t seed, uint32_t site) {
+    const long long n = rows * cols;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = vf_dropout_hash(seed, site, (uint64_t)i) >= thresh ? x[i] * scale : 0.f;
+        const long long m = i / cols;
+        const uint32_t c = (uint32_t)(i - m * cols);
+        const float v = vf_dropout_keep_elem(seed, site, (uint64_t)(m + row0), c, (uint32_t)cols, thresh) ? x[i] * scale : 0.f;
         out[i] = res ? v + res[i] : v;
+    }
+}
+// cols % 4 == 0, 16-byte aligned pointers: one float4 per thread (four columns of one row: four mask groups)
+__global__ void dropout_add4_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                    long long rows, int cols, long long row0, uint32_t thresh, float scale, uint32_t seed, uint32_t site) {
+    const int c4 = cols >> 2;
+    const long long n4 = rows * c4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / c4;
+        const uint32_t c = (uint32_t)(i - m * c4) * 4u;
+        const uint64_t g = ((uint64_t)(m + row0) >> 2) * (uint64_t)cols + c;
+        const int j = (int)((m + row0) & 3);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint64_t ge = g + e;
+            const uint32_t w = vf_dropout_word(vf_dropout_key(seed, site, (uint32_t)(ge >> 32)), (uint32_t)ge);
+            v[e] = vf_dropout_keep(w, j, thresh) ? v[e] * scale : 0.f;
+        }
+        if (res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(res + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = v;
     }
 }
 
@@ -636,23 +677,27 @@ size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
 }
 
 int vf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                         int64_t rows, int d, float eps, int accumulate, const float* res, void* dx_bf16, void* ws, void* stream) {
+                         int64_t rows, int d, float eps, int accumulate, const float* res, void* dx_bf16, float drop_rate, uint32_t drop_seed,
+                         uint32_t drop_site, int64_t drop_row0, void* ws, void* stream) {
     if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !ws || rows <= 0 || d <= 0) return VF_ERR_BAD_ARG;
     if ((d & 3) || d > 1024) return VF_ERR_UNSUPPORTED;
+    if (!(drop_rate >= 0.f && drop_rate < 1.f) || (drop_rate > 0.f && !dx_bf16) || drop_row0 < 0) return VF_ERR_BAD_ARG;
+    if (drop_rate > 0.f && (unsigned long long)((rows + drop_row0 + 3) / 4) * (unsigned long long)d >= (1ull << 32)) return VF_ERR_UNSUPPORTED;   // 32-bit mask groups
+    const uint32_t dthr = vf_dropout_thresh(drop_rate), dkey = vf_dropout_key(drop_seed, drop_site, 0u);
+    const float dscale = 1.0f / (1.0f - drop_rate);
     const int rpb = LN_BWD_RPB;
     const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
     __bf16* d16 = reinterpret_cast<__bf16*>(dx_bf16);
-    // Two rows of a wave in flight (62 us against 68-70 for one row at the training shape; VF_LN_BWD_R1=1 selects the one-row form, same bits).
+    // Two rows of a wave in flight (62 us against 68-70 for one row at the training shape; vf_select(VF_SEL_LN_BWD_TWO_ROWS, 0) selects the one-row form, same bits).
     // History of this switch (round 3): with the wave sums on ds_bpermute (vf_wave_sum) the two-row form was bit-identical in a process that
     // owns the GPU but NOT bit-reproducible when a second process shared the device — the 2-rank gloo test on one GPU failed every other
     // run; tools/flaky_probe2.py traced it to ~1 call in 75 returning a few rows of dx ~1e-4 off on identical inputs (0 of 6 000 calls with
     // the one-row form).  With the sums on DPP adds (vf_wave_sum_dpp) both forms are reproducible there (0 of 5 000 calls): two interleaved
     // ds_bpermute chains do not survive the context switches of a shared GPU; nothing else in the library interleaves them.
-    const char* r1 = getenv("VF_LN_BWD_R1");
-    const bool one = r1 && r1[0] == '1';
+    const bool one = !vf_selected(VF_SEL_LN_BWD_TWO_ROWS);
 #define VF_LN_BWD_LAUNCH(MV, RR) hipLaunchKernelGGL((layernorm_bwd_kernel<MV, RR>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, (float*)ws, \
-                                                    (long long)rows, d, eps, rpb, res, d16)
+                                                    (long long)rows, d, eps, rpb, res, d16, dthr, dscale, dkey, (long long)drop_row0)
     if (d <= 256) { if (one) VF_LN_BWD_LAUNCH(1, 1); else VF_LN_BWD_LAUNCH(1, 2); }
     else if (d <= 512) { if (one) VF_LN_BWD_LAUNCH(2, 1); else VF_LN_BWD_LAUNCH(2, 2); }
     else if (d <= 768) { if (one) VF_LN_BWD_LAUNCH(3, 1); else VF_LN_BWD_LAUNCH(3, 2); }      // (d_model 768: three float4 per lane exactly)
@@ -781,13 +826,19 @@ int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream) {
     return vf_last_status();
 }
 
-int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t n, float rate, uint32_t seed, uint32_t site,
-                       void* stream) {
-    if (!x || !out || n < 0 || !(rate >= 0.f && rate < 1.f)) return VF_ERR_BAD_ARG;
-    if (n == 0) return VF_OK;
-    const uint32_t thresh = (uint32_t)((double)rate * 4294967296.0);
-    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, res, out, (long long)n,
-                       thresh, 1.0f / (1.0f - rate), seed, site);
+int vf_dropout_add_f32(const float* x, const float* res, float* out, int64_t rows, int cols, int64_t row0, float rate, uint32_t seed,
+                       uint32_t site, void* stream) {
+    if (!x || !out || rows < 0 || cols <= 0 || row0 < 0 || !(rate >= 0.f && rate < 1.f)) return VF_ERR_BAD_ARG;
+    if (rows == 0) return VF_OK;
+    const uint32_t thresh = vf_dropout_thresh(rate);
+    const float scale = 1.0f / (1.0f - rate);
+    const long long n = (long long)rows * cols;
+    if ((cols & 3) == 0 && !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15))
+        hipLaunchKernelGGL(dropout_add4_kernel, dim3(grid1(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, res, out, (long long)rows, cols,
+                           (long long)row0, thresh, scale, seed, site);
+    else
+        hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, res, out, (long long)rows, cols,
+                           (long long)row0, thresh, scale, seed, site);
     return vf_last_status();
 }
 

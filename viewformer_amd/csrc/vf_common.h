@@ -134,9 +134,11 @@ __device__ __forceinline__ void vf_block_max_atomic(float m, unsigned* out) {
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(vf_bm_red[0], vf_bm_red[1]), fmaxf(vf_bm_red[2], vf_bm_red[3]))));
 }
 
-// Counter-based dropout mask (training step): keep element `idx` of dropout site `site` iff hash >= thresh, where
-// thresh = floor(rate * 2^32).  A pure function of (seed, site, idx): the forward and backward passes recompute the same mask
-// and nothing is stored; oracle/train_oracle.py restates it in numpy for the tests.
+// Counter-based dropout masks (training step): pure functions of (seed, site, element), so that the forward and backward passes recompute
+// the same mask and nothing is stored; viewformer_amd/_hash.py and oracle/train_oracle.py restate them in numpy for the tests.
+//
+// vf_dropout_hash: the strong (3-multiply) 32-bit mix of (seed, site, 64-bit index) — host-side per-scene draws (random pose multiplier)
+// and the per-plane KEY of the mask words below.
 __host__ __device__ __forceinline__ uint32_t vf_dropout_hash(uint32_t seed, uint32_t site, uint64_t idx) {
     uint32_t h = seed ^ (site * 0x9E3779B9u);
     h ^= (uint32_t)idx;
@@ -150,6 +152,38 @@ __host__ __device__ __forceinline__ uint32_t vf_dropout_hash(uint32_t seed, uint
     h ^= h >> 16;
     return h;
 }
+// The masks themselves (round 4).  Elements come in GROUPS of four that share one 32-bit word:
+//     word(g) = lowbias32(lo32(g) ^ key),  key = vf_dropout_hash(seed, site, hi32(g))           g = 64-bit group index
+//     keep(element j of group g) = rotl32(word, 8 j) >= thresh,  thresh = floor(rate * 2^32)
+// A rotation of a uniform word is uniform, so every element is kept with probability exactly 1 - thresh / 2^32; the four decisions of a
+// group are decided by four different bytes of the word except in the 2^-8 boundary band (tests/test_host_logic.py checks rates, pair
+// correlations and the joint distribution of a group).  One hash (two v_mul_lo_u32, 8 VALU cycles each) serves the four elements a
+// lane holds: per element that is a rotate, a compare and a select.  Group index / position of an element:
+//     [M][N] activations (embedding, residual, MLP sites):  g = (m >> 2) * N + n,  j = m & 3   — four consecutive ROWS of a column, which
+//         is what a lane of a GEMM epilogue holds (accumulator rows (r & 3) + 8 (r >> 2) + 4 half of column lane & 31);
+//     attention weights (b, h, q, k), T tokens:  g = ((b H + h) << 32) | (q * ceil(T / 4) + (k >> 2)),  j = k & 3   — four consecutive
+//         KEYS of a query: what a lane of the S^T = K.Q^T accumulator holds (forward and dQ kernels; the dK / dV kernel's lanes hold four
+//         queries of a key and pay one hash per element).
+__host__ __device__ __forceinline__ uint32_t vf_lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t vf_dropout_key(uint32_t seed, uint32_t site, uint32_t hi) { return vf_dropout_hash(seed, site, (uint64_t)hi); }
+__host__ __device__ __forceinline__ uint32_t vf_dropout_word(uint32_t key, uint32_t lo) { return vf_lowbias32(lo ^ key); }
+__host__ __device__ __forceinline__ bool vf_dropout_keep(uint32_t word, int j, uint32_t thresh) {
+    const uint32_t s = 8u * ((uint32_t)j & 3u);
+    return ((word << s) | (word >> ((32u - s) & 31u))) >= thresh;
+}
+// one element of an [M][N] activation (generic, 64-bit safe; kernels that hold a whole group hash once and call vf_dropout_keep four times)
+__host__ __device__ __forceinline__ bool vf_dropout_keep_elem(uint32_t seed, uint32_t site, uint64_t m, uint32_t n, uint32_t N, uint32_t thresh) {
+    const uint64_t g = (m >> 2) * (uint64_t)N + n;
+    return vf_dropout_keep(vf_dropout_word(vf_dropout_key(seed, site, (uint32_t)(g >> 32)), (uint32_t)g), (int)(m & 3), thresh);
+}
+__host__ __device__ __forceinline__ uint32_t vf_dropout_thresh(float rate) { return (uint32_t)((double)rate * 4294967296.0); }
 
 // XCD-aware workgroup order.  The dispatcher hands consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2, so
 // the workgroups that share an operand tile (the column blocks of one GEMM row tile, the output-channel blocks and halo
@@ -208,6 +242,9 @@ VF_REG_FLAG(G256_A_VIA_REGS)
 #endif
 #ifdef G256_STAMPS
 VF_REG_FLAG(G256_STAMPS)
+#endif
+#if defined(G256_PERSIST) && G256_PERSIST
+VF_REG_FLAG(G256_PERSIST)
 #endif
 #ifdef VQF_STAMPS
 VF_REG_FLAG(VQF_STAMPS)

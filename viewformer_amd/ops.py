@@ -240,7 +240,23 @@ def gemm_bf16_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulat
 
 
 def gemm_tn_bf16_supported(x, M, K, N):
-    return x.dtype == torch.bfloat16 and K % 256 == 0 and N % 256 == 0 and M % 64 == 0 and M * K * 2 < 2 ** 31
+    return x.dtype == torch.bfloat16 and gemm_tn_bf16_shape_ok(M, K, N)
+
+
+def gemm_tn_bf16_shape_ok(M, K, N):
+    """shapes vf_gemm_tn_bf16 takes (csrc/gemm_tn_bf16.hip): 256-wide tiles of dW, 64-row chunks, 32-bit offsets into x"""
+    return K % 256 == 0 and N % 256 == 0 and M % 64 == 0 and M * K * 2 < 2 ** 31
+
+
+def gemm_g256_shape_ok(M, K, N):
+    """shapes the 256-tile LDS-DMA bf16 GEMM takes (csrc/gemm_bf16_g256.hip: vf_gemm_bf16_g256_launch) — the only kernel behind the fused
+    epilogues EPI_GELU_DUAL, EPI_GELU_BWD with a bf16 pre-activation, and the fused output dropout"""
+    return N % 256 == 0 and K % 64 == 0 and M >= 256 and M * K * 2 < 2 ** 31 and K * N * 2 < 2 ** 31
+
+
+def gemm_drop_supported(M, K, N, row0=0):
+    """the fused output dropout of vf_gemm_bf16 (igemm(drop=...)): 256-tile shapes, 32-bit mask group indices"""
+    return gemm_g256_shape_ok(M, K, N) and row0 % 4 == 0 and ((M + row0 + 3) // 4) * N < 2 ** 32
 
 
 def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
@@ -271,7 +287,7 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
-          x3h=False, a16=False, o16=False, out_aux=None, res16=False):
+          x3h=False, a16=False, o16=False, out_aux=None, res16=False, drop=None):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
@@ -279,7 +295,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     ``gn_part``: fp32 [Nimg][halo_gn_slots(Hout, Wout)][32][2] buffer that receives the GroupNorm partial statistics of the
     output (halo kernels only; reduce with groupnorm_finalize).
     ``out_aux`` (with ``epilogue=EPI_GELU_DUAL``, bf16 arm, bf16 x, fp32 or bf16 out): bf16 [M][ldc] that receives gelu(out).
-    ``res16`` (with ``epilogue=EPI_GELU_BWD``): the pre-activation behind ``res`` was saved as bf16."""
+    ``res16`` (with ``epilogue=EPI_GELU_BWD``): the pre-activation behind ``res`` was saved as bf16.
+    ``drop`` = (rate, seed, site), bf16 arm with bf16 x and fp32 out only: the training step's output dropout in the epilogue, before the
+    residual joins (vf_igemm_args.drop_rate; the masks of train_ops.dropout_add with cols = Cout).  Shapes outside the 256-tile kernel
+    raise 'unsupported' (callers run the GEMM, then dropout_add)."""
     lib = _lib.load()
     if not 0 <= M < 2 ** 31 or max(Cin, Cout, Hin, Win, Hout, Wout, batch) >= 2 ** 31:
         # vf_igemm_args carries 32-bit row / channel counts (byte offsets inside the kernels are 64-bit): refuse instead of wrapping
@@ -319,6 +338,11 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
         _chk(x, torch.bfloat16 if a16 else torch.float32, 'x')
         _chk(out, torch.bfloat16 if o16 else torch.float32, 'out')
         a.reserved0 = (1 if a16 else 0) | (2 if o16 else 0)
+    if drop is not None and drop[0]:
+        if not (bf16 and a16 and not o16 and mode == MODE_GEMM and epilogue == EPI_NONE):
+            raise _lib.VfError('drop needs the bf16 GEMM with bf16 x, fp32 out and no epilogue function')
+        a.drop_rate, a.drop_seed, a.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
+        a.drop_row0 = int(drop[3]) if len(drop) > 3 else 0          # first row's index in the global batch (data-parallel step)
     if res16:
         if not (a16 and o16 and epilogue == EPI_GELU_BWD and res is not None):
             raise _lib.VfError('res16 is the bf16 pre-activation of EPI_GELU_BWD (bf16 in, bf16 out)')
@@ -511,8 +535,8 @@ def codebook_gather(E, idx, D, Kc):
 # ------------------------------------------------------------------ attention / transformer glue
 def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, skip_masked=True, twin_view=-1, bf16=False, x6=False,
                      fp8=False):
-    """``bf16`` / ``fp8``: the tolerance arms (bf16 or OCP e4m3 operands, fp32 softmax; csrc/attention_lp.hip — VF_ATTN_BF16_V1=1
-    selects the first bf16 kernel, csrc/attention_bf16.hip, for A/B); ``x6``: fp32-equivalent; default: native f32 MFMA."""
+    """``bf16`` / ``fp8``: the tolerance arms (bf16 or OCP e4m3 operands, fp32 softmax; csrc/attention_lp.hip, and for bf16 tensors with
+    64-token views the LDS-DMA kernel of csrc/attention_dma.hip); ``x6``: fp32-equivalent; default: native f32 MFMA."""
     lib = _lib.load()
     if fp8:
         bf16 = True
@@ -526,8 +550,7 @@ def attn_blockcausal(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, sk
         i16 = q.dtype == torch.bfloat16            # bf16 q/k/v: the fused c_attn output written by its GEMM with o16=True
         for t in (q, k, v):
             _chk(t, torch.bfloat16 if i16 else torch.float32, 'q/k/v')
-        fn = (lib.vf_attn_blockcausal_fp8 if fp8 else lib.vf_attn_blockcausal_bf16 if os.environ.get('VF_ATTN_BF16_V1') == '1'
-              else lib.vf_attn_blockcausal_bf16_v2)
+        fn = lib.vf_attn_blockcausal_fp8 if fp8 else lib.vf_attn_blockcausal_bf16_v2
         check(fn(_p(q), _p(k), _p(v), 1 if i16 else 0, _p(out if o16 else _f32(out)), 1 if o16 else 0, B, H, T, L,
                  ldq, ldk, ldv, ldo, scale, 1 if skip_masked else 0, twin_view, _stream()), 'vf_attn_blockcausal_lp')
         return out

@@ -18,7 +18,10 @@ is done (overlapping the remaining backward).
 Dropout (config.dropout, default 0.1 in the reference: migt.py:72,216,403 and attn_dropout branching_attention.py:15-17) uses a
 counter-based mask — keep = hash(seed, site, element index) >= rate * 2^32 (csrc/vf_common.h) — that the backward pass recomputes;
 ``dropout_seed`` and the step counter give the per-step seed.  The masks cannot coincide with TensorFlow's RNG stream; the tests
-check the kernels against autograd with the SAME masks restated in numpy (oracle/train_oracle.py).
+check the kernels against autograd with the SAME masks restated in numpy (oracle/train_oracle.py).  In the bf16 arm (the timed one: the
+reference trains with --fp16) no dropout site is a pass of its own except the embedding's: the residual / MLP masks are applied by the
+epilogue of the projection GEMM (igemm(drop=...)), their backward by the LayerNorm backward that writes the bf16 gradient operand
+(layernorm_bwd(drop=...)), the attention's inside the flash forward / backward kernels.
 
 ``random_pose_multiplier`` (migt.py:350-354,160-161): each scene's positions are scaled by rpm ** u, u ~ U(-1, 1), on the way in
 and the predicted position is divided by the same factor before the loss; u comes from the same counter hash as the dropout masks
@@ -214,6 +217,21 @@ class MIGTTrainer:
     def _linear(self, x, name, M, res=None):
         return self.model._gemm(x, name, M, res=res)
 
+    fuse_dropout = True               # bf16 arm: residual / MLP dropout in the projection GEMM's epilogue and in the LayerNorm backward's bf16 copy
+                                      # (False: the separate dropout_add passes; the same masks, the same values up to the GEMM's own rounding)
+
+    def _proj_dropout(self, x, name, M, res, drop):
+        """res + dropout(x @ W + b)  (attn.c_proj -> resid_dropout, migt.py:216; mlp.c_proj -> the MLP's dropout, :72)"""
+        dn = self.model._dense[name]
+        if not drop[0]:
+            return self._linear(x, name, M, res=res)
+        if (self.fuse_dropout and dn.wp16 is not None and x.dtype == torch.bfloat16 and ops.gemm_drop_supported(M, dn.k, dn.n, drop[3])):
+            out = torch.empty((M, dn.n), dtype=torch.float32, device=x.device)
+            ops.igemm(x, dn.wp16, M, dn.k, dn.n, out, bias=dn.bias, res=res, bf16=True, a16=True, drop=drop)
+            return out
+        y = self._linear(x, name, M)
+        return T.dropout_add(y, drop[0], drop[1], drop[2], res=res, out=y, row0=drop[3])
+
     def _linear_bwd(self, name, x, dy, M, need_dx=True, res=None, dx_bf16=False, gelu_bwd_u=None):
         """grads of y = x @ W + b given dy [M,N]; returns dx (+res) or None.  ``x`` may be a saved bf16 activation (bf16 arm);
         ``dx_bf16``: the bf16 arm's dX GEMM writes bf16 (the attention backward's dO operand)."""
@@ -286,9 +304,10 @@ class MIGTTrainer:
             ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
-    def _ln_bwd(self, name, dy, x, M, res=None, also_bf16=False):
+    def _ln_bwd(self, name, dy, x, M, res=None, also_bf16=False, drop=(0.0, 0, 0)):
         d = self.cfg.d_model
-        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res, also_bf16=also_bf16)
+        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res, also_bf16=also_bf16,
+                               drop=drop if also_bf16 else (0.0, 0, 0))
 
     bf16_preactivation = True         # bf16 arm, with both GELU fusions: c_fc's pre-activation u is SAVED as bf16 (the reference's mixed_float16 policy
                                       # keeps every activation in half precision); gelu(u) is still taken from the fp32 accumulator, gelu'(u)
@@ -318,10 +337,20 @@ class MIGTTrainer:
     _nodecay = None
     attention_backward = 'flash'      # 'dense': the first version (P materialised per head with batched GEMMs), kept for A/B
 
-    def random_pose_factors(self, B, seed):
-        """rpm ** u_b, u_b = 2 * hash(seed, SITE_POSE_MULT, b) / 2^32 - 1 (migt.py:351; counter-based like the dropout masks)"""
+    scene_offset = None               # index of this rank's first scene in the GLOBAL batch of a data-parallel step (None: rank * local batch).
+                                      # Every random draw of the step — the dropout masks, the random pose multiplier — is a function of
+                                      # the GLOBAL scene index, so N ranks draw exactly what one process draws on the concatenated batch,
+                                      # and no two replicas share a mask (with one seed per step and local indices they all would)
+
+    def _scene_offset(self, B):
+        if self.scene_offset is not None:
+            return int(self.scene_offset)
+        return (dist.get_rank(self.group) * B) if self._world() > 1 else 0
+
+    def random_pose_factors(self, B, seed, b0=0):
+        """rpm ** u_b, u_b = 2 * hash(seed, SITE_POSE_MULT, b0 + b) / 2^32 - 1 (migt.py:351; counter-based like the dropout masks)"""
         from ._hash import dropout_hash
-        u = dropout_hash(seed, SITE_POSE_MULT, np.arange(B, dtype=np.uint64)).astype(np.float64) / 2.0 ** 32 * 2.0 - 1.0
+        u = dropout_hash(seed, SITE_POSE_MULT, np.arange(b0, b0 + B, dtype=np.uint64)).astype(np.float64) / 2.0 ** 32 * 2.0 - 1.0
         return torch.from_numpy((float(self.cfg.random_pose_multiplier) ** u).astype(np.float32))
 
     def step_seed(self, step):
@@ -402,7 +431,7 @@ class MIGTTrainer:
         rmul = None
         pin = geometry.pose_model_input(poses, c.pose_multiplier)
         if c.random_pose_multiplier != 1 and not _forward_only:                      # migt.py:350-354: rpm ** U(-1, 1) per scene (training only)
-            rmul = self.random_pose_factors(B, seed).to(dev)
+            rmul = self.random_pose_factors(B, seed, self._scene_offset(B)).to(dev)
             pin = torch.cat([pin[..., :3] * rmul.view(B, 1, 1), pin[..., 3:]], -1)
         pin = pin.reshape(B * S, 7).contiguous()
         fc = m._dense['pose_embedding.c_fc']
@@ -419,14 +448,18 @@ class MIGTTrainer:
         add = torch.cat(add_streams, 1).contiguous().view(B * V, d)
         h = ops.embed_sum(ids32, m._wte, m._wpe, add, B * V, L, d, nE + 2)
         rate = 0.0 if _forward_only else float(c.dropout)                            # Dropout layers are inert with training=False
+        b0 = self._scene_offset(B) if rate else 0
+        row0, plane0 = b0 * V * L, b0 * H                                            # this rank's first row / first attention plane in the global batch
         if rate:
-            T.dropout_add(h, rate, seed, SITE_EMBED, out=h)                          # self.drop, migt.py:403
+            T.dropout_add(h, rate, seed, SITE_EMBED, out=h, row0=row0)               # self.drop, migt.py:403
         saved = []
         # attention of the bf16 arm on the bf16 matrix pipe (csrc/attention_dma.hip + attention_train_bf16.hip) where its kernels apply:
-        # 64-token views, no attention dropout, the wide c_attn / c_proj layers on their bf16 packings; otherwise the exact-f32 kernels
+        # 64-token views, the wide c_attn / c_proj layers on their bf16 packings; otherwise the exact-f32 kernels.  Attention dropout is
+        # inside both sets of kernels (the same masks)
         ca, cp = m._dense['h.0.attn.c_attn'], m._dense['h.0.attn.c_proj']
-        attn16 = (self.attention_arith == 'bf16' and m.precision == 'bf16' and rate == 0.0 and T.attn_bf16_supported(Tn, L)
-                  and d // H == 64 and ca.wp16 is not None and cp.wp16 is not None and M % 128 == 0)
+        attn16 = (self.attention_arith == 'bf16' and m.precision == 'bf16' and T.attn_bf16_supported(Tn, L)
+                  and d // H == 64 and ca.wp16 is not None and cp.wp16 is not None and M % 128 == 0
+                  and (rate == 0.0 or Tn * (Tn // 4) < 2 ** 32))
         # bf16 arm, wide layers: the activations only GEMMs read — both LayerNorm outputs, the attention output, the MLP hidden — are
         # SAVED AS bf16 by their producers (the rounding the GEMM applied on load before: identical products), so the forward GEMMs take
         # the 256-tile LDS-DMA kernel (bf16 A operand) and the saved activations halve; the backward reads them through the widening
@@ -434,9 +467,18 @@ class MIGTTrainer:
         # ... and the two gradients only GEMMs read — d(MLP pre-activation) from the GELU backward, d(q | k | v) from the attention backward —
         # are WRITTEN as bf16 by those kernels (again the rounding their consumers applied on load: identical dX / dW; the bias gradients
         # become sums of the rounded values), so that dX takes the 256-tile kernel and the TN kernel moves half the bytes
-        grad16 = False
         act16 = attn16 and self.bf16_saved_activations and all(m._dense[f'h.0.{n}'].wp16 is not None for n in ('mlp.c_fc', 'mlp.c_proj'))
-        grad16 = act16 and self.bf16_gradient_operands and self.tn_weight_gradient
+        # bf16 gradient operands need every consumer that can read one: the TN weight-gradient kernel for all four layer shapes of a block
+        # at this M (K, N multiples of 256, 32-bit offsets) and the 256-tile GEMM for the dX products (an explicit predicate: d_model 384
+        # or 640 passes the packing rule of `act16` but not these, and keeps fp32 gradients + the transpose / pack weight-gradient path)
+        block_shapes = [(m._dense[f'h.0.{n}'].k, m._dense[f'h.0.{n}'].n) for n in ('attn.c_attn', 'attn.c_proj', 'mlp.c_fc', 'mlp.c_proj')]
+        grad16 = (act16 and self.bf16_gradient_operands and self.tn_weight_gradient
+                  and all(ops.gemm_tn_bf16_shape_ok(M, k_, n_) and ops.gemm_g256_shape_ok(M, n_, k_) for k_, n_ in block_shapes))
+        # the LayerNorm backward hands the projection layers' backward GEMMs a bf16 copy of the residual-stream gradient (with dropout: under
+        # the consuming layer's output mask, which only the fused form applies there)
+        res16 = grad16 and self.bf16_residual_gradient and self.fuse_gelu_backward and (rate == 0.0 or self.fuse_dropout)
+        drop_of = lambda site: (rate, seed, site, row0)                              # noqa: E731  (elementwise sites: row offset)
+        drop_attn = lambda i_: (rate, seed, site_attn(i_), plane0)                   # noqa: E731  (attention: plane offset)
         for i in range(c.n_layer):
             p = f'h.{i}'
             n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d, out_bf16=act16)
@@ -445,22 +487,19 @@ class MIGTTrainer:
                 # that c_proj reads as it is (the rounding the GEMM would apply on load)
                 qkv = m._gemm(n1, p + '.attn.c_attn', M, out_bf16=True)
                 att = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
-                lse = T.attn_fwd_lse_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S)
+                lse = T.attn_fwd_lse_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
+                                          drop=drop_attn(i))
             else:
                 qkv = self._linear(n1, p + '.attn.c_attn', M)
                 att = torch.empty((M, d), dtype=torch.float32, device=dev)
                 lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
-                                     drop=(rate, seed, site_attn(i)))
-            if rate:                                                                 # resid_dropout, migt.py:216
-                y = self._linear(att, p + '.attn.c_proj', M)
-                h_mid = T.dropout_add(y, rate, seed, site_resid(i), res=h, out=y)
-            else:
-                h_mid = self._linear(att, p + '.attn.c_proj', M, res=h)
+                                     drop=drop_attn(i))
+            h_mid = self._proj_dropout(att, p + '.attn.c_proj', M, h, drop_of(site_resid(i)))          # h + resid_dropout(c_proj(a)), migt.py:216,233
             n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d, out_bf16=act16)
             if act16 and self.fuse_gelu_forward and self._gelu_dual_ok(M):
                 # c_fc keeps the fp32 pre-activation for the backward pass AND hands bf16 gelu(u) to mlp.c_proj from one epilogue
                 dn = m._dense[p + '.mlp.c_fc']
-                u16 = grad16 and self.fuse_gelu_backward and self.bf16_residual_gradient and self.bf16_preactivation      # (its only reader then: the
+                u16 = res16 and self.bf16_preactivation      # (its only reader then: the
                 # GELU-backward epilogue of the 256-tile kernel, fed by the bf16 residual-stream gradient)
                 u = torch.empty((M, dn.n), dtype=torch.bfloat16 if u16 else torch.float32, device=dev)
                 f = torch.empty((M, dn.n), dtype=torch.bfloat16, device=dev)
@@ -468,11 +507,7 @@ class MIGTTrainer:
             else:
                 u = self._linear(n2, p + '.mlp.c_fc', M)
                 f = T.gelu(u, out_bf16=act16)
-            if rate:                                                                 # MLP dropout, migt.py:72
-                y = self._linear(f, p + '.mlp.c_proj', M)
-                h_out = T.dropout_add(y, rate, seed, site_mlp(i), res=h_mid, out=y)
-            else:
-                h_out = self._linear(f, p + '.mlp.c_proj', M, res=h_mid)
+            h_out = self._proj_dropout(f, p + '.mlp.c_proj', M, h_mid, drop_of(site_mlp(i)))           # h + dropout(mlp(...)), migt.py:72,237
             if not _forward_only:
                 saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
             h = h_out
@@ -561,39 +596,43 @@ class MIGTTrainer:
             dup = T.gelu_bwd(up, dp1)
             dhl = self._linear_bwd('pose_criterion.pose_classifier.c_fc', hloc, dup, M1)
             dhf[:, 2] = dhl.view(B, S, L, d)
-        res16 = grad16 and self.bf16_residual_gradient and self.fuse_gelu_backward
-        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M, also_bf16=res16)
-        dh, dh16 = dh if res16 else (dh, None)
+        # with dropout, the bf16 copy of a residual-stream gradient is the dY of the projection layer that consumes it, i.e. that gradient
+        # under the layer's OUTPUT mask: the LayerNorm backward applies it while it writes the copy (the fp32 gradient stays unmasked)
+        nl = c.n_layer
+        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M, also_bf16=res16 and nl > 0, drop=drop_of(site_mlp(nl - 1)))
+        dh, dh16 = dh if (res16 and nl > 0) else (dh, None)
         handles = []
         overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
+            dy_mlp = dh16 if res16 else (T.dropout_add(dh, rate, seed, site_mlp(i), row0=row0) if rate else dh)      # d(mlp.c_proj output)
             if grad16 and self.fuse_gelu_backward:                                   # GELU backward in the epilogue of the dX GEMM that feeds it
-                du = self._linear_bwd(p + '.mlp.c_proj', f, dh16 if res16 else dh, M, dx_bf16=True, gelu_bwd_u=u)
+                du = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, M, dx_bf16=True, gelu_bwd_u=u)
             else:
-                df = self._linear_bwd(p + '.mlp.c_proj', f, T.dropout_add(dh, rate, seed, site_mlp(i)) if rate else dh, M)
+                df = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, M)
                 du = T.gelu_bwd(u, df, out_bf16=grad16)
             dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
-            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh, also_bf16=res16)  # (+ the residual branch's gradient, same pass)
+            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh, also_bf16=res16, drop=drop_of(site_resid(i)))  # (+ the residual branch's gradient)
             dh_mid, dh_mid16 = dh_mid if res16 else (dh_mid, None)
             datt = self._linear_bwd(p + '.attn.c_proj', att,
-                                    dh_mid16 if res16 else (T.dropout_add(dh_mid, rate, seed, site_resid(i)) if rate else dh_mid), M, dx_bf16=attn16)
+                                    dh_mid16 if res16 else (T.dropout_add(dh_mid, rate, seed, site_resid(i), row0=row0) if rate else dh_mid), M,
+                                    dx_bf16=attn16)
             if attn16:
                 dqkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if grad16 else torch.float32, device=dev)
                 T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
-                                B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S)
+                                B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S, drop=drop_attn(i))
             else:
-                dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=(rate, seed, site_attn(i)))
+                dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=drop_attn(i))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)
-            dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid, also_bf16=res16 and i > 0)
+            dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid, also_bf16=res16 and i > 0, drop=drop_of(site_mlp(i - 1)))
             dh, dh16 = dh if (res16 and i > 0) else (dh, None)
             saved[i] = None
             if overlap:                                                              # this layer's grads are final
                 handles.append(self._allreduce_range(*self.layer_ranges[i]))
         # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
         if rate:
-            T.dropout_add(dh, rate, seed, SITE_EMBED, out=dh)
+            T.dropout_add(dh, rate, seed, SITE_EMBED, out=dh, row0=row0)
         dadd = T.embed_bwd(dh, ids32, gwte, self.g('wpe.embeddings'), B * V, L, d, nE + 2).view(B, V, d)
         dpe = (dadd[:, :S] + dadd[:, S:2 * S]).contiguous().view(B * S, d)
         if use_loc:

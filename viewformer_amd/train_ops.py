@@ -45,14 +45,25 @@ def colsum(x, out, M, N, ld=None, accumulate=False):
     return out
 
 
-def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True, res=None, also_bf16=False):
-    """``res``: the residual branch's gradient, added to dx in the same pass (dx = LN'(dy) + res); ``also_bf16``: returns (dx, bf16 copy)"""
+def _drop4(drop):
+    """(rate, seed, site[, offset]) -> the four scalars of the C-ABI; ``offset``: the first row's (elementwise sites) / first plane's
+    (attention: first scene's index times H) position in the GLOBAL batch of a data-parallel step, 0 by default"""
+    rate, seed, site = drop[:3]
+    return float(rate), int(seed) & 0xFFFFFFFF, int(site), (int(drop[3]) if len(drop) > 3 else 0)
+
+
+def layernorm_bwd(dy, x, gamma, dgamma, dbeta, rows, d, eps=1e-5, accumulate=True, res=None, also_bf16=False, drop=(0.0, 0, 0)):
+    """``res``: the residual branch's gradient, added to dx in the same pass (dx = LN'(dy) + res); ``also_bf16``: returns (dx, bf16 copy);
+    ``drop`` = (rate, seed, site) with ``also_bf16``: the bf16 copy is dropout_add(dx) of that site — the dY of a layer whose output went
+    through that dropout (the fp32 dx, the residual path's gradient, is not masked)"""
     lib = _lib.load()
     dx = torch.empty_like(x)
     dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if also_bf16 else None
+    if drop[0] and not also_bf16:
+        raise _lib.VfError('layernorm_bwd: drop masks the bf16 copy (also_bf16=True)')
     ws = _ws(int(lib.vf_layernorm_bwd_workspace_bytes(rows, d)), x.device, 'lnbwd')
     check(lib.vf_layernorm_bwd_f32(_p(_f32(dy)), _p(_f32(x)), _p(_f32(gamma)), _p(dx), _p(dgamma), _p(dbeta), rows, d, eps,
-                                   1 if accumulate else 0, _p(_f32(res)) if res is not None else None, _p(dx16), _p(ws), _stream()),
+                                   1 if accumulate else 0, _p(_f32(res)) if res is not None else None, _p(dx16), *_drop4(drop), _p(ws), _stream()),
           'vf_layernorm_bwd_f32')
     return (dx, dx16) if also_bf16 else dx
 
@@ -169,7 +180,7 @@ def attn_fwd_lse(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_s
     lib = _lib.load()
     lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(lib.vf_attn_blockcausal_lse_f32(_p(q), _p(k), _p(v), _p(out), _p(lse), B, H, T, L, ldq, ldk, ldv, ldo, scale, 1,
-                                          mask_spec, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]), _stream()),
+                                          mask_spec, *_drop4(drop), _stream()),
           'vf_attn_blockcausal_lse_f32')
     return lse
 
@@ -181,8 +192,7 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo
     D = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(lib.vf_attn_bwd_prep_f32(_p(dout), _p(out), _p(D), B, H, T, lddo, ldo, _stream()), 'vf_attn_bwd_prep_f32')
     check(lib.vf_attn_bwd_f32(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), B, H, T, L, ldq, ldk, ldv,
-                              lddo, lddq, lddk, lddv, scale, mask_spec, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]),
-                              _stream()), 'vf_attn_bwd_f32')
+                              lddo, lddq, lddk, lddv, scale, mask_spec, *_drop4(drop), _stream()), 'vf_attn_bwd_f32')
 
 
 def attn_bf16_supported(T, L):
@@ -190,19 +200,21 @@ def attn_bf16_supported(T, L):
     return L == 64 and T % 64 == 0 and T // 64 <= 64
 
 
-def attn_fwd_lse_bf16(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1):
-    """bf16 q / k / v -> bf16 ``out`` (LDS-DMA kernel of the inference arm) plus the per-query log-sum-exp [B,H,T] fp32"""
+def attn_fwd_lse_bf16(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, mask_spec=-1, drop=(0.0, 0, 0)):
+    """bf16 q / k / v -> bf16 ``out`` (LDS-DMA kernel of the inference arm) plus the per-query log-sum-exp [B,H,T] fp32; ``drop`` =
+    (rate, seed, site): attn_dropout on softmax(w) with the masks of vf_common.h (the same masks as attn_fwd_lse)"""
     for t in (q, k, v, out):
         _chk(t, torch.bfloat16)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     check(_lib.load().vf_attn_blockcausal_bf16_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), B, H, T, L, ldq, ldk, ldv, ldo, scale, mask_spec,
-                                                   _stream()), 'vf_attn_blockcausal_bf16_lse')
+                                                   *_drop4(drop), _stream()), 'vf_attn_blockcausal_bf16_lse')
     return lse
 
 
-def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0, mask_spec=-1):
+def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0, mask_spec=-1,
+                  drop=(0.0, 0, 0)):
     """dQ, dK, dV (fp32, or bf16 when the output tensors are bf16; written in place; column views allowed) from bf16 q / k / v / out / dout
-    on the bf16 matrix pipe"""
+    on the bf16 matrix pipe; ``drop`` as in the forward (the masks are recomputed)"""
     lib = _lib.load()
     for t in (q, k, v, out, dout):
         _chk(t, torch.bfloat16)
@@ -212,15 +224,20 @@ def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv
     for t in (dq, dk, dv):
         _chk(t, torch.bfloat16 if o16 else torch.float32)
     check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), 1 if o16 else 0, B, H, T, L, ldq, ldk,
-                               ldv, lddo, lddq, lddk, lddv, scale, mask_spec, _stream()), 'vf_attn_bwd_bf16')
+                               ldv, lddo, lddq, lddk, lddv, scale, mask_spec, *_drop4(drop), _stream()), 'vf_attn_bwd_bf16')
 
 
-def dropout_add(x, rate, seed, site, res=None, out=None):
-    """out = keep ? x / (1 - rate) : 0 [+ res] with the counter-based mask (seed, site, flat index); in place when out is x"""
+def dropout_add(x, rate, seed, site, res=None, out=None, cols=None, row0=0):
+    """out = keep ? x / (1 - rate) : 0 [+ res] with the counter-based mask of (seed, site) over x viewed as [rows][cols] (``cols`` defaults
+    to the last dimension: mask group ((m + row0) >> 2) * cols + n, position (m + row0) & 3 — csrc/vf_common.h; ``row0``: the first row's
+    index in the global batch of a data-parallel step); in place when out is x"""
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.load().vf_dropout_add_f32(_p(_f32(x)), _p(_f32(res)) if res is not None else None, _p(out), x.numel(), float(rate),
-                                         int(seed) & 0xFFFFFFFF, int(site), _stream()), 'vf_dropout_add_f32')
+    cols = int(x.shape[-1]) if cols is None else int(cols)
+    if cols <= 0 or x.numel() % cols:
+        raise _lib.VfError('dropout_add: cols must divide the element count')
+    check(_lib.load().vf_dropout_add_f32(_p(_f32(x)), _p(_f32(res)) if res is not None else None, _p(out), x.numel() // cols, cols, int(row0),
+                                         float(rate), int(seed) & 0xFFFFFFFF, int(site), _stream()), 'vf_dropout_add_f32')
     return out
 
 
