@@ -53,7 +53,8 @@ const char* vf_build_flag_name(int i);
 enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA ring kernel where it applies, 0 = register-staged kernel */
        VF_SEL_GEMM_G256 = 1,         /* vf_gemm_bf16: 1 = 256-tile LDS-DMA kernel where it applies, 0 = 128-tile kernel */
        VF_SEL_LN_BWD_TWO_ROWS = 2,   /* vf_layernorm_bwd_f32: 1 = two rows of a wave in flight, 0 = one */
-       VF_SEL_COUNT = 3 };
+       VF_SEL_ATTN_Q32 = 3,          /* the LDS-DMA attention kernel: 1 = 8 waves x 32 queries per workgroup, 0 = 4 waves x 64 queries */
+       VF_SEL_COUNT = 4 };
 int vf_select(int which, int value);
 int vf_selected(int which);
 

@@ -275,10 +275,22 @@ def test_s20_full_size_matches_oracle_and_properties(dev):
             assert e_l < tol and e_p < tol
         else:
             assert e_l < 3e-2 * scale and e_p < 3e-2
-        # dense "-1e4" form == masked-tile skipping
+        # dense "-1e4" form == masked-tile skipping: a property of each kernel that has both forms (attention_f32 / attention_lp).  The
+        # bf16 arm's product kernel (attention_dma.hip) only has the skipping form and, since round 4, its own rounding points: compare
+        # the two forms on the register-staged kernel, and the product kernel against it within the arm's tolerance
+        from viewformer_amd import _lib
         m_dense = MIGT(cfg, precision=arm, skip_masked=False).load_state_dict(sd).to(dev)
-        assert torch.equal(m_dense(dict(input_ids=gen_ids.to(dev), poses=cams.to(dev)), last_view_logits_only=True)['logits_last'],
-                           o1['logits_last'])
+        lg_dense = m_dense(dict(input_ids=gen_ids.to(dev), poses=cams.to(dev)), last_view_logits_only=True)['logits_last']
+        prev = _lib.select(_lib.SEL_ATTN_DMA, 0)
+        try:
+            lg_skip = m(dict(input_ids=gen_ids.to(dev), poses=cams.to(dev)), last_view_logits_only=True)['logits_last']
+        finally:
+            _lib.select(_lib.SEL_ATTN_DMA, prev)
+        assert torch.equal(lg_dense, lg_skip)
+        if arm == 'bf16':
+            assert _maxerr(o1['logits_last'], lg_skip) < 1e-2 * scale
+        else:
+            assert torch.equal(o1['logits_last'], lg_skip)
         # block-causality: views 0..6 of the 20-view pass == the 7-view pass
         full = m(dict(input_ids=ids.to(dev), poses=cams.to(dev)))['hidden_states'][0]
         short = m(dict(input_ids=ids[:, :7].to(dev), poses=cams[:, :7].to(dev)))['hidden_states'][0]

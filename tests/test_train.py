@@ -651,7 +651,8 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
     lse16 = T.attn_fwd_lse_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, spec)
     e_fwd = ((att16.float() - att32).abs().max() / att32.abs().max()).item()
     e_lse = (lse16 - lse32).abs().max().item()
-    assert e_fwd < ATTN_BF16_FWD_TOL and e_lse < 2e-3, (e_fwd, e_lse)                  # lse: fp32 softmax over bf16-product scores
+    assert e_fwd < ATTN_BF16_FWD_TOL and e_lse < 5e-3, (e_fwd, e_lse)                  # lse: fp32 softmax over bf16-product scores (q re-rounded
+    # to bf16 after the multiplication by scale * log2 e since round 4: scores carry one more 2^-9 rounding)
     got = torch.full((B * Tn, 3 * d), float('nan'), device=dev)
     T.attn_bwd_bf16(qkv16[:, d:2 * d], qkv16[:, 2 * d:], qkv16[:, :d], att16, do16, lse16, got[:, d:2 * d], got[:, 2 * d:], got[:, :d],
                     B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, spec)

@@ -248,12 +248,52 @@ def attn(B=128, H=12, S=8, L=64, bf16=False, x6=False, fp8=False, twin=6, a16=Fa
         arm_dma = bool(_vl.load().vf_selected(_vl.SEL_ATTN_DMA))      # (VF_ATTN_DMA=0 in the environment is applied once, at load)
     ms = timeit(lambda: ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], out, B, H, T, L, 3 * d, 3 * d,
                                              3 * d, d, 1.0, True, twin, bf16=bf16, x6=x6, fp8=fp8), iters=20)
-    pairs = S * (S + 1) // 2 if twin < 0 else (twin * (twin + 1) // 2 + (S - twin) * (twin + 1))
+    if twin <= -2:
+        sv = -twin
+        pairs = sv * (sv + 1) // 2 + (S // sv - 1) * sv * (sv + 1) // 2        # streams: branch position i sees i main views + itself
+    else:
+        pairs = S * (S + 1) // 2 if twin < 0 else (twin * (twin + 1) // 2 + (S - twin) * (twin + 1))
     useful = 4.0 * H * 64 * L * L * pairs * B
     arm = 'fp8' if fp8 else 'bf16' if bf16 else 'x6' if x6 else 'f32'
     peak = 2500.0 if (bf16 or fp8) else 2500.0 / 6 if x6 else 157.3
+    if a16 and arm_dma:
+        arm += ', q32' if _vl.load().vf_selected(_vl.SEL_ATTN_Q32) else ', q64'
     print(f'attn[{arm}{(",bf16 io, dma ring" if arm_dma else ",bf16 io") if a16 else ""}] B={B} H={H} T={T} twin={twin}: {ms * 1e3:.1f} us  {useful / ms / 1e9:.1f} TF useful = '
           f'{useful / ms / 1e9 / peak * 100:.1f} % of {peak:.0f}')
+
+
+def attn_stamps(B=128, H=12, S=8, twin=6):
+    """phase timeline of the LDS-DMA attention (library built with -DADMA_STAMPS: the log-sum-exp pointer carries the stamp buffer): per
+    wave, cycles summed over its tile steps — wait for the tile's DMA, wait at the barrier, S MFMAs + softmax, V^T reads + P.V MFMAs"""
+    import ctypes
+    import numpy as np
+    from viewformer_amd import _lib
+    L, d, T = 64, H * 64, S * 64
+    qkv = (torch.randn(B * T, 3 * d, device=dev) * 0.3).to(torch.bfloat16)
+    out = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16)
+    nq = (T + 255) // 256
+    for q32 in (1, 0):
+        _lib.select(_lib.SEL_ATTN_Q32, q32)
+        nw = 8 if q32 else 4
+        st = torch.zeros(B * H * nq * nw * 8, dtype=torch.int32, device=dev)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+        for _ in range(3):
+            st.zero_()
+            _lib.check(_lib.load().vf_attn_blockcausal_bf16_lse(P(qkv[:, d:2 * d]), P(qkv[:, 2 * d:]), P(qkv[:, :d]), P(out), P(st), B, H, T, L, 3 * d, 3 * d,
+                                                               3 * d, d, 1.0, twin, 0.0, 0, 0, 0, ops._stream()), 'lse')
+        torch.cuda.synchronize()
+        t = st.cpu().numpy().view(np.uint32).reshape(nq, B, H, nw, 8).astype(np.float64)
+        print(f'attention stamps B={B} H={H} T={T} twin={twin}, {"8 waves x 32 queries" if q32 else "4 waves x 64 queries"}: cycles per wave')
+        for z in range(nq):
+            tz = t[z].reshape(-1, nw, 8)
+            vis = np.maximum(tz[:, :, 5], 1)
+            print(f'  query block {z}: prologue (entry -> Q in registers) mean {tz[:, :, 6].mean():.0f}; tile loop mean {tz[:, :, 7].mean():.0f} '
+                  f'(max wave {tz[:, :, 7].max():.0f}); visible tile steps per wave {tz[:, :, 5].mean(0).round(1).tolist()}')
+            for i, name in enumerate(('dma wait', 'barrier wait', 'dma issue', 'S + softmax', 'V reads + PV')):
+                per_wave = tz[:, :, i].mean(0)
+                print('    %-13s per wave (summed over its tile steps): %s' % (name, ' '.join('%6.0f' % v for v in per_wave)))
+            print('    S + softmax + PV per VISIBLE tile step: %s' % ' '.join('%6.0f' % v for v in ((tz[:, :, 3] + tz[:, :, 4]) / vis).mean(0)))
+    _lib.select(_lib.SEL_ATTN_Q32, 1)
 
 
 def gn(n_img=56, C=128, HW=16384):
@@ -295,7 +335,8 @@ def clockprobe(n_img=56, C=128, H=128):
 ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True), convbf16_dec=lambda: conv(128, 128, 128, bf16=True), convbf16_dec_nopro=lambda: conv(128, 128, 128, bf16=True, pro=False), convbf16_dec512=lambda: conv(128, 512, 16, bf16=True),
-           attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True),
+           attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True), attn_stamps=attn_stamps, attn_stamps_s20=lambda: attn_stamps(12, 12, 21, 19),
+           attnbf16_train=lambda: attn(B=10, H=12, S=30, bf16=True, a16=True, twin=-10),
            attnbf16_s20=lambda: attn(B=12, S=21, twin=19, bf16=True), attnfp8_s20=lambda: attn(B=12, S=21, twin=19, fp8=True),
            convs2=lambda: conv_s2(x6=False), convs2x6=conv_s2, convs2x3h=lambda: conv_s2(x3h=True), convs2x3h_256=lambda: conv_s2(224, 256, 32, x3h=True), convs2x6_256=lambda: conv_s2(224, 256, 32),
            gemmx3h=lambda: gemm(16384, 768, 2304, arith='x3h'), gemmx3h_gelu=lambda: gemm(16384, 768, 3072, 1, 'x3h'),

@@ -225,6 +225,9 @@ VF_REG_FLAG(ADMA_X_NODMA)
 #ifdef ADMA_X_NOSM
 VF_REG_FLAG(ADMA_X_NOSM)
 #endif
+#ifdef ADMA_STAMPS
+VF_REG_FLAG(ADMA_STAMPS)
+#endif
 #ifdef ATT_X_NOMFMA
 VF_REG_FLAG(ATT_X_NOMFMA)
 #endif
