@@ -737,6 +737,48 @@ def test_bf16_flash_attention_with_dropout(dev, B, H, S, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_bf16_training_arm_at_widths_the_tn_kernel_does_not_tile(dev, dropout):
+    """d_model = 384 (head dim 64, a multiple of 128 but not of 256): the bf16 packings and the bf16 attention apply, the TN weight-gradient
+    kernel and the 256-tile GEMM do not (K, N % 256).  ADVICE r3: the step then handed a bf16 gradient to the transpose + pack path and
+    raised.  Since round 4 the bf16 gradient operands are switched on by an explicit predicate over the four layer shapes: here they stay
+    fp32 and the step runs — gradients within the bf16 arm's tolerance of the fp32-equivalent arm, with and without dropout (fused where
+    the 256-tile kernel applies, the separate passes where it does not: same masks)."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from viewformer_amd import ops
+    from oracle import migt_oracle as mg
+    cfg = MIGTConfig(n_layer=2, d_model=384, n_head=6, sequence_size=4, n_loss_skip=1, localization_weight='2', pose_multiplier=0.2,
+                     dropout=dropout, learning_rate=1e-3, weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=4)                            # (the reference's initializer range, 0.02: with std 0.05 this toy's logits
+    # saturate — loss 10.9 against ln 1024 = 6.9 — and the bf16 arm sits at 4.9e-2 .. 7.7e-2 of the fp32 arm, dropout or not: tools/diag384.py)
+    g = np.random.Generator(np.random.PCG64(11))
+    B, S = 2, 4                                                   # M = 2 * 3 * 4 * 64 = 1536 rows
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 5)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    assert not ops.gemm_tn_bf16_shape_ok(1536, 384, 1152)
+    grads, losses = {}, {}
+    for arm in ('bf16', 'f32'):
+        tr = MIGTTrainer(MIGT(cfg, precision=arm).load_state_dict(sd).to(dev), warmup_steps=4)
+        tr.step_count, tr.dropout_seed = 3, 17
+        m = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+        grads[arm], losses[arm] = tr.flat_g.clone(), float(m['loss'])
+        assert bool(torch.isfinite(tr.flat_g).all())
+    assert abs(losses['bf16'] - losses['f32']) < 2e-2 * max(1.0, abs(losses['f32']))
+    worst = 0.0
+    for n in tr.names:
+        a, b, _ = tr.slices[n]
+        ref = grads['f32'][a:b]
+        if float(ref.abs().max()) > 0:
+            worst = max(worst, ((grads['bf16'][a:b] - ref).abs().max() / ref.abs().max()).item())
+    print(f'd_model 384, dropout {dropout}: bf16 arm vs fp32-equivalent arm, worst per-tensor gradient difference', worst)
+    assert worst < BF16_GRAD_TOL, worst
+
+
+@pytest.mark.gpu
 def test_bf16_attention_is_what_the_bf16_training_arm_runs_at_full_width(dev):
     """head dim 64, 64-token views, no dropout: the trainer takes the bf16 attention kernels; with attention_arith='f32' the exact-f32
     ones — gradients of the two agree within the bf16 arm's own tolerance"""

@@ -255,6 +255,9 @@ VF_REG_FLAG(VQF_STAMPS)
 #ifdef VQF_X_NORERANK
 VF_REG_FLAG(VQF_X_NORERANK)
 #endif
+#ifdef VQF_X_STAGGER
+VF_REG_FLAG(VQF_X_STAGGER)
+#endif
 #ifdef VF_X3H_STAMPS
 VF_REG_FLAG(VF_X3H_STAMPS)
 #endif

@@ -181,6 +181,16 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
 #define VQF_STAMP(i)
 #endif
     VQF_STAMP(0);
+#ifdef VQF_X_STAGGER      // experiment (round 4, tools/variants.sh): every second workgroup starts VQF_X_STAGGER cycles late, so that the two
+    if (blockIdx.x & 1) {  // workgroups of a CU are in different phases (z read / matrix loop / classification / re-rank) at any time
+        unsigned long long t0, t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+        do {
+            __builtin_amdgcn_s_sleep(32);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        } while (t1 - t0 < (unsigned long long)(VQF_X_STAGGER));
+    }
+#endif
     const Blob B = blob_view(blob_p, Kc);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;

@@ -43,7 +43,8 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     if images.shape[0] > chunk:
         parts = [generate_batch_predictions(transformer_model, codebook_model, images[i:i + chunk], cameras[i:i + chunk], return_codes,
                                             fused_passes, chunk) for i in range(0, images.shape[0], chunk)]
-        return {k: torch.cat([p[k] for p in parts]) for k in parts[0] if parts[0][k] is not None}
+        # (a key that is None for a chunk — pose_last without localization — stays None: the schema does not depend on the batch size)
+        return {k: (None if parts[0][k] is None else torch.cat([p[k] for p in parts])) for k in parts[0]}
     ground_truth_cameras = cameras[:, -1]
     transform = None
     if transformer_model.config.augment_poses == 'relative':            # :99-101
@@ -121,8 +122,9 @@ def stream_batch_predictions(transformer_model, codebook_model, batches, depth: 
     downloaded on a second HIP stream while batch i computes.  ``batches`` yields ``(images uint8 [B,S,H,W,3], cameras [B,S,7])``
     host tensors (pinned ones copy asynchronously); yields per batch the same dict as ``generate_batch_predictions`` with
     ``generated_images`` / ``generated_cameras`` on the host.  Results are those of the plain call, in order.  The host tensors
-    come from a ring of ``depth + 1`` pinned buffers per key: they stay valid until ``depth`` further batches have been yielded
-    (the reference's loop consumes a batch's images before it asks for the next one); copy what must live longer."""
+    come from a ring of ``2 * depth`` pinned buffers per key: batch j is yielded once download j + depth - 1 has been issued and its
+    buffer is reused by download j + 2 * depth, so a yielded batch's host tensors stay valid until ``depth`` further batches have been
+    REQUESTED (the reference's loop consumes a batch's images before it asks for the next one); copy what must live longer."""
     dev = codebook_model.device
     compute = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(dev)
@@ -131,8 +133,8 @@ def stream_batch_predictions(transformer_model, codebook_model, batches, depth: 
     def host_buffer(k, t):
         key = (k, tuple(t.shape), t.dtype)
         if key not in ring:
-            ring[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(depth + 1)]
-        return ring[key][ring_pos[0] % (depth + 1)]
+            ring[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(2 * depth)]
+        return ring[key][ring_pos[0] % (2 * depth)]
 
     def upload(b):
         img, cam = (torch.as_tensor(x) for x in b)

@@ -173,6 +173,13 @@ class MIGTTrainer:
         lm16 = bf16 and self.bf16_lm_head and d % 256 == 0 and nE % 256 == 0
         if lm16 and self._lm16 is None:
             self._pack16 = None                                  # (the LM-head packings join the descriptor table: rebuild it)
+        if self._pack16 is not None and (not bf16 or any(
+                dn.wp16 is None or name not in self.wpT16 for name, dn in m._dense.items()
+                if dn.k % 128 == 0 and dn.n % 128 == 0)):
+            # the table holds raw pointers into packings that are gone (the arm was switched to f32 and back, or a layer lost its
+            # buffers): never run it against them — rebuild from scratch below
+            self._pack16 = None
+            self._pack16_keep = None
         if self._pack16 is not None:
             self._pack16()
         pack_items = []
@@ -209,6 +216,7 @@ class MIGTTrainer:
             self._lm16 = (ops.pack_dense_nk_bf16(head), ops.pack_dense_kn_bf16(head))
         if bf16 and self._pack16 is None and pack_items and self.one_launch_repack:
             self._pack16 = ops.pack_bf16_multi(pack_items)          # (re-packs once more; from now on the closure is the refresh)
+            self._pack16_keep = pack_items                          # (the closure holds raw pointers: keep the tensors alive with it)
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T (kept fresh for
         if not lm16:                                                                                      # whoever reads the model afterwards)
             self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
@@ -328,6 +336,7 @@ class MIGTTrainer:
     _lm16 = None
     one_launch_repack = True          # bf16 arm: all weight packings refreshed by one launch per step
     _pack16 = None
+    _pack16_keep = None
     fuse_gelu_backward = True         # bf16 arm: d(pre-activation) = dX(mlp.c_proj) * gelu'(u) in that GEMM's epilogue (same bits as the two passes)
     bf16_gradient_operands = True     # bf16 arm: gelu_bwd / attention backward write their gradients as bf16 (see train_step)
     tn_weight_gradient = True         # bf16 arm: dW / db of the wide layers straight from the row-major operands (False: transpose + pack + column sums)
@@ -577,8 +586,8 @@ class MIGTTrainer:
             # dwte[:nE] = dlogits^T @ H straight from the row-major operands (the TN kernel: x = dlogits as bf16, dy = H)
             ops.gemm_tn_bf16(dlogits.to(torch.bfloat16), hmask, M1, nE, d, gwte[:nE], None)
         else:
-            if getattr(self, 'lm_T', None) is None:
-                self.repack()                                                         # (bf16_lm_head switched off after the last repack)
+            if getattr(self, 'lm_T', None) is None:                                   # (bf16_lm_head off, or M1 % 64 != 0, after a repack that
+                self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0)              # skipped it: build the transposed LM-head packing here)
             ops.igemm(dlogits, self.lm_T, M1, nE, d, dhm)
             dlt = T.transpose(dlogits, M1, nE)
             hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
@@ -700,11 +709,15 @@ class MIGTTrainer:
             B, S = tokens.shape[:2]
             pp = geometry.pose_head_postprocess(out['pose_head_raw'], c.pose_multiplier)[:, skip:]
             gt = poses.to(self.dev).view(B, S, 1, 7)[:, skip:]
-            metrics['pose_pos_err'] = (pp[..., :3] - gt[..., :3]).norm(dim=-1).mean()            # CameraPositionError, utils/metrics.py:90-95
+            # AllowNanMean (utils/metrics.py:75-87) as the reference computes it: a NaN sample — asin of a norm that rounding pushed past 1,
+            # a zero quaternion — is REPLACED BY 0 and still counted (the weight line :86 tests the already-cleaned values, so no sample is
+            # ever dropped): mean over all samples of nan_to_zero(value).  No clamp on the asin argument.
+            nan_mean = lambda v: torch.where(torch.isnan(v), torch.zeros_like(v), v).mean()      # noqa: E731
+            metrics['pose_pos_err'] = nan_mean((pp[..., :3] - gt[..., :3]).norm(dim=-1))         # CameraPositionError, :90-95
             q1 = geometry.quaternion_normalize(pp[..., 3:])                                     # CameraOrientationError, :98-110: the sine
             q2 = geometry.quaternion_normalize(gt[..., 3:].expand_as(pp[..., 3:]))              # form, stable near zero rotation
             diff = geometry.quaternion_multiply(q1, geometry.quaternion_conjugate(q2))
-            metrics['pose_ori_err'] = (2.0 * torch.asin(diff[..., 1:].norm(dim=-1).clamp(max=1.0))).mean()
+            metrics['pose_ori_err'] = nan_mean(2.0 * torch.asin(diff[..., 1:].norm(dim=-1)))
         if codebook_model is not None:
             t = c.token_image_size
             gen = out['predicted_tokens'][:, -1].reshape(-1, t, t)
