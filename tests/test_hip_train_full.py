@@ -265,6 +265,12 @@ def test_full_size_step_at_the_reference_dropout(dev):
         else:
             assert torch.equal(g1[a:b], tr16.flat_g[a:b]), n
     tr16.fuse_dropout = True
+    # the weight-gradient GEMMs on a second stream beside the dX GEMMs (default) vs everything on the compute stream: the same kernels on the
+    # same operands -> the same bits
+    tr16.overlap_weight_gradients = False
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(tr16.flat_g, g1)
+    tr16.overlap_weight_gradients = True
     # the fp32-equivalent arm under the same masks
     tr32 = _trainer(cfg, dev, 'f32')
     tr32.dropout_seed = 5

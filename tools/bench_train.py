@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='bf16: dense GEMMs of the forward and backward pass on bf16 MFMA (fp32 master weights, fp32 attention / '
                          'normalisation / losses / optimizer), like the reference\'s --fp16')
+    ap.add_argument('--serial-wgrad', action='store_true', help='weight-gradient GEMMs on the compute stream (A/B of MIGTTrainer.overlap_weight_gradients)')
     args = ap.parse_args()
     from viewformer_amd import sharding
     from viewformer_amd.config import MIGTConfig
@@ -40,6 +41,7 @@ def main():
                      learning_rate=1e-4, weight_decay=0.05, total_steps=40000, batch_size=80)
     model = MIGT(cfg, precision=args.precision).load_state_dict(make_migt_weights(cfg, seed=0)).to(dev)
     tr = MIGTTrainer(model)
+    tr.overlap_weight_gradients = not args.serial_wgrad
     g = np.random.Generator(np.random.PCG64(rank))
     B, S = args.batch, args.seq
     tokens = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8))).to(dev)
@@ -60,7 +62,7 @@ def main():
         tf = 3 * 0.37 * B * world
         print(json.dumps({'metric': 'MIGT training step (fwd+bwd+AdamW), CO3D-10cat config', 'ms_per_step': round(dt * 1e3, 1),
                           'samples_per_s': round(B * world / dt, 2), 'n_gpus': world, 'scenes_per_gpu': B,
-                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': args.precision, 'dropout': args.dropout,
+                          'approx_tflops': round(tf / dt, 1), 'loss': float(met['loss']), 'dtype': args.precision, 'dropout': args.dropout, 'wgrad_stream': 'compute' if args.serial_wgrad else 'second',
                           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -249,7 +249,21 @@ class MIGTTrainer:
         if bf16 and self.tn_weight_gradient and ops.gemm_tn_bf16_supported(x, M, K, N):
             # bf16 arm with a saved bf16 activation: dW and db in ONE pass over x and dy as they lie (csrc/gemm_tn_bf16.hip) — no widening
             # transpose of x, no packed bf16 copy of dy, no column-sum pass
-            ops.gemm_tn_bf16(x, dy, M, K, N, self.g(name + '.weight'), self.g(name + '.bias'))
+            gw, gb = self.g(name + '.weight'), self.g(name + '.bias')
+            if self.overlap_weight_gradients and need_dx:
+                # ... on a SECOND HIP stream, beside the dX GEMM that reads the same dy: both are one under-filled round of 256-tile
+                # workgroups (225-243 on 256 CUs, one per CU: 128 KB of LDS each), so the weight gradient's workgroups take the CUs the
+                # dX GEMM leaves idle and its tail.  Joined before anything reads the layer's gradients (_join_side)
+                main = torch.cuda.current_stream(self.dev)
+                side = self._side()
+                side.wait_stream(main)                                                 # dy (and x) are complete
+                with torch.cuda.stream(side):
+                    ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb)
+                for t in (x, dy):
+                    t.record_stream(side)                                              # (the allocator must not recycle them under the side stream)
+                self._side_busy = True
+            else:
+                ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb)
             return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u) if need_dx else None
         if dy.dtype != torch.float32:
             raise RuntimeError('a bf16 gradient operand needs the TN weight-gradient path')
@@ -285,6 +299,21 @@ class MIGTTrainer:
         if not need_dx:
             return None
         return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u)
+
+    overlap_weight_gradients = True   # bf16 arm: the TN weight-gradient GEMM of a layer on a second stream beside that layer's dX GEMM
+    _side_stream = None
+    _side_busy = False
+
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.dev)
+        return self._side_stream
+
+    def _join_side(self):
+        """the compute stream waits for the weight-gradient stream (before a layer's gradients are reduced, clipped or applied)"""
+        if self._side_busy:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side_stream)
+            self._side_busy = False
 
     def _linear_dx(self, name, dy, M, res=None, dx_bf16=False, gelu_bwd_u=None):
         """dx = dy @ W^T (+ res).  ``gelu_bwd_u`` (bf16 arm): the saved fp32 pre-activation u of the GELU that produced this layer's input —
@@ -638,6 +667,7 @@ class MIGTTrainer:
             dh, dh16 = dh if (res16 and i > 0) else (dh, None)
             saved[i] = None
             if overlap:                                                              # this layer's grads are final
+                self._join_side()
                 handles.append(self._allreduce_range(*self.layer_ranges[i]))
         # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
         if rate:
@@ -651,6 +681,7 @@ class MIGTTrainer:
         T.dense_small_k_bwd(pin, du1, self.g('pose_embedding.c_fc.weight'), self.g('pose_embedding.c_fc.bias'), B * S, 7, fc.n)
 
         # ---- clip (per replica, per tensor, before aggregation), all-reduce SUM, AdamWeightDecay ------------
+        self._join_side()
         if c.gradient_clip_val and c.gradient_clip_val > 0:
             for n in self.names:
                 T.clip_by_norm_(self.g(n).reshape(-1), float(c.gradient_clip_val), self._scratch)
