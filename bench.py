@@ -45,7 +45,7 @@ PMC_SOURCE = {'x3h': ('profiles/r2_new_kernels_pmc.txt', 466930e3, 458750e3),   
 
 
 def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h', bf16_activations: bool = True,
-                 encoder_chunk: int = 1024, attention=None, sequence_size: int = 6):
+                 encoder_chunk: int = 1024, attention=None, sequence_size: int = 6, decoder_act16=None):
     from viewformer_amd.config import VQGANConfig, MIGTConfig
     from viewformer_amd.weights import make_vqgan_weights, make_migt_weights
     from viewformer_amd.vqgan import VQGAN
@@ -62,6 +62,8 @@ def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: st
     arm = 'bf16' if precision == 'mixed' else 'f32'
     vq = VQGAN(vcfg, data_format='NHWC', decoder_precision=arm, conv_arith=conv_arith,
                max_images_per_call=encoder_chunk).load_state_dict(vsd).to(dev)
+    if decoder_act16 is not None:
+        vq.decoder_act16 = int(decoder_act16)
     # the transformer's fp32 dense layers follow the convolutions' arithmetic (x3h: LayerNorm / GELU / attention outputs are O(1))
     tr = MIGT(mcfg, precision=arm, dense_arith=conv_arith, bf16_activations=bf16_activations,
               attention=attention if arm == 'bf16' else None).load_state_dict(msd).to(dev)
@@ -391,6 +393,8 @@ def main():
                     help='mixed arm: attention operand format (default bf16 everywhere; fp8 = the OCP e4m3 tolerance arm configs[4] names — slower and looser)')
     ap.add_argument('--fp32-activations', action='store_true',
                     help='mixed arm: keep LayerNorm / GELU / attention outputs fp32 in HBM (A/B of the bf16 activation chain; same results)')
+    ap.add_argument('--decoder-act16', type=int, choices=[0, 32, 64, 128], default=None,
+                    help='mixed arm: bf16 activations between the decoder layers from this resolution up (0 = fp32 activations; default: VQGAN.decoder_act16)')
     ap.add_argument('--encoder-chunk', type=int, default=1024, help='images per encoder / decoder launch chunk (VQGAN max_images_per_call)')
     ap.add_argument('--cpu-scenes', type=int, default=0, help='scenes in the CPU-baseline sample (0 = auto)')
     ap.add_argument('--dropout', type=float, default=0.1,
@@ -424,7 +428,7 @@ def main():
     S, B = args.views or 7, args.batch or 128
 
     vq, tr, models_cfg = build_models(dev, localization, args.precision, args.conv_arith, not args.fp32_activations, args.encoder_chunk,
-                                      attention=args.attention)
+                                      attention=args.attention, decoder_act16=args.decoder_act16)
     if args.batch_sweep:
         sweep = []
         for b in [int(x) for x in args.batch_sweep.split(',')]:

@@ -147,10 +147,11 @@ int vf_conv_in_x3h(const uint8_t* img_u8, const float* img_f32, const void* w_pa
 
 /* 3x3 stride-1 pad-1 convolution to 1..4 output channels (the decoder's conv_out, vqgan_th.py:285-289,316-318) with
  * the GroupNorm-apply(+swish) of the preceding norm_out (:313-315) fused; plain fp32 fmaf arithmetic.  x NHWC
- * [n_img][H][W][Cin], w OIHW, out NHWC [n_img][H][W][Cout].  Cin % 32 == 0, H % 8 == 0, W % 32 == 0. */
+ * [n_img][H][W][Cin], w OIHW, out NHWC [n_img][H][W][Cout].  Cin % 32 == 0, H % 8 == 0, W % 32 == 0.  x_bf16 != 0: x is a bf16 NHWC
+ * activation (the bf16-activation decoder: vf_conv3_halo_bf16 with reserved0 bit 1). */
 int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bias, const float* pro_mean,
                             const float* pro_scale, const float* pro_beta, int pro_swish, float* out, int n_img, int H, int W,
-                            int Cin, int Cout, void* stream);
+                            int Cin, int Cout, int x_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32 groups) statistics.  Replaces torch.nn.GroupNorm vqgan_th.py:16-17.
@@ -290,7 +291,9 @@ int vf_resize_u8(const uint8_t* src, uint8_t* dst, int n_img, int Hin, int Win, 
  * the decoder's convolutions.  Same vf_igemm_args as the exact path; w_packed points to the bf16 packing.
  * vf_gemm_bf16: VF_MODE_GEMM, Cin % 64 == 0, no prologue.
  * vf_conv3_halo_bf16: VF_MODE_CONV3_S1 / _UP2 with the halo-kernel shape rules (Cin % 32, Cout % 128,
- * Wout % 16, Hout % 8), GroupNorm(+swish) prologue, bias, residual.
+ * Wout % 16, Hout % 8), GroupNorm(+swish) prologue, bias, residual.  reserved0 carries dtype flags like vf_gemm_bf16's: bit 1 = out AND
+ * res are bf16 NHWC (ldc / ldr in elements, even); bit 0 (only together with bit 1) = x is bf16 NHWC: the decoder's activations stay bf16
+ * between its layers (fused GroupNorm partials are taken from the fp32 values before the output rounding).
  * ------------------------------------------------------------------------------------- */
 size_t vf_gemm_bf16_packed_elems(int K, int N);            /* number of bf16 elements of the packed weight */
 int vf_gemm_bf16_pack(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int batch,

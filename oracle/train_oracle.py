@@ -76,13 +76,58 @@ def gradients(sd_np, cfg, poses, tokens, step=0, pose_factors=None):
     return grads, {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in metrics.items()}
 
 
-def learning_rate(step, init_lr, total_steps, warmup_steps):
-    """WarmUp over CosineDecay (models/utils.py:346-361,403-412)"""
+def learning_rate(step, init_lr, total_steps, warmup_steps, offset=0):
+    """WarmUp over CosineDecay (models/utils.py:346-361,403-412); offset: WarmUp.offset (:337,341, set by finetune_transformer.py:86)"""
+    step = max(step - offset, 0)
     if warmup_steps and step < warmup_steps:
         return init_lr * (step / warmup_steps)
     decay_steps = max(total_steps - warmup_steps, 1)
     t = min(step - warmup_steps, decay_steps)
     return init_lr * 0.5 * (1.0 + math.cos(math.pi * t / decay_steps))
+
+
+def process_batch_np(cameras, augment, split, draws=None):
+    """fp64 numpy restatement of process_batch (viewformer/train/train_transformer.py:28-61) for ONE sequence ``cameras`` [S,7]; ``draws``: the
+    random numbers of the call — shift [3], y0, x, y1 scalars (the reference draws them from tf.random: shapes (1,3) / (1,))."""
+    def qmul(a, b):                                   # geometry_tf.py:6-13
+        w1, x1, y1, z1 = np.moveaxis(a, -1, 0)
+        w2, x2, y2, z2 = np.moveaxis(b, -1, 0)
+        return np.stack((-x1 * x2 - y1 * y2 - z1 * z2 + w1 * w2, x1 * w2 + y1 * z2 - z1 * y2 + w1 * x2,
+                         -x1 * z2 + y1 * w2 + z1 * x2 + w1 * y2, x1 * y2 - y1 * x2 + z1 * w2 + w1 * z2), -1)
+
+    def qconj(q):                                     # geometry_tf.py:53-56
+        return np.concatenate([q[..., :1], -q[..., 1:]], -1)
+
+    def qrot(p, q):                                   # geometry_tf.py:59-68
+        p4 = np.concatenate([np.zeros_like(p[..., :1]), p], -1)
+        return qmul(qmul(q, p4), qconj(q))[..., 1:]
+
+    def mkq(axis, angle):                             # geometry_tf.py:16-33
+        return np.concatenate([[np.cos(angle / 2)], np.sin(angle / 2) * np.asarray(axis, np.float64)])[None]
+
+    cam = np.asarray(cameras, np.float64)
+    xyz, q = cam[:, :3], cam[:, 3:]
+    if augment == 'relative':                         # :31-36
+        rinv = qconj(q[:1])
+        xyz = qrot(xyz - xyz[:1], rinv)
+        q = qmul(rinv, q)
+    elif augment == 'no' or split != 'train':         # :37-38
+        pass
+    elif augment == 'simple':                         # :39-50
+        xyz = xyz + np.asarray(draws['shift'], np.float64)[None]
+        rot = qmul(mkq([0, 1, 0], draws['y0']), qmul(mkq([1, 0, 0], draws['x']), mkq([0, 1, 0], draws['y1'])))
+        xyz = qrot(xyz, rot)
+        q = qmul(q, rot)
+    elif augment == 'advanced':                       # :51-55
+        xyz = xyz + np.asarray(draws['shift'], np.float64)[None]
+        rot = mkq([0, 1, 0], draws['y0'])
+        xyz = qrot(xyz, rot)
+        q = qmul(q, rot)
+    else:
+        raise ValueError(f'Augment {augment} is not supported')
+    q = q / np.sqrt(np.maximum((q * q).sum(-1, keepdims=True), 1e-12))       # quaternion_normalize, geometry_tf.py:44-45
+    q = q * (2.0 * (q[:, :1] >= 0) - 1.0)                                     # quaternion_remove_sign, :48-50
+    return np.concatenate([xyz, q], -1)
 
 
 def adam_weight_decay_step(params, grads, m, v, step, cfg, warmup_steps=2000, b1=0.9, b2=0.999, eps=1e-8):

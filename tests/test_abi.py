@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_queries(lib):
-    assert lib.vf_abi_version() == 17
+    assert lib.vf_abi_version() == 18
     # the struct mirrors of the binding have the library's layout (checked again at load time: a mismatch raises)
     import ctypes
     from viewformer_amd import _lib as L

@@ -15,6 +15,11 @@ PIXEL_TOL_ABS = 8e-2        # max |decoded pixel error| on the [-1, 1] scale, bf
                             # maximum over 98k pixels moves with any last-bit change upstream; the mean is 4.4e-3)
 PIXEL_TOL_MEAN = 6e-3       # mean |decoded pixel error|
 U8_TOL_LEVELS = 10          # max uint8 level difference of the final image (measured 7 .. 8)
+# VQGAN.decoder_act16 = 64 / 32 (bf16 activations between the decoder's layers from 64^2 / 32^2 up; the default, 128, stays inside the bounds above:
+# measured 6.4e-2 / 4.6e-3 / 8 levels)
+ACT16_PIXEL_TOL_ABS = 1.1e-1     # measured 6.9e-2 (64), 8.1e-2 (32)
+ACT16_PIXEL_TOL_MEAN = 7e-3      # measured 4.9e-3, 5.3e-3
+ACT16_U8_TOL_LEVELS = 13         # measured 9, 10
 
 
 @pytest.fixture(scope='module')
@@ -92,6 +97,55 @@ def test_conv3_halo_bf16(dev, mode, cin, cout, H, pro):
     assert _rel(out, ref) < (3e-3 if pro else 3e-5), (mode, cin, cout, pro, _rel(out, ref))
 
 
+@pytest.mark.parametrize('mode,cin,cout,H,pro,a16,with_res', [('s1', 128, 128, 16, True, True, True), ('s1', 256, 128, 32, True, True, False),
+                                                               ('up', 256, 256, 16, False, False, False), ('up', 128, 128, 16, False, True, False),
+                                                               ('s1', 64, 256, 32, False, True, True), ('s1', 128, 128, 64, True, True, True)])
+def test_conv3_halo_bf16_with_bf16_activations_rounds_the_fp32_result(dev, mode, cin, cout, H, pro, a16, with_res):
+    """vf_conv3_halo_bf16 with reserved0 bit 1 (bf16 out + residual) and bit 0 (bf16 in): the SAME accumulators as the fp32-activation
+    launch on the widened operands, rounded once at the store; the fused GroupNorm partials are those of the fp32 values"""
+    from viewformer_amd import ops
+    n = 2
+    x16 = (_rand((n * H * H, cin), 21) * 1.5 + 0.2).to(torch.bfloat16).to(dev)
+    x32 = x16.float()
+    w, b = _rand((cout, cin, 3, 3), 22, 0.05), _rand((cout,), 23)
+    gamma, beta = _rand((cin,), 24) * 0.3 + 1, _rand((cin,), 25) * 0.2
+    m, Ho = (ops.MODE_CONV3_S1, H) if mode == 's1' else (ops.MODE_CONV3_UP2, 2 * H)
+    prol = None
+    if pro:
+        mean_c, scale_c = ops.groupnorm_stats(x32, gamma.to(dev), n, H * H, cin)
+        prol = (mean_c, scale_c, beta.to(dev))
+    M = n * Ho * Ho
+    res16 = _rand((M, cout), 26).to(torch.bfloat16).to(dev) if with_res else None
+    wp = ops.pack_conv3_bf16(w.to(dev))
+    kw = dict(bias=b.to(dev), mode=m, pro=prol, pro_swish=True, Hin=H, Win=H, Hout=Ho, Wout=Ho, bf16=True)
+    out32, part32 = torch.empty((M, cout), device=dev), ops.new_gn_part(n, Ho, Ho, dev)
+    ops.igemm(x32, wp, M, cin, cout, out32, res=res16.float() if with_res else None, gn_part=part32, **kw)
+    out16, part16 = torch.empty((M, cout), dtype=torch.bfloat16, device=dev), ops.new_gn_part(n, Ho, Ho, dev)
+    ops.igemm(x16 if a16 else x32, wp, M, cin, cout, out16, res=res16, gn_part=part16, a16=a16, o16=True, **kw)
+    assert torch.equal(out16, out32.to(torch.bfloat16))
+    g32 = ops.groupnorm_finalize(part32, gamma[:1].expand(cout).contiguous().to(dev), n, Ho * Ho, cout, 32, 1e-6)
+    g16 = ops.groupnorm_finalize(part16, gamma[:1].expand(cout).contiguous().to(dev), n, Ho * Ho, cout, 32, 1e-6)
+    assert torch.equal(g16[0], g32[0]) and torch.equal(g16[1], g32[1])
+    with pytest.raises(ops._lib.VfError):             # bf16 in with fp32 out is not an arm of the kernel
+        ops.igemm(x16, wp, M, cin, cout, out32, a16=True, **kw)
+    if with_res:
+        with pytest.raises(TypeError):                # bf16 out takes its residual as bf16 too
+            ops.igemm(x16, wp, M, cin, cout, out16, res=res16.float(), a16=True, o16=True, **kw)
+
+
+def test_conv3_small_cout_reads_bf16_activations(dev):
+    from viewformer_amd import ops
+    n, H, C = 2, 64, 128
+    x16 = (_rand((n * H * H, C), 31) * 1.2).to(torch.bfloat16).to(dev)
+    w, b = _rand((3, C, 3, 3), 32, 0.05).to(dev), _rand((3,), 33).to(dev)
+    gamma, beta = (_rand((C,), 34) * 0.3 + 1).to(dev), (_rand((C,), 35) * 0.2).to(dev)
+    mean_c, scale_c = ops.groupnorm_stats(x16.float(), gamma, n, H * H, C)
+    for pro in (None, (mean_c, scale_c, beta)):
+        a = ops.conv3_small_cout(x16, w, b, n, H, H, C, 3, pro=pro)
+        r = ops.conv3_small_cout(x16.float(), w, b, n, H, H, C, 3, pro=pro)
+        assert torch.equal(a, r)
+
+
 def test_migt_bf16_logits_within_stated_tolerance(dev):
     from oracle import migt_oracle as mg
     from viewformer_amd.config import MIGTConfig
@@ -134,6 +188,20 @@ def test_decoder_bf16_pixels_within_stated_tolerance_and_tokens_stay_exact(dev, 
     print(f'bf16 decoder: max |pixel err| {err.max():.3e} (mean {err.mean():.2e}); uint8 max diff {du.max().item()}, '
           f'{(du > 1).float().mean().item():.4f} of pixels differ by > 1 level')
     assert err.max() < PIXEL_TOL_ABS and err.mean() < PIXEL_TOL_MEAN and du.max() <= U8_TOL_LEVELS
+    # bf16 activations between the decoder's layers from R x R up (decoder_act16 = R; default 128, inside the tolerance above): fp32
+    # activations throughout (0) inside it too; the wider forms carry their own, looser, stated tolerance
+    assert m16.decoder_act16 == 128
+    for R in (0, 64, 32):
+        m16.decoder_act16 = R
+        dec2 = m16.decode_code(torch.from_numpy(g['codes'][:2]).to(dev)).permute(0, 3, 1, 2).cpu()
+        err2 = (dec2.double() - torch.from_numpy(g['decoded']).double()).abs()
+        du2 = (vq.postprocess_u8(dec2).int() - u32.int()).abs()
+        print(f'  decoder_act16={R}: max |pixel err| {err2.max():.3e} (mean {err2.mean():.2e}); uint8 max diff {du2.max().item()}')
+        wide = R != 0
+        assert err2.max() < (ACT16_PIXEL_TOL_ABS if wide else PIXEL_TOL_ABS) and err2.mean() < (ACT16_PIXEL_TOL_MEAN if wide else PIXEL_TOL_MEAN)
+        assert du2.max() <= (ACT16_U8_TOL_LEVELS if wide else U8_TOL_LEVELS)
+        assert not torch.equal(dec, dec2)                               # (the switch does something)
+    m16.decoder_act16 = 128
 
 
 def test_pipeline_bf16_arm(dev, full_vq):

@@ -33,6 +33,59 @@ def test_schedules_match_reference_formulas():
     assert abs(to.schedule_value('cosine(0,1,120000)', 30000) - f(30000)) < 1e-15
 
 
+def test_learning_rate_offset_of_the_finetune_driver():
+    """WarmUp.offset (models/utils.py:337,341; finetune_transformer.py:86): the schedule counts from the restored iteration count"""
+    from oracle import train_oracle as to
+    from viewformer_amd.train import learning_rate
+    assert learning_rate(120000, 1e-5, 10000, 2000, offset=120000) == 0.0
+    assert abs(learning_rate(121000, 1e-5, 10000, 2000, offset=120000) - 0.5e-5) < 1e-18
+    assert learning_rate(100, 1e-5, 10000, 2000, offset=120000) == 0.0                   # max(step - offset, 0)
+    for s_ in (120000, 120007, 123456, 131000):
+        assert learning_rate(s_, 1e-5, 10000, 2000, 120000) == to.learning_rate(s_, 1e-5, 10000, 2000, 120000) == learning_rate(s_ - 120000, 1e-5, 10000, 2000)
+
+
+@pytest.mark.parametrize('augment', ['relative', 'no', 'simple', 'advanced'])
+def test_process_batch_pose_augmentation(augment):
+    """the token dataset's per-sequence transform (train_transformer.py:28-61) against the fp64 restatement, with the random numbers handed to both"""
+    import math
+    from oracle import train_oracle as to
+    from oracle import migt_oracle as mg
+    from viewformer_amd.train import process_batch, pose_augmentation_draws
+    from viewformer_amd.weights import synthetic_scene_batch
+    B, S = 3, 5
+    _, cams = synthetic_scene_batch(B, S, 8, 11)
+    cams = torch.from_numpy(cams)
+    cams[1, :, 3:] *= -1.0                                       # a sign the sign-fix has to undo
+    tokens = torch.arange(B * S).view(B, S)
+    gen = torch.Generator().manual_seed(5)
+    draws = pose_augmentation_draws(augment, B, gen)
+    out, tok = process_batch(cams, tokens, augment, 'train', draws=draws)
+    assert tok is tokens and out.shape == cams.shape and out.dtype == cams.dtype
+    for b in range(B):
+        d = {k: (v[b].double().numpy() if v[b].dim() else float(v[b])) for k, v in draws.items()}
+        ref = to.process_batch_np(cams[b].numpy(), augment, 'train', d)
+        assert np.abs(out[b].double().numpy() - ref).max() < 5e-6, (augment, b)
+        one, _ = process_batch(cams[b], tokens[b], augment, 'train', draws={k: v[b:b + 1] for k, v in draws.items()})   # [S,7] form
+        assert torch.equal(one, out[b])
+    assert (out[..., 3] >= 0).all() and ((out[..., 3:] ** 2).sum(-1) - 1).abs().max() < 1e-5
+    if augment == 'relative':                                    # the evaluators' frame change is the same map (evaluate_transformer.py:70-78)
+        assert torch.allclose(out, mg.normalize_cameras(mg.to_relative_cameras(cams)[0]), atol=1e-6)
+        assert out[:, 0, :3].abs().max() < 1e-6 and (out[:, 0, 3:] - torch.tensor([1.0, 0, 0, 0])).abs().max() < 1e-6
+    if augment in ('simple', 'advanced'):
+        same, _ = process_batch(cams, tokens, augment, 'test')   # outside the training split nothing is drawn (:37-38)
+        base, _ = process_batch(cams, tokens, 'no', 'train')
+        assert torch.equal(same, base) and not torch.allclose(out, base)
+        assert set(draws) == ({'shift', 'y0', 'x', 'y1'} if augment == 'simple' else {'shift', 'y0'})
+        assert float(draws['y0'].max()) < 2 * math.pi and ('x' not in draws or float(draws['x'].max()) < math.pi / 8)
+        a, _ = process_batch(cams, tokens, augment, 'train', generator=torch.Generator().manual_seed(9))
+        b_, _ = process_batch(cams, tokens, augment, 'train', generator=torch.Generator().manual_seed(9))
+        assert torch.equal(a, b_)
+        # a rigid change of the world frame: distances between the views' positions are untouched
+        assert torch.allclose(torch.cdist(out[..., :3], out[..., :3]), torch.cdist(cams[..., :3], cams[..., :3]), atol=1e-4)
+    with pytest.raises(ValueError):
+        process_batch(cams, tokens, 'fancy', 'train')
+
+
 def test_oracle_adam_weight_decay_step():
     from oracle import train_oracle as to
     from viewformer_amd.config import MIGTConfig
@@ -223,6 +276,41 @@ def test_train_steps_follow_the_optimizer_restatement(dev):
         # Adam normalises by sqrt(v): a coordinate whose true gradient is ~0 (e.g. the key bias of c_attn — softmax is
         # invariant to it) moves by +-lr on rounding noise alone, in the reference too; allow that much absolute slack.
         assert diff < 2e-3 * ref.abs().max().item() + 0.2 * lr_sum, (k, diff)
+
+
+@pytest.mark.gpu
+def test_optimizer_state_round_trip_and_finetune_schedule(dev):
+    """resume: weights + Adam moments + iteration count restored into a fresh trainer continue bit-identically; finetune
+    (finetune_transformer.py:76-86): the new schedule starts its warm-up at the restored count while Adam's bias correction goes on"""
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer, learning_rate
+    cfg, sd, tokens, poses, tr = _setup(True, dev)
+    for _ in range(3):
+        tr.train_step(poses, tokens)
+    w, o = tr.state_dict(), tr.optimizer_state_dict()
+    assert o['iterations'] == 3 and o['lr_offset'] == 0 and o['m/wte.weight'].shape == w['wte.weight'].shape
+    full = dict(sd)
+    full.update(w)
+    tr2 = MIGTTrainer(MIGT(cfg, dense_arith='x3h').load_state_dict(full).to(dev), warmup_steps=4).load_optimizer_state_dict(o)
+    assert tr2.step_count == 3
+    a, b = tr.train_step(poses, tokens), tr2.train_step(poses, tokens)
+    assert a['loss'] == b['loss'] and torch.equal(tr.flat_p, tr2.flat_p) and torch.equal(tr.flat_m, tr2.flat_m) and torch.equal(tr.flat_v, tr2.flat_v)
+    bad = dict(o)
+    bad.pop('v/wte.weight')
+    with pytest.raises(RuntimeError):
+        MIGTTrainer(MIGT(cfg, dense_arith='x3h').load_state_dict(full).to(dev)).load_optimizer_state_dict(bad)
+    # finetune: lr(iterations = offset) = 0 -> the first step moves no weight (weight decay is lr-scaled) but feeds the moments
+    tr2.begin_finetune(learning_rate=1e-5, total_steps=100, warmup_steps=10)
+    assert tr2.lr_offset == 4 and tr2.cfg.total_steps == cfg.total_steps
+    p0, m0 = tr2.flat_p.clone(), tr2.flat_m.clone()
+    tr2.train_step(poses, tokens)
+    assert torch.equal(tr2.flat_p, p0) and not torch.equal(tr2.flat_m, m0) and tr2.step_count == 5
+    tr2.train_step(poses, tokens)
+    lr = learning_rate(5, 1e-5, 100, 10, offset=4)
+    assert abs(lr - 1e-6) < 1e-18
+    d = (tr2.flat_p - p0).abs().max().item()
+    assert 0 < d <= 4.0 * lr * (1.0 + cfg.weight_decay * p0.abs().max().item())          # an Adam step is O(lr) per element: the finetune rate, not the 1e-3 of the run before
+    assert tr2.optimizer_state_dict()['lr_offset'] == 4
 
 
 @pytest.mark.gpu

@@ -42,7 +42,7 @@ def conv_s2(n_img=224, C=128, H=128, x6=True, x3h=False):
     print(f'conv3x3 s2{" x3h" if x3h else " x6" if x6 else ""} {C}->{C} @{H}^2->{Ho}^2 x{n_img}: {ms:.3f} ms  {2.0 * M * C * C * 9 / ms / 1e9:.1f} TF')
 
 
-def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
+def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False, io16=False):
     x = torch.randn(n_img * H * H, C, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
     if os.environ.get('VF_MB_ZERO') == '1':           # zero operands: no datapath toggling -> how much of the time is power (DVFS)?
@@ -56,10 +56,13 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False):
         m, s = ops.groupnorm_stats(x, g, n_img, H * H, C)
         prol = (m, s, torch.zeros(C, device=dev))
     M = n_img * H * H
+    if io16:                                          # bf16 activations in / out (the decoder's act16 stream)
+        x = x.to(torch.bfloat16)
+        out = torch.empty_like(x)
     ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
-                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16, x3h=x3h))
+                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16, x3h=x3h, a16=io16, o16=io16))
     fl = 2.0 * M * C * C * 9
-    print(f'conv3x3{" x3h" if x3h else " x6" if x6 else " bf16" if bf16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
+    print(f'conv3x3{" x3h" if x3h else " x6" if x6 else " bf16" if bf16 else ""}{" io16" if io16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 
 
 def gemm(M=7168, K=768, N=3072, epi=0, arith='f32'):
@@ -335,6 +338,8 @@ def clockprobe(n_img=56, C=128, H=128):
 ALL = dict(clockprobe=clockprobe,
            convbf16=lambda: conv(32, 128, 128, bf16=True), convbf16_64=lambda: conv(32, 128, 64, bf16=True),
            convbf16_256=lambda: conv(32, 256, 32, bf16=True), convbf16_dec=lambda: conv(128, 128, 128, bf16=True), convbf16_dec_nopro=lambda: conv(128, 128, 128, bf16=True, pro=False), convbf16_dec512=lambda: conv(128, 512, 16, bf16=True),
+           convbf16_io16=lambda: conv(128, 128, 128, bf16=True, io16=True), convbf16_io16_nopro=lambda: conv(128, 128, 128, bf16=True, io16=True, pro=False),
+           convbf16_io16_64=lambda: conv(128, 128, 64, bf16=True, io16=True), convbf16_io16_256=lambda: conv(128, 256, 32, bf16=True, io16=True),
            attnbf16=lambda: attn(bf16=True), attnx6=lambda: attn(x6=True), attnfp8=lambda: attn(fp8=True), attnbf16_io16=lambda: attn(bf16=True, a16=True), attn_stamps=attn_stamps, attn_stamps_s20=lambda: attn_stamps(12, 12, 21, 19),
            attnbf16_train=lambda: attn(B=10, H=12, S=30, bf16=True, a16=True, twin=-10),
            attnbf16_s20=lambda: attn(B=12, S=21, twin=19, bf16=True), attnfp8_s20=lambda: attn(B=12, S=21, twin=19, fp8=True),

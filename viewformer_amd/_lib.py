@@ -55,7 +55,7 @@ EXPORTS = {
     'vf_conv_in_x3h_pack': (c_int, [P, P, c_int, P]),
     'vf_conv_in_x3h': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_crc32c': (ctypes.c_uint32, [P, c_size_t, ctypes.c_uint32]),
-    'vf_conv3_small_cout_f32': (c_int, [P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'vf_conv3_small_cout_f32': (c_int, [P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'vf_groupnorm_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vf_groupnorm_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
     'vf_groupnorm_finalize_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P]),

@@ -7,6 +7,7 @@
 // through the GroupNorm-apply(+swish) ONCE into LDS (fp32, 36-float pixel stride: conflict-free b128 reads), the chunk's
 // [tap][c][4] weights sit next to it (wave-uniform broadcast reads), and each thread accumulates its pixel's outputs in
 // fp32 fmaf order (chunk, tap, channel).
+#include <type_traits>
 #include "vf_common.h"
 #include "../../include/vf_hip.h"
 
@@ -16,7 +17,8 @@ constexpr int CK = 32, TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW
 constexpr int SLOTS = (NPIX * 8 + 255) / 256;          // float4 staging slots per thread (11)
 constexpr int MAXCO = 4;
 
-template <bool PRO, bool SWISH>
+// IN16 (round 4): the input activation is bf16 NHWC (the bf16-activation decoder, conv3_halo_bf16.hip's IO16): 8 bytes per thread and chunk, widened exactly
+template <bool PRO, bool SWISH, bool IN16 = false>
 __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, const float* __restrict__ pro_mean,
                                                                const float* __restrict__ pro_scale,
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
     const int ty = bid % tilesY;
     const int img = bid / tilesY;
     const int y0 = ty * TH, x0 = tx * TW;
-    const float* __restrict__ X = x + (size_t)img * H * W * Cin;
+    const float* __restrict__ X = IN16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(x) + (size_t)img * H * W * Cin)
+                                       : x + (size_t)img * H * W * Cin;
     const int c4 = tid & 7;
     const int px = tid & 31, py = tid >> 5;
     const int nchunks = Cin / CK;
@@ -62,7 +65,18 @@ __global__ __launch_bounds__(256) void conv3_small_cout_kernel(const float* __re
     f32x4 preg[SLOTS];
     auto fetch = [&](int chunk) {
 #pragma unroll
-        for (int q = 0; q < SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + s_off[q] + chunk * CK);
+        for (int q = 0; q < SLOTS; ++q) {
+            if constexpr (IN16) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(X) + s_off[q] + chunk * CK);
+                preg[q][0] = __builtin_bit_cast(float, w[0] << 16);
+                preg[q][1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                preg[q][2] = __builtin_bit_cast(float, w[1] << 16);
+                preg[q][3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+            } else {
+                preg[q] = *reinterpret_cast<const f32x4*>(X + s_off[q] + chunk * CK);
+            }
+        }
     };
     fetch(0);
 
@@ -121,7 +135,7 @@ extern "C" {
 
 int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bias, const float* pro_mean,
                             const float* pro_scale, const float* pro_beta, int pro_swish, float* out, int n_img, int H, int W,
-                            int Cin, int Cout, void* stream) {
+                            int Cin, int Cout, int x_bf16, void* stream) {
     if (!x || !w_oihw || !out || n_img <= 0 || H <= 0 || W <= 0) return VF_ERR_BAD_ARG;
     if (Cout < 1 || Cout > MAXCO || Cin % CK != 0 || H % TH != 0 || W % TW != 0) return VF_ERR_UNSUPPORTED;
     if ((pro_mean || pro_scale || pro_beta) && !(pro_mean && pro_scale && pro_beta)) return VF_ERR_BAD_ARG;
@@ -129,24 +143,22 @@ int vf_conv3_small_cout_f32(const float* x, const float* w_oihw, const float* bi
     hipStream_t s = (hipStream_t)stream;
     const size_t wsm = (size_t)(Cin / CK) * 9 * CK * MAXCO * sizeof(float);
     if (wsm > 96 * 1024) return VF_ERR_UNSUPPORTED;
-    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
-    if (vf_attr_needed(&attr_devs)) {                                        // static patch (49 KB) + dynamic weights exceed the default 64 KB
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return (int)e;
-        vf_attr_done(&attr_devs);
-    }
-    if (!pro_mean)
-        hipLaunchKernelGGL((conv3_small_cout_kernel<false, false>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
-                           pro_beta, out, H, W, Cin, Cout);
-    else if (pro_swish)
-        hipLaunchKernelGGL((conv3_small_cout_kernel<true, true>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
-                           pro_beta, out, H, W, Cin, Cout);
-    else
-        hipLaunchKernelGGL((conv3_small_cout_kernel<true, false>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale,
-                           pro_beta, out, H, W, Cin, Cout);
-    return vf_last_status();
+    auto launch = [&](auto pro, auto swish, auto in16) -> int {
+        constexpr bool P = decltype(pro)::value, S = decltype(swish)::value, I = decltype(in16)::value;
+        static unsigned long long attr_devs = 0;      // per instantiation; bit d: raised on device d (static patch 49 KB + dynamic weights > 64 KB)
+        if (vf_attr_needed(&attr_devs)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_small_cout_kernel<P, S, I>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(&attr_devs);
+        }
+        hipLaunchKernelGGL((conv3_small_cout_kernel<P, S, I>), grid, dim3(256), wsm, s, x, w_oihw, bias, pro_mean, pro_scale, pro_beta, out, H, W, Cin, Cout);
+        return vf_last_status();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (!pro_mean) return x_bf16 ? launch(F_{}, F_{}, T_{}) : launch(F_{}, F_{}, F_{});
+    if (pro_swish) return x_bf16 ? launch(T_{}, T_{}, T_{}) : launch(T_{}, T_{}, F_{});
+    return x_bf16 ? launch(T_{}, F_{}, T_{}) : launch(T_{}, F_{}, F_{});
 }
 
 }  // extern "C"

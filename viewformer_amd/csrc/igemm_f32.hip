@@ -311,7 +311,7 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 
 extern "C" {
 
-int vf_abi_version(void) { return 17; }
+int vf_abi_version(void) { return 18; }
 
 // ---- kernel selection (include/vf_hip.h): process-wide switches between kernels whose results the tests assert BIT-IDENTICAL.  The library
 // reads no environment variable (tests/test_abi.py checks that it does not even import the libc call); a host that wants an environment override

@@ -258,6 +258,9 @@ VF_REG_FLAG(VQF_X_NORERANK)
 #ifdef VQF_X_STAGGER
 VF_REG_FLAG(VQF_X_STAGGER)
 #endif
+#if defined(VF_W2_ABL) && VF_W2_ABL
+VF_REG_FLAG(VF_W2_ABL)
+#endif
 #ifdef VF_X3H_STAMPS
 VF_REG_FLAG(VF_X3H_STAMPS)
 #endif

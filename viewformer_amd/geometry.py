@@ -36,6 +36,21 @@ def quaternion_rotate(point, q):
     return quaternion_multiply(quaternion_multiply(q, p), quaternion_conjugate(q))[..., 1:]
 
 
+def make_quaternion(axis, angle):
+    """geometry_tf.py:16-21: (cos(a/2), sin(a/2) * axis); angle [...], axis [3] -> [...,4]"""
+    angle = torch.as_tensor(angle)
+    axis = torch.as_tensor(axis, dtype=angle.dtype, device=angle.device)
+    return torch.cat([torch.cos(angle / 2)[..., None], torch.sin(angle / 2)[..., None] * axis], -1)
+
+
+def make_quaternion_y(angle):
+    return make_quaternion([0.0, 1.0, 0.0], angle)              # geometry_tf.py:24-27
+
+
+def make_quaternion_x(angle):
+    return make_quaternion([1.0, 0.0, 0.0], angle)              # geometry_tf.py:30-33
+
+
 def to_relative_cameras(cameras):
     """evaluate_transformer.py:70-78 -> (relative cameras, transform of the first view)"""
     xyz, quat = cameras[..., :3], cameras[..., 3:]

@@ -332,12 +332,19 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     if gn_part is not None:
         a.gn_part = _f32(gn_part).data_ptr()
         a.gn_slots = gn_part.shape[1]
-    if a16 or o16:                            # bf16 activations in / out: the bf16 GEMM only (dtype flags in reserved0)
-        if not bf16 or mode != MODE_GEMM:
-            raise _lib.VfError('a16 / o16 need bf16=True, mode GEMM')
+    conv16 = False
+    if a16 or o16:                            # bf16 activations in / out: the bf16 arm only (dtype flags in reserved0)
+        if not bf16 or mode not in (MODE_GEMM, MODE_CONV3_S1, MODE_CONV3_UP2):
+            raise _lib.VfError('a16 / o16 need bf16=True and a GEMM or 3x3 stride-1 / upsample convolution')
         _chk(x, torch.bfloat16 if a16 else torch.float32, 'x')
         _chk(out, torch.bfloat16 if o16 else torch.float32, 'out')
         a.reserved0 = (1 if a16 else 0) | (2 if o16 else 0)
+        conv16 = mode != MODE_GEMM
+        if conv16:                            # vf_conv3_halo_bf16: bf16 out means a bf16 residual too (the same activation stream)
+            if a16 and not o16:
+                raise _lib.VfError('the bf16 convolution takes bf16 activations in only together with bf16 out')
+            if res is not None:
+                _chk(res, torch.bfloat16 if o16 else torch.float32, 'res')
     if drop is not None and drop[0]:
         if not (bf16 and a16 and not o16 and mode == MODE_GEMM and epilogue == EPI_NONE):
             raise _lib.VfError('drop needs the bf16 GEMM with bf16 x, fp32 out and no epilogue function')
@@ -348,7 +355,7 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
             raise _lib.VfError('res16 is the bf16 pre-activation of EPI_GELU_BWD (bf16 in, bf16 out)')
         _chk(res, torch.bfloat16, 'res')
         a.reserved0 |= 4
-    for t in ((None if a16 else x), (None if o16 else out), bias, (None if res16 else res)):
+    for t in ((None if a16 else x), (None if o16 else out), bias, (None if (res16 or conv16) else res)):
         if t is not None:
             _f32(t)
     if x3h:                                   # w_packed = pack_conv3_x3h / pack_dense_*_x3h: the 3-product split-fp16 kernels
@@ -383,15 +390,16 @@ def conv3_small_cout_supported(mode, Cin, Cout, H, W):
 
 
 def conv3_small_cout(x, w_oihw, bias, n_img, H, W, Cin, Cout, pro=None, pro_swish=True, out=None):
-    """3x3 conv to <= 4 channels (decoder conv_out) with the fused GroupNorm(+swish) prologue; x NHWC rows"""
+    """3x3 conv to <= 4 channels (decoder conv_out) with the fused GroupNorm(+swish) prologue; x NHWC rows, fp32 or bf16"""
     lib = _lib.load()
     if out is None:
         out = torch.empty((n_img * H * W, Cout), dtype=torch.float32, device=x.device)
     pm, ps, pb = (None, None, None) if pro is None else pro
-    check(lib.vf_conv3_small_cout_f32(_p(_f32(x)), _p(_f32(w_oihw)), _p(_f32(bias)) if bias is not None else None,
+    x16 = x.dtype == torch.bfloat16
+    check(lib.vf_conv3_small_cout_f32(_p(x if x16 else _f32(x)), _p(_f32(w_oihw)), _p(_f32(bias)) if bias is not None else None,
                                       _p(pm) if pm is not None else None, _p(ps) if ps is not None else None,
                                       _p(pb) if pb is not None else None, 1 if pro_swish else 0, _p(out), n_img, H, W, Cin, Cout,
-                                      _stream()), 'vf_conv3_small_cout_f32')
+                                      1 if x16 else 0, _stream()), 'vf_conv3_small_cout_f32')
     return out
 
 

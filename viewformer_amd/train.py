@@ -51,13 +51,64 @@ def parse_schedule(s, total_steps=None):
     return sch.with_total_steps(total_steps) if total_steps is not None else sch
 
 
-def learning_rate(step, init_lr, total_steps, warmup_steps):
-    """WarmUp(CosineDecay) of create_optimizer (models/utils.py:310-361,403-412); ``step`` = optimizer.iterations"""
+def learning_rate(step, init_lr, total_steps, warmup_steps, offset: int = 0):
+    """WarmUp(CosineDecay) of create_optimizer (models/utils.py:310-361,403-412); ``step`` = optimizer.iterations; ``offset`` = WarmUp.offset
+    (models/utils.py:337,341: the schedule counts from there — set by the finetune driver to the restored iteration count)"""
+    step = max(step - offset, 0)
     if warmup_steps and step < warmup_steps:
         return init_lr * (step / warmup_steps)
     decay_steps = max(total_steps - warmup_steps, 1)
     t = min(step - warmup_steps, decay_steps)
     return init_lr * 0.5 * (1.0 + math.cos(math.pi * t / decay_steps))
+
+
+def pose_augmentation_draws(augment: str, n_scenes: int, generator=None, dtype=torch.float32):
+    """the random numbers one ``process_batch`` call per scene consumes (train_transformer.py:39-52): a dict of per-scene tensors —
+    'shift' [n,3] ~ N(0,1); 'y0' / 'y1' [n] ~ U(0, 2 pi) and 'x' [n] ~ U(0, pi / 8) for 'simple'; 'y0' only for 'advanced'.  The reference draws
+    from TensorFlow's global generator, so the stream itself cannot be reproduced — the distributions and their use are what is mirrored."""
+    if augment not in ('simple', 'advanced'):
+        return {}
+    def uni(hi):
+        return torch.rand((n_scenes,), generator=generator, dtype=dtype) * hi
+    d = dict(shift=torch.randn((n_scenes, 3), generator=generator, dtype=dtype), y0=uni(2 * math.pi))
+    if augment == 'simple':
+        d.update(x=uni(math.pi / 8), y1=uni(2 * math.pi))
+    return d
+
+
+def process_batch(cameras, tokens, augment: str, split: str, draws=None, generator=None):
+    """The token dataset's per-sequence transform (viewformer/train/train_transformer.py:28-61, mapped over every sampled sequence by
+    load_token_dataset, data/tfrecord_dataset.py:177-184): ``cameras`` [S,7] or [B,S,7] (xyz + quaternion w,x,y,z) -> the poses the
+    model trains on.  'relative': the first view becomes the frame (:31-36); 'no', or any mode outside the training split: unchanged
+    (:37-38); 'simple': a random shift and a random rotation Ry * (Rx * Ry) of the whole scene (:39-50); 'advanced': shift + Ry (:51-55);
+    then the quaternions are normalised and sign-fixed (:60-61).  One set of random numbers per sequence, as in the reference (its
+    shapes are (1, 3) / (1,): broadcast over the sequence's views).  ``draws`` = pose_augmentation_draws(...) to make a call reproducible."""
+    cameras = torch.as_tensor(cameras)
+    single = cameras.dim() == 2
+    cam = cameras[None] if single else cameras
+    xyz, quaternion = cam[..., :3], cam[..., 3:]
+    if augment == 'relative':
+        rotation_inverse = geometry.quaternion_conjugate(quaternion[..., :1, :])
+        xyz = geometry.quaternion_rotate(xyz - xyz[..., :1, :], rotation_inverse)
+        quaternion = geometry.quaternion_multiply(rotation_inverse, quaternion)
+    elif augment == 'no' or split != 'train':
+        pass
+    elif augment in ('simple', 'advanced'):
+        d = draws if draws is not None else pose_augmentation_draws(augment, cam.shape[0], generator, cam.dtype)
+        d = {k: v.to(cam.device, cam.dtype) for k, v in d.items()}
+        xyz = xyz + d['shift'][:, None, :]
+        rotation = geometry.make_quaternion_y(d['y0'])
+        if augment == 'simple':
+            rotation = geometry.quaternion_multiply(rotation, geometry.quaternion_multiply(geometry.make_quaternion_x(d['x']),
+                                                                                            geometry.make_quaternion_y(d['y1'])))
+        rotation = rotation[:, None, :]
+        xyz = geometry.quaternion_rotate(xyz, rotation)
+        quaternion = geometry.quaternion_multiply(quaternion, rotation)
+    else:
+        raise ValueError(f'Augment {augment} is not supported')
+    quaternion = geometry.quaternion_remove_sign(geometry.quaternion_normalize(quaternion))
+    out = torch.cat([xyz, quaternion], -1)
+    return (out[0] if single else out), tokens
 
 
 # dropout sites (the `site` word of the counter-based mask): one per Dropout layer instance of the reference
@@ -95,6 +146,8 @@ class MIGTTrainer:
         self.warmup_steps, self.b1, self.b2, self.eps = warmup_steps, beta1, beta2, eps
         self.group = process_group
         self.step_count = 0                          # optimizer.iterations == model._train_counter
+        self.lr_offset = 0                           # WarmUp.offset (models/utils.py:337): begin_finetune() moves it
+        self.lr_init, self.lr_total_steps = cfg.learning_rate, cfg.total_steps     # create_optimizer's arguments (train_transformer.py)
         self.loc_weight = parse_schedule(cfg.localization_weight, cfg.total_steps)
         self._layout()
         self._bind()
@@ -774,7 +827,7 @@ class MIGTTrainer:
     def apply_gradients(self):
         c = self.cfg
         step = self.step_count
-        lr = learning_rate(step, c.learning_rate, c.total_steps, self.warmup_steps)
+        lr = learning_rate(step, self.lr_init, self.lr_total_steps, self.warmup_steps, self.lr_offset)
         t = step + 1
         lr_adam = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         if self.fused_optimizer:
@@ -795,3 +848,44 @@ class MIGTTrainer:
 
     def state_dict(self):
         return {n: self.p(n).detach().cpu().clone() for n in self.names}
+
+    # ------------------------------------------------------------------ resume / finetune (the optimizer half of a checkpoint)
+    def optimizer_state_dict(self):
+        """what ``model.load_weights(checkpoint)`` restores beside the weights (finetune_transformer.py:76-85: "this restores the model and
+        the optimizer"): Adam's first / second moments per parameter, optimizer.iterations and the schedule's offset"""
+        sd = {'iterations': int(self.step_count), 'lr_offset': int(self.lr_offset)}
+        for n in self.names:
+            a, b, s = self.slices[n]
+            sd['m/' + n] = self.flat_m[a:b].view(s).detach().cpu().clone()
+            sd['v/' + n] = self.flat_v[a:b].view(s).detach().cpu().clone()
+        return sd
+
+    def load_optimizer_state_dict(self, sd, strict: bool = True):
+        want = {p + n for n in self.names for p in ('m/', 'v/')}
+        have = {k for k in sd if k.startswith(('m/', 'v/'))}
+        if strict and want != have:
+            raise RuntimeError(f'optimizer state: missing {sorted(want - have)[:4]}, unexpected {sorted(have - want)[:4]}')
+        for n in self.names:
+            a, b, s = self.slices[n]
+            for pre, flat in (('m/', self.flat_m), ('v/', self.flat_v)):
+                if pre + n in sd:
+                    t = torch.as_tensor(sd[pre + n], dtype=torch.float32)
+                    if tuple(t.shape) != tuple(s):
+                        raise RuntimeError(f'optimizer state {pre}{n}: shape {tuple(t.shape)} != {tuple(s)}')
+                    flat[a:b] = t.reshape(-1).to(self.dev)
+        self.step_count = int(sd.get('iterations', self.step_count))
+        self.lr_offset = int(sd.get('lr_offset', self.lr_offset))
+        return self
+
+    def begin_finetune(self, learning_rate: float = 1e-5, total_steps: int = None, warmup_steps: int = 2000):
+        """viewformer/train/finetune_transformer.py:76-86: a NEW schedule (the finetune learning rate — default 1e-5, :22 — over the finetune
+        run's ``total_steps`` with 2000 warm-up steps) on the RESTORED optimizer (moments and iteration count kept: Adam's bias correction goes
+        on from the restored count), with the schedule's origin moved to that count (``lr_schedule.offset.assign(optimizer.iterations)``).
+        Call after load_state_dict / load_optimizer_state_dict; config overrides (pose_multiplier, localization_weight, ... :57-70) are made
+        on the model's config before the trainer is built, as the reference makes them before load_model."""
+        self.lr_init = float(learning_rate)          # (the model's config keeps its own total_steps: the localization-weight schedule, migt.py:268)
+        if total_steps is not None:
+            self.lr_total_steps = int(total_steps)
+        self.warmup_steps = int(warmup_steps)
+        self.lr_offset = int(self.step_count)
+        return self

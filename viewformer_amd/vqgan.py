@@ -193,8 +193,11 @@ class VQGAN:
         torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ building blocks (NHWC rows)
-    def _conv3(self, x, name, n, H, W, mode=ops.MODE_CONV3_S1, pro=None, pro_swish=True, res=None):
+    def _conv3(self, x, name, n, H, W, mode=ops.MODE_CONV3_S1, pro=None, pro_swish=True, res=None, o16=False):
+        """``o16``: write the output as bf16 (bf16 arm, halo-kernel shapes only); a bf16 ``x`` is read as such.  The activation stream
+        switches to bf16 once (at the 16 -> 32 upsample convolution, see _run_plan) and stays bf16 to conv_out."""
         c = self._conv[name]
+        a16 = x.dtype == torch.bfloat16
         if mode == ops.MODE_CONV3_S2PAD:
             Ho, Wo = H // 2, W // 2
         elif mode == ops.MODE_CONV3_UP2:
@@ -204,10 +207,13 @@ class VQGAN:
         if res is None and ops.conv3_small_cout_supported(mode, c.cin, c.cout, Ho, Wo):      # conv_out (-> 3 channels)
             self._stats_of = None
             return ops.conv3_small_cout(x, c.w_raw, c.bias, n, H, W, c.cin, c.cout, pro=pro, pro_swish=pro_swish), Ho, Wo
-        out = torch.empty((n * Ho * Wo, c.cout), dtype=torch.float32, device=x.device)
+        o16 = o16 or a16
+        out = torch.empty((n * Ho * Wo, c.cout), dtype=torch.bfloat16 if o16 else torch.float32, device=x.device)
         # the 8x8 stage (512 channels, first 11 convs of the decoder) stays fp32 even in the bf16 arm: rounding there is
         # amplified by every later layer (8.3e-2 max pixel error with it in bf16 vs 4.6e-2 without) and it is ~1 ms of work
         bf16 = (c.wp16 is not None and mode in (ops.MODE_CONV3_S1, ops.MODE_CONV3_UP2) and Ho % 8 == 0 and Wo % 16 == 0)
+        if o16 and not bf16:
+            raise ops._lib.VfError(f'{name}: bf16 activations need the bf16 convolution arm (halo-kernel shape)')
         x3h = (not bf16 and c.wp3h is not None and ops.conv3_x3h_supported(mode, c.cin, c.cout, Ho, Wo)
                and not (mode == ops.MODE_CONV3_S2PAD and pro is not None))
         x6 = (not bf16 and not x3h and c.wp6 is not None and ops.conv3_x6_supported(mode, c.cin, c.cout, Ho, Wo)
@@ -218,18 +224,22 @@ class VQGAN:
         if (bf16 or x6 or x3h) and self.fuse_gn_stats and c.cout in (128, 256, 512, 1024):
             part = ops.new_gn_part(n, Ho, Wo, x.device)
         ops.igemm(x, c.wp16 if bf16 else c.wp3h if x3h else c.wp6 if x6 else c.wp, n * Ho * Wo, c.cin, c.cout, out, bias=c.bias, res=res,
-                  mode=mode, pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6, x3h=x3h, gn_part=part)
+                  mode=mode, pro=pro, pro_swish=pro_swish, Hin=H, Win=W, Hout=Ho, Wout=Wo, bf16=bf16, x6=x6, x3h=x3h, gn_part=part,
+                  a16=a16, o16=o16)
         self._stats_of = (out, part) if part is not None else None
         return out, Ho, Wo
 
     def _conv1(self, x, name, M, pro=None, pro_swish=False, rows_per_img=0, res=None):
         c = self._conv[name]
-        out = torch.empty((M, c.cout), dtype=torch.float32, device=x.device)
+        a16 = x.dtype == torch.bfloat16           # a bf16 activation stream (nin_shortcut of the 64x64 level): bf16 in, bf16 out
+        out = torch.empty((M, c.cout), dtype=x.dtype, device=x.device)
         bf16 = c.wp16 is not None and pro is None
+        if a16 and not (bf16 and res is None):
+            raise ops._lib.VfError(f'{name}: bf16 activations need the plain bf16 GEMM')
         x3h = not bf16 and c.k == 1 and c.wp3h is not None
         x6 = not bf16 and not x3h and c.wp6 is not None
         ops.igemm(x, c.wp16 if bf16 else c.wp3h if x3h else c.wp6 if x6 else c.wp, M, c.cin, c.cout, out, bias=c.bias, res=res, pro=pro,
-                  pro_swish=pro_swish, pro_rows_per_img=rows_per_img, bf16=bf16, x6=x6, x3h=x3h)
+                  pro_swish=pro_swish, pro_rows_per_img=rows_per_img, bf16=bf16, x6=x6, x3h=x3h, a16=a16, o16=a16)
         return out
 
     def _gn(self, x, name, n, HW, C):
@@ -237,10 +247,16 @@ class VQGAN:
         if self._stats_of is not None and self._stats_of[0] is x:
             mean_c, scale_c = ops.groupnorm_finalize(self._stats_of[1], gamma, n, HW, C, 32, 1e-6)
         else:
+            if x.dtype != torch.float32:
+                raise ops._lib.VfError(f'{name}: a bf16 activation carries its GroupNorm statistics from the producing kernel (fuse_gn_stats)')
             mean_c, scale_c = ops.groupnorm_stats(x, gamma, n, HW, C, 32, 1e-6)
         return (mean_c, scale_c, beta)
 
     _stats_of = None          # (tensor, partials) of the most recent halo-conv output
+    # bf16 arm only: R > 0 = bf16 activations between the decoder's layers from resolution R x R up (see _run_plan).  Default 128: the last
+    # level holds 6 of the decoder's 9.5 ms and costs one uint8 level of the stated bound (max 7 -> 8, mean |err| 4.4e-3 -> 4.6e-3;
+    # R = 32: max 10, 5.3e-3 — tests/test_hip_bf16.py); 0 = fp32 activations throughout (the round-3 form)
+    decoder_act16 = 128
     fuse_gn_stats = True
     fused_attention = True    # AttnBlock core in one kernel where the shape allows (False: batched GEMMs + row softmax, kept for A/B)
 
@@ -302,7 +318,11 @@ class VQGAN:
             elif kind == 'down':
                 x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_S2PAD)
             elif kind == 'up':
-                x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_UP2)
+                # decoder_act16 = R > 0: from the first upsample whose output is R x R or larger (R >= 32) the activations stay bf16 in HBM
+                # to conv_out; the stages below keep fp32 activations
+                o16 = (self.decoder_act16 and self.decoder_precision == 'bf16' and self.fuse_gn_stats and name.startswith('decoder.')
+                       and H * 2 >= max(32, int(self.decoder_act16)) and (H * 2) % 8 == 0 and (W * 2) % 16 == 0)
+                x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_UP2, o16=o16)
             elif kind == 'norm_swish':
                 self._pending_pro = self._gn(x, name, n, H * W, args[0])   # folded into the next conv
         return x, H, W
