@@ -123,18 +123,23 @@ def x3h_stamps(n_img=56, C=128, H=128):
     m, s = ops.groupnorm_stats(x, g, n_img, H * H, C)
     slots = ops.halo_gn_slots(H, H) if hasattr(ops, 'halo_gn_slots') else (H // 8) * (H // 16) * 2
     nwg = n_img * (H // 8) * (H // 16) * (C // 128)
-    extra = (nwg * 8 + slots * 64 - 1) // (slots * 64)
+    extra = (nwg * 16 + slots * 64 - 1) // (slots * 64)
     part = torch.zeros(n_img + extra, slots, 32, 2, device=dev)
     M = n_img * H * H
     for _ in range(3):
         ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=(m, s, torch.zeros(C, device=dev)), pro_swish=True,
                   Hin=H, Win=H, Hout=H, Wout=H, x3h=True, gn_part=part)
     torch.cuda.synchronize()
-    t = part.view(-1)[n_img * slots * 64:].view(torch.int32)[:nwg * 8].cpu().numpy().view(np.uint32).reshape(nwg, 4, 2).astype(np.float64)
+    t = part.view(-1)[n_img * slots * 64:].view(torch.int32)[:nwg * 16].cpu().numpy().view(np.uint32).reshape(nwg, 4, 4).astype(np.float64)
     nch = C // 32
     print(f'x3h conv {C}->{C} @{H}^2 x{n_img}: {nwg} workgroups, {nch} chunks of 18 stages (216 MFMAs = 6912 pipe cycles per wave per chunk)')
     print('  stage loop   per chunk: mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 0].mean() / nch, np.percentile(t[:, :, 0], 10) / nch, np.percentile(t[:, :, 0], 90) / nch))
     print('  barrier wait per chunk: mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 1].mean() / nch, np.percentile(t[:, :, 1], 10) / nch, np.percentile(t[:, :, 1], 90) / nch))
+    print('  tile head (first patch: load, transform, park, barrier): mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 2].mean(), np.percentile(t[:, :, 2], 10), np.percentile(t[:, :, 2], 90)))
+    print('  epilogue (residual, stores accepted):                    mean %7.0f  p10 %7.0f  p90 %7.0f' % (t[:, :, 3].mean(), np.percentile(t[:, :, 3], 10), np.percentile(t[:, :, 3], 90)))
+    tot = t[:, :, 0] + t[:, :, 1] + t[:, :, 2] + t[:, :, 3]
+    print('  share of a wave\'s tile time: loop %.3f  barrier %.3f  head %.3f  epilogue %.3f  (tile %.0f cycles)' % (
+        t[:, :, 0].sum() / tot.sum(), t[:, :, 1].sum() / tot.sum(), t[:, :, 2].sum() / tot.sum(), t[:, :, 3].sum() / tot.sum(), tot.mean()))
 
 
 def gemm_tf(M=65536, only=None):

@@ -492,7 +492,8 @@ __global__ __launch_bounds__(128, 2) void conv3_halo_bf16_w2_kernel(vf_igemm_arg
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
-        if (!(VF_W2_ABL & 16)) patch_load(min(chunk + 1, nchunks - 1));
+        const bool more = chunk + 1 < nchunks;               // (the four-wave kernel re-stages the last chunk once more instead of branching)
+        if (!(VF_W2_ABL & 16) && more) patch_load(chunk + 1);
         a_load(aring[0], patch, 0);
         if (VF_W2_ABL & 2) a_load(aring[1], patch, 1);
 #pragma unroll
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(128, 2) void conv3_halo_bf16_w2_kernel(vf_igemm_arg
                     else acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[s & 1][mi], bring[s % RB][j], acc[mi][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (!(VF_W2_ABL & 16) && (s & 1) && (s >> 1) < SLOTS) patch_store_slot((chunk + 1) & 1, s >> 1);
+            if (!(VF_W2_ABL & 16) && (s & 1) && (s >> 1) < SLOTS && more) patch_store_slot((chunk + 1) & 1, s >> 1);
         }
         __syncthreads();
     }

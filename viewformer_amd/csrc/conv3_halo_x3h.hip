@@ -40,6 +40,9 @@
 #endif                    // then needs 2 weight fragments through the L1 -> VGPR return path instead of 4 (and 8 activation fragments
                           // from LDS instead of 4).  PMC of the 2 x 2 form (profiles/r2_conv_x3h_l1path_pmc.txt): TD (the vector-memory
                           // data-return unit) 92 % busy, TA 71 %, matrix pipe 54 % — the return path was the bound, LDS had 4x headroom.
+#ifndef VF_X3H_SKIP_LAST
+#define VF_X3H_SKIP_LAST 1  // the last chunk of a tile has no successor to stage: branch around the patch loads and the transform + split slots (the
+#endif                      // round-1..3 form re-staged the last chunk into the idle buffer: a fifth staging per four at 128 channels)
 #ifndef VF_X3H_PRECISE_SWISH
 #define VF_X3H_PRECISE_SWISH 0
 #endif
@@ -257,20 +260,24 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
+#ifdef VF_X3H_STAMPS      // per-wave cycle sums (tools/microbench.py x3h_stamps): stage loop vs the wait at the chunk barrier; the tile's head and epilogue
+    unsigned long long st_t[3], st_k[4];
+    unsigned st_acc[2] = {0, 0};
+#define X3H_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t[i]) :: "memory")
+#define X3H_KSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k[i]) :: "memory")
+#else
+#define X3H_STAMP(i)
+#define X3H_KSTAMP(i)
+#endif
+    X3H_KSTAMP(0);
     patch_load(0);
 #pragma unroll
     for (int g = 0; g < BD; ++g) b_load(bring[g], g);
 #pragma unroll
     for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
     __syncthreads();
+    X3H_KSTAMP(1);
 
-#ifdef VF_X3H_STAMPS      // per-wave cycle sums (tools/microbench.py x3h_stamps): stage loop vs the wait at the chunk barrier
-    unsigned long long st_t[3];
-    unsigned st_acc[2] = {0, 0};
-#define X3H_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t[i]) :: "memory")
-#else
-#define X3H_STAMP(i)
-#endif
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         X3H_STAMP(0);
         const unsigned char* patch = smem_h + (chunk & 1) * G::BUF;
@@ -282,7 +289,10 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 #ifdef VF_X3H_X_NOPATCH      // ablation: what do the next chunk's patch loads (HBM latency in front of the in-order vmcnt queue) cost?
         if (chunk == 0)
 #endif
-        patch_load(min(chunk + 1, nchunks - 1));
+        // A/B on one MI355X box, skip vs re-stage: 128 ch @128^2 365 vs 362 TF, @64^2 372 vs 365, stride 2 301 vs 295, 256 ch @32^2 equal; the
+        // 8x8 pair form LOSES 2 % (367 vs 374) and the upsampling form spills with the branch: both keep the old order
+        const bool more = !VF_X3H_SKIP_LAST || UP2 || PAIR || chunk + 1 < nchunks;
+        if (more) patch_load(min(chunk + 1, nchunks - 1));
         if (AD) a_load(aring[0], patch, 0);
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
             }
             // the next chunk's patch: one staging slot per odd stage (transform + split in the MFMA shadow)
             if (VF_X3H_SB == 1 || VF_X3H_SB == 3) __builtin_amdgcn_sched_barrier(0);
-            if ((s & 1) && (s >> 1) >= VF_X3H_STORE && (s >> 1) - VF_X3H_STORE < G::SLOTS) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X3H_STORE);
+            if ((s & 1) && (s >> 1) >= VF_X3H_STORE && (s >> 1) - VF_X3H_STORE < G::SLOTS && more) patch_store_slot((chunk + 1) & 1, (s >> 1) - VF_X3H_STORE);
             if (VF_X3H_SB == 2) __builtin_amdgcn_sched_barrier(0);
         }
         X3H_STAMP(1);
@@ -320,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
 #endif
     }
 
+    X3H_KSTAMP(2);
     // out = (acc + accx * 2^-11) / S with S the power-of-two weight scale stored behind the packed planes
     const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nchunks * 9 * nb * TAP_BYTES);
 #pragma unroll
@@ -330,10 +341,14 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_x3h_kernel(vf_igemm_args p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(accx[i][j][r], 4.8828125e-4f, acc[i][j][r]) * inv_s;
     vf_halo_epilogue_t<PAIR, MI, NJ>(p, acc, img, img1, y0, x0, PAIR ? 0 : (ty * tilesX + tx) * 2, nblk, wave_m, wave_n, half, l31);
 #ifdef VF_X3H_STAMPS      // behind the GroupNorm partials of the launch (the caller sizes gn_part for it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the epilogue's stores have been accepted)
+    X3H_KSTAMP(3);
     if (p.gn_part && lane == 0) {
-        unsigned* o = reinterpret_cast<unsigned*>(p.gn_part + (size_t)n_img_total * p.gn_slots * 64) + ((size_t)blockIdx.x * 4 + wave) * 2;
+        unsigned* o = reinterpret_cast<unsigned*>(p.gn_part + (size_t)n_img_total * p.gn_slots * 64) + ((size_t)blockIdx.x * 4 + wave) * 4;
         o[0] = st_acc[0];
         o[1] = st_acc[1];
+        o[2] = (unsigned)(st_k[1] - st_k[0]);
+        o[3] = (unsigned)(st_k[3] - st_k[2]);
     }
 #endif
 }
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
 #ifdef VF_X3H_X_NOPATCH
         if (chunk == 0)
 #endif
-        patch_load(min(chunk + 1, nchunks - 1));
+        if (!VF_X3H_SKIP_LAST || chunk + 1 < nchunks) patch_load(min(chunk + 1, nchunks - 1));
         __syncthreads();
         a_load(aring[0], 0);
 #pragma unroll
@@ -572,10 +587,16 @@ __global__ void pack_conv_x3h_kernel(const float* __restrict__ w, _Float16* __re
 template <bool UP2, bool PRO, bool SWISH, bool PAIR>
 int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
     using G = Geo<UP2, PAIR>;
-    const size_t smem = (size_t)2 * G::BUF;
+#ifndef VF_X3H_LDS_PAD
+#define VF_X3H_LDS_PAD 0    // probe: extra LDS bytes per workgroup (> 28 KB: one workgroup per CU, i.e. one wave per SIMD — profiles/r4_power_ceiling_probe.txt)
+#endif
+    const size_t smem = (size_t)2 * G::BUF + VF_X3H_LDS_PAD;
     const int n_img = a.M / (a.Hout * a.Wout);
     const long long blocks = PAIR ? (long long)((n_img + 1) / 2) * (a.Cout / BN)
                                   : (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+#if VF_X3H_LDS_PAD
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_x3h_kernel<UP2, PRO, SWISH, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
     hipLaunchKernelGGL((conv3_halo_x3h_kernel<UP2, PRO, SWISH, PAIR>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
     return vf_last_status();
 }

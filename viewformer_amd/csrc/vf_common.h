@@ -261,6 +261,9 @@ VF_REG_FLAG(VQF_X_STAGGER)
 #if defined(VF_W2_ABL) && VF_W2_ABL
 VF_REG_FLAG(VF_W2_ABL)
 #endif
+#if defined(VF_X3H_LDS_PAD) && VF_X3H_LDS_PAD
+VF_REG_FLAG(VF_X3H_LDS_PAD)
+#endif
 #ifdef VF_X3H_STAMPS
 VF_REG_FLAG(VF_X3H_STAMPS)
 #endif
