@@ -37,6 +37,10 @@ import torch  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, f32 in)
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / f16 / non-scaled fp8 MFMA peak
 HBM_PEAK_GBS = 8000.0
+# measured, not a contract peak: what a loop of nothing but 16-bit MFMAs sustains on full-entropy operands before the package power limit
+# (tools/mfma16_peak.hip, profiles/r4_power_ceiling_probe.txt; 2440 on operands that do not toggle)
+F16_MFMA_POWER_LIMITED_TFLOPS = 1722.0
+BF16_MFMA_POWER_LIMITED_TFLOPS = 1839.0
 
 # HBM traffic of the dominant launch: NOT measured in this run (PMC counters need rocprofv3) — taken from the committed PMC pass of a
 # 56-image launch of the same kernel and shape (2 * FETCH_SIZE with the gfx950 unit correction + WRITE_SIZE) and scaled by pixels
@@ -575,7 +579,10 @@ def main():
                         'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                         'frac': round(ach / peak, 4),
                         'peak_note': (f'algorithmic fp32 TFLOP/s; peak = dense 16-bit MFMA peak 2500 / {nprod} partial products. Executed '
-                                      f'16-bit rate {round(nprod * ach, 1)} TFLOP/s; the native f32 MFMA peak is {F32_MFMA_PEAK_TFLOPS}'
+                                      f'16-bit rate {round(nprod * ach, 1)} TFLOP/s; the native f32 MFMA peak is {F32_MFMA_PEAK_TFLOPS}.  On full-entropy '
+                                      f'operands the matrix pipe alone draws the package power limit at {F16_MFMA_POWER_LIMITED_TFLOPS} TFLOP/s (f16; '
+                                      f'bf16 {BF16_MFMA_POWER_LIMITED_TFLOPS}; profiles/r4_power_ceiling_probe.txt): the executed rate is '
+                                      f'{round(nprod * ach / (F16_MFMA_POWER_LIMITED_TFLOPS if nprod == 3 else BF16_MFMA_POWER_LIMITED_TFLOPS), 3)} of that'
                                       if x6 else 'dense f32 MFMA peak'),
                         'traffic': (round(pmc_bytes_per_pixel * dom_key[1]) if pmc_bytes_per_pixel else None),
                         'traffic_unit': 'bytes/launch',
