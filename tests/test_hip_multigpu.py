@@ -79,3 +79,47 @@ def test_two_rank_launch_line_on_one_gpu_over_gloo():
     assert c['gradient_dtype_on_the_links'] == 'f32'
     half = _launch(['--workload', 'train', '--steps', '2', '--warmup', '1', '--batch', '2', '--grad-dtype', 'bf16'], n=2, backend='gloo')
     assert half['config']['collective']['gradient_dtype_on_the_links'] == 'bf16' and half['value'] > 0
+
+
+RCCL_ONE = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{sys.argv[2]}', rank=0, world_size=1)
+assert dist.get_backend() == 'nccl'
+from viewformer_amd import sharding
+dev = torch.device('cuda:0')
+flat = torch.randn(3_000_001, device=dev)
+ref = flat.clone()
+assert sharding.allreduce_sum_ranges(flat, [(0, 1000)], None) == []        # (the product skips the collective when there is one rank)
+hs = [dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, async_op=True)      # ... so issue its calls directly: the trainer's per-layer ranges
+      for a, b in [(0, 1000), (1000, 2_000_000), (2_000_000, 3_000_001)]]
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):                                   # kernels on another stream while the collectives are in flight
+    x = torch.randn(2048, 2048, device=dev); y = x @ x
+b16 = flat[:4096].to(torch.bfloat16)
+h16 = dist.all_reduce(b16, op=dist.ReduceOp.SUM, async_op=True)  # the bf16-bucket form
+for h in hs:
+    h.wait()
+h16.wait()
+torch.cuda.synchronize()
+assert torch.equal(flat, ref) and torch.equal(b16, ref[:4096].to(torch.bfloat16))      # a SUM over one rank
+sharding.barrier()
+assert sharding.max_over_ranks(1.25, dev) == 1.25
+assert sharding.sum_over_ranks(3.0, dev) == 3.0
+parts = sharding.gather_to_rank0(torch.arange(12, device=dev).view(4, 3))
+assert len(parts) == 1 and parts[0].shape == (4, 3)
+dist.destroy_process_group()
+print('rccl-one ok', flush=True)
+'''
+
+
+def test_rccl_communicator_of_one_rank_runs_the_products_collectives():
+    """No box here has two GPUs, so RCCL never sees N > 1 in this suite; what CAN be checked on one GPU is that the image's RCCL creates a
+    communicator under the product's environment (HSA_ENABLE_IPC_MODE_LEGACY=0, device bound before init) and executes the collectives the
+    product issues — per-range async SUM all-reduces of the flat gradient buffer (fp32 and bf16 buckets) beside kernels on another stream,
+    barrier, max-over-ranks — with the arithmetic of a one-rank sum.  (The 2-rank launch tests above run wherever >= 2 GPUs exist.)"""
+    r = subprocess.run([sys.executable, '-c', RCCL_ONE, REPO, str(_port())], cwd=REPO, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and 'rccl-one ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
