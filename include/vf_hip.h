@@ -48,13 +48,15 @@ const char* vf_build_arch(void);          /* "gfx950" */
 int vf_build_flags(void);
 const char* vf_build_flag_name(int i);
 /* Kernel selection for A/B runs and parity tests.  The library reads NO environment variable; the only run-time switches are these, and each
- * chooses between two kernels whose results the tests assert bit-identical (tests/test_hip_bf16.py, tests/test_train.py) — no switch changes a
- * result.  Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}, all default to 1. */
+ * chooses between two kernels whose results the tests assert bit-identical (tests/test_hip_bf16.py, tests/test_train.py) — VF_SEL_CONV_X3H_K32
+ * excepted, whose two kernels are held to the same fp32-equivalence bound and the same reference tokens instead.  Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}, all default to 1. */
 enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA ring kernel where it applies, 0 = register-staged kernel */
        VF_SEL_GEMM_G256 = 1,         /* vf_gemm_bf16: 1 = 256-tile LDS-DMA kernel where it applies, 0 = 128-tile kernel */
        VF_SEL_LN_BWD_TWO_ROWS = 2,   /* vf_layernorm_bwd_f32: 1 = two rows of a wave in flight, 0 = one */
        VF_SEL_ATTN_Q32 = 3,          /* the LDS-DMA attention kernel: 1 = 8 waves x 32 queries per workgroup, 0 = 4 waves x 64 queries */
-       VF_SEL_COUNT = 4 };
+       VF_SEL_CONV_X3H_K32 = 4,      /* vf_conv3_halo_x3h, stride 1: 1 = the v_mfma_f32_16x16x32_f16 kernel where it applies, 0 = the 32x32x16 kernel.  The ONE
+                                      * switch whose two sides differ in the last bits (another accumulation order; same fp32-equivalence bound) */
+       VF_SEL_COUNT = 5 };
 int vf_select(int which, int value);
 int vf_selected(int which);
 

@@ -46,8 +46,20 @@ FLIP_MARGIN_MAX = 2e-4
 FLIP_RATE_MAX = 1e-3        # and at most 0.1 % of tokens
 
 
-@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h'])
+@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h', 'x3h/32x32x16'])
 def test_token_flip_rate_on_20k_reference_tokens(dev, arith):
+    """'x3h' runs the stride-1 convolutions on the 16x16x32 MFMA kernel (the default), 'x3h/32x32x16' on the 32x32x16 one
+    (vf_select(VF_SEL_CONV_X3H_K32, 0)): two accumulation orders, the same tokens"""
+    from viewformer_amd import _lib
+    k32 = 0 if arith.endswith('32x32x16') else 1
+    _lib.select(_lib.SEL_CONV_X3H_K32, k32)
+    try:
+        _token_flip_rate(dev, arith.split('/')[0], arith)
+    finally:
+        _lib.select(_lib.SEL_CONV_X3H_K32, 1)
+
+
+def _token_flip_rate(dev, arith, label):
     from viewformer_amd.config import VQGANConfig
     from viewformer_amd.vqgan import VQGAN
     from viewformer_amd.weights import make_vqgan_weights, synthetic_scene_batch
@@ -63,7 +75,7 @@ def test_token_flip_rate_on_20k_reference_tokens(dev, arith):
     bad = codes != ref
     flips = [dict(token=int(i), ref=int(ref.reshape(-1)[i]), got=int(codes.reshape(-1)[i]), runner_up=int(runner.reshape(-1)[i]),
                   ref_margin=float(margin.reshape(-1)[i])) for i in np.flatnonzero(bad.reshape(-1))]
-    _report(test='token_flip_rate', arith=arith, tokens=int(ref.size), flips=len(flips), flip_rate=len(flips) / ref.size,
+    _report(test='token_flip_rate', arith=label, tokens=int(ref.size), flips=len(flips), flip_rate=len(flips) / ref.size,
             tokens_with_ref_margin_below_1e_4=int((margin < 1e-4).sum()), min_ref_margin=float(margin.min()), detail=flips)
     for f in flips:
         assert f['got'] == f['runner_up'], f'flip to a code that is not the reference runner-up: {f}'

@@ -80,6 +80,51 @@ def test_conv3_halo_x3h_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
     assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
 
 
+@pytest.mark.parametrize('cin,cout,H,pro', [(128, 128, 16, True), (64, 256, 32, False), (128, 128, 64, True), (256, 256, 16, True), (512, 512, 16, False),
+                                            (512, 128, 16, True)])
+def test_conv3_halo_x3h_both_mfma_shapes_meet_the_same_bound(dev, cin, cout, H, pro):
+    """stride-1 halo convolution on v_mfma_f32_16x16x32_f16 (default where it applies: even chunk count, LDS for two workgroups) and on
+    32x32x16 (vf_select(VF_SEL_CONV_X3H_K32, 0)): another accumulation order -> different last bits, the SAME fp32-equivalence bound; the fused
+    GroupNorm partials of both describe what was stored"""
+    from viewformer_amd import ops, _lib
+    res = {}
+    try:
+        for k32 in (1, 0):
+            _lib.select(_lib.SEL_CONV_X3H_K32, k32)
+            res[k32] = _run(dev, 's1', cin, cout, H, pro)
+    finally:
+        _lib.select(_lib.SEL_CONV_X3H_K32, 1)
+    for k32, ((mx3, rms3), (mx32, rms32)) in res.items():
+        print(f'k32={k32} {cin}->{cout} @{H} pro={pro}: x3h max {mx3:.2e} rms {rms3:.2e} | f32 MFMA max {mx32:.2e} rms {rms32:.2e}')
+        assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
+    # outputs + partials of the two kernels on one input
+    n = 2
+    x = (_rand((n, H, H, cin), 41) * 1.3 + 0.1).to(dev)
+    w, b = _rand((cout, cin, 3, 3), 42, 0.08).to(dev), _rand((cout,), 43).to(dev)
+    gamma = (_rand((cout,), 44) * 0.3 + 1).to(dev)
+    wp = ops.pack_conv3_x3h(w)
+    outs, stats = [], []
+    try:
+        for k32 in (1, 0):
+            _lib.select(_lib.SEL_CONV_X3H_K32, k32)
+            out = torch.empty((n * H * H, cout), device=dev)
+            part = ops.new_gn_part(n, H, H, dev)
+            part.fill_(float('nan'))
+            ops.igemm(x, wp, n * H * H, cin, cout, out, bias=b, mode=ops.MODE_CONV3_S1, Hin=H, Win=H, Hout=H, Wout=H, x3h=True, gn_part=part)
+            assert torch.isfinite(part).all()
+            mean_f, scale_f = ops.groupnorm_finalize(part, gamma, n, H * H, cout)
+            mean_s, scale_s = ops.groupnorm_stats(out, gamma, n, H * H, cout)
+            assert (mean_f - mean_s).abs().max().item() < 2e-6 * (1 + mean_s.abs().max().item())
+            assert ((scale_f - scale_s).abs() / scale_s.abs()).max().item() < 5e-6
+            outs.append(out)
+            stats.append((mean_f, scale_f))
+    finally:
+        _lib.select(_lib.SEL_CONV_X3H_K32, 1)
+    assert not torch.equal(outs[0], outs[1])                                    # (two kernels really ran)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-6 * outs[1].abs().max().item()
+    assert (stats[0][0] - stats[1][0]).abs().max().item() < 1e-6 * (1 + stats[1][0].abs().max().item())
+
+
 @pytest.mark.parametrize('xscale,wscale', [(1e-2, 0.05), (300.0, 0.02), (1.0, 1e-4), (1.0, 30.0), (3e-3, 2.0)])
 def test_x3h_holds_over_the_magnitudes_of_the_inference_path(dev, xscale, wscale):
     """un-normalised inputs (no prologue) from 1e-2 to a few hundred and any weight scale (absorbed by the pack-time power of two)"""

@@ -50,6 +50,66 @@ __global__ __launch_bounds__(256, 2) void loop16(float* out, unsigned long long*
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+// the 16x16x32 shape (4 accumulator registers per tile, half the flops per instruction) and operand-reuse orders of the 32x32x16 shape:
+// reuse 0: A and B both change every instruction; 1: B fixed for runs of 4 (the x3h kernel's order: one weight fragment, four pixel fragments);
+// 2: A fixed for runs of 4
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int REUSE, bool SMALL>
+__global__ __launch_bounds__(256, 2) void loop16b(float* out, int iters) {
+    f32x16 acc[4];
+    f32x4 acc4[8];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc4[i][r] = 0.f;
+    u32x4 a[4], b[4];
+    for (int q = 0; q < 4; ++q)
+        for (int e = 0; e < 4; ++e) {
+            unsigned ra = mix(threadIdx.x * 977u + q * 31u + e * 7u + 1u), rb = mix(threadIdx.x * 1361u + q * 17u + e * 3u + 5u);
+            a[q][e] = (ra & 0x83ff83ffu) | 0x38003800u;
+            b[q][e] = (rb & 0x83ff83ffu) | 0x2c002c00u;
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (SMALL) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(u + i) & 3]), __builtin_bit_cast(f16x8, b[(u * 3 + i) & 3]), acc4[i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ia = REUSE == 2 ? (u & 3) : ((u + i) & 3), ib = REUSE == 1 ? (u & 3) : REUSE == 2 ? ((u * 3 + i) & 3) : ((u * 3 + i) & 3);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ia]), __builtin_bit_cast(f16x8, b[ib]), acc[i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(a[q]), "+v"(b[q]));
+        if ((it & 255) == 255) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) for (int e = 0; e < 4; ++e) a[q][e] ^= 0x80008000u;
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc4[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int REUSE, bool SMALL>
+void runb(const char* name, int iters) {
+    float* out; hipMalloc(&out, (size_t)512 * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) loop16b<REUSE, SMALL><<<512, 256>>>(out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int w = 0; w < 3; ++w) loop16b<REUSE, SMALL><<<512, 256>>>(out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    double fl = (double)512 * 4 * iters * 8 * (SMALL ? 8 * 16384.0 : 4 * 32768.0);
+    printf("%-44s random %8.3f ms  %7.1f TF  (%.3f of 2500)\n", name, ms, fl / ms / 1e9, fl / ms / 1e9 / 2500.0);
+    hipFree(out);
+}
+
 template <int NACC, bool BF16>
 void run(const char* name, int blocks, int iters, int mode) {
     float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -77,5 +137,9 @@ int main() {
         run<4, false>("f16 4acc 1w/SIMD", 256, it, mode);
         run<4, true>("bf16 4acc 2w/SIMD", 512, it, mode);
     }
+    runb<0, false>("f16 32x32x16, A and B change every MFMA", it);
+    runb<1, false>("f16 32x32x16, B fixed for runs of 4", it);
+    runb<2, false>("f16 32x32x16, A fixed for runs of 4", it);
+    runb<0, true>("f16 16x16x32 (8 acc)", it);
     return 0;
 }

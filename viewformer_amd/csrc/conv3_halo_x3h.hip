@@ -18,6 +18,7 @@
 // the kernel is bound by that stream, so the gain over x6 is ~1.5x, not 2x).
 // Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,197,249) with
 // GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
+#include <type_traits>
 #include "halo_common.h"
 
 #ifndef VF_X3H_BD
@@ -547,6 +548,286 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same convolution on v_mfma_f32_16x16x32_f16 (round 4).  Why: the kernel above runs at the package power limit (profiles/
+// r4_power_ceiling_probe.txt): a loop of nothing but 32x32x16 MFMAs on full-entropy operands sustains 1.72 - 1.80 PF, the same loop of 16x16x32
+// MFMAs 2.05 PF (+13.6 % on one box) — the deeper-K shape reads and writes HALF the accumulator registers per flop (4 per 16 K flop against 16 per
+// 32 K), and on a kernel whose tile costs a fixed energy that is throughput.  Same workgroup tile (8 x 16 pixels x 128 channels), same LDS patch
+// ([pixel][plane h | l'][32 ch], 144-byte stride), same packed weights (a 16x16x32 B fragment — lane: channel lane & 15, k group lane >> 4 — is
+// (k-step, half) = (group >> 1, group & 1) of the [ks][plane][half][n][8] layout), same wave tile (all 128 pixels x 32 channels).  A wave's 8 x 2
+// accumulator tiles are 16 pixels (one tile row) x 16 channels; one MFMA consumes a whole 32-channel chunk of a tap, so a tap is ONE k-step:
+//   per tap: 4 weight fragments (h, l' x 2 channel tiles; double-buffered one tap ahead), per tile row 2 patch fragments (h, l'; ring of 3, two
+//   rows ahead) feeding 6 MFMAs ordered so that the two products into the cross accumulator are four instructions apart.
+// The accumulation ORDER differs from the 32x32x16 kernel's (32 products per instruction instead of 16, cross terms interleaved differently), so
+// the results differ in the last bits: both are fp32-equivalent to the same bound (tests/test_hip_x3h.py) and both reproduce every one of the
+// 20 480 reference-recorded tokens (tests/test_hip_parity_scale.py).  Stride 1, no pair tiles, an even number of 32-channel chunks.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef X3H16_LB
+#define X3H16_LB 2
+#endif
+
+template <bool PRO, bool SWISH>
+__global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igemm_args p) {
+    using G = Geo<false, false>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][BUF]
+    constexpr int RT = 8, CT = 2;                      // accumulator tiles per wave: tile rows x 16-channel tiles
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, lg = lane >> 4;
+
+    const int nb = p.Cout / BN;
+    const int tilesX = p.Wout / TW, tilesY = p.Hout / TH;
+    int bid = (int)vf_xcd_bid();
+    const int nblk = bid % nb; bid /= nb;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int img = bid / tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int sy0 = y0 - 1, sx0 = x0 - 1;
+    const float* __restrict__ X = p.x + (size_t)img * p.Hin * p.Win * p.Cin;
+    const int nchunks = p.Cin / CK;
+
+    // ---- patch staging: as in the kernel above (8 threads per pixel, 4 channels each; transform + split once per element)
+    const int c4 = tid & 7;
+    unsigned ok_mask = 0;
+    const int lds0 = (tid >> 3) * P_LDB + c4 * 8;
+    int lds_last = 0;
+    // source offset of staging slot q (pixel (tid >> 3) + 32 q of the 10 x 18 patch): recomputed at every chunk's loads instead of held in six
+    // registers (pix / 18 == pix * 3641 >> 16 for pix < 192)
+    int pix0 = tid >> 3;
+    auto slot_src = [&](int q, bool& ok) {
+        const int pix = pix0 + 32 * q;
+        const int pixc = min(pix, (int)G::NPIX);
+        const int pr = (pixc * 3641) >> 16, pc = pixc - pr * G::PW;
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        ok = (pix < G::NPIX) & ((unsigned)sy < (unsigned)p.Hin) & ((unsigned)sx < (unsigned)p.Win);      // (bitwise: no branches around six DMA issues)
+        const int off = (sy * p.Win + sx) * p.Cin;
+        return (ok ? off : 0) + c4 * 4;
+    };
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+        bool ok;
+        (void)slot_src(q, ok);
+        ok_mask |= (unsigned)ok << q;
+        if (q == G::SLOTS - 1) { const int pix = (tid >> 3) + 32 * q; lds_last = (pix < G::NPIX ? pix : G::NPIX) * P_LDB + c4 * 8; }
+    }
+    // The next chunk's RAW patch values do not wait in registers (6 x 4 per thread for a whole chunk: with 128 accumulator registers and the
+    // fragment rings that spilled, and a spill right behind a load waits for HBM): they travel HBM -> LDS by DMA (buffer_load ... lds, 16 bytes per
+    // lane, slot q of wave w at raw_l + q * 4096 + w * 1024) and each thread reads its own 16 bytes back when the slot's turn comes.
+    unsigned char* __restrict__ raw_l = smem_h + 2 * G::BUF;      // [SLOTS][256 threads][16 B] behind the two patch buffers
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+    // the image's GroupNorm-apply parameters for ALL input channels, once, behind the two patch buffers: [mean | scale | beta][Cin] (the kernel
+    // above keeps a chunk's twelve values per thread in registers; here those registers go to the deeper fragment rings)
+    float* __restrict__ pro_l = reinterpret_cast<float*>(smem_h + 2 * G::BUF + G::SLOTS * 4096);
+    if (PRO) {
+        for (int i = tid; i < p.Cin; i += 256) {
+            pro_l[i] = p.pro_mean[(size_t)img * p.Cin + i];
+            pro_l[p.Cin + i] = p.pro_scale[(size_t)img * p.Cin + i];
+            pro_l[2 * p.Cin + i] = p.pro_beta[i];
+        }
+    }
+    int pro_chunk = 0;                                             // the chunk whose patch is in preg
+    auto patch_load = [&](int chunk) {
+        asm volatile("" : "+v"(pix0));                            // (not loop-invariant as far as the compiler knows: no hoisting into registers)
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q) {
+            bool ok;
+            const int off = slot_src(q, ok);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (__attribute__((address_space(3))) void*)(raw_l + q * 4096 + wave * 1024), 16, (unsigned)off * 4u,
+                                                     (unsigned)(chunk * CK * 4), 0, 0);
+        }
+        pro_chunk = chunk;
+    };
+    auto patch_store_slot = [&](int buf, int q) {
+        unsigned char* dst = smem_h + buf * G::BUF + (q == G::SLOTS - 1 ? lds_last : lds0 + q * 32 * P_LDB);
+        f32x4 pmean, pscale, pbeta;
+        if (PRO) {
+            const float* pl = pro_l + pro_chunk * CK + c4 * 4;
+            pmean = *reinterpret_cast<const f32x4*>(pl);
+            pscale = *reinterpret_cast<const f32x4*>(pl + p.Cin);
+            pbeta = *reinterpret_cast<const f32x4*>(pl + 2 * p.Cin);
+        }
+        const f32x4 raw = *reinterpret_cast<const f32x4*>(raw_l + q * 4096 + tid * 16);
+        f16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = raw[e];
+            if (PRO) {
+                t = (t - pmean[e]) * pscale[e] + pbeta[e];
+                if (SWISH) t = VF_X3H_PRECISE_SWISH ? vf_swish(t) : vf_swish_1ulp(t);
+            }
+            _Float16 h, l;
+            split2(((ok_mask >> q) & 1u) ? t : 0.f, h, l);
+            oh[e] = h; ol[e] = l;
+        }
+        *reinterpret_cast<f16x4*>(dst) = oh;
+        *reinterpret_cast<f16x4*>(dst + 64) = ol;
+    };
+
+    // ---- fragments
+    const int a_lane = lm * P_LDB + lg * 16;                       // pixel lm of a tile row, channels 8 lg .. 8 lg + 7 of the chunk
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * TAP_BYTES;
+    const size_t tap_stride = (size_t)nb * TAP_BYTES;
+    const int b_lane = ((lg >> 1) * 4 + (lg & 1)) * (BN * 16) + (wave * 32 + lm) * 16;
+    const int last_tap = nchunks * 9 - 1;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
+    f16x8 bring[2][4];                                              // [tap parity][h ct0, h ct1, l' ct0, l' ct1]
+#ifndef X3H16_AR
+#define X3H16_AR 3
+#endif
+    constexpr int AR = X3H16_AR;                                    // patch-fragment ring: AR - 1 tile rows ahead (AR divides 72)
+    f16x8 aring[AR][2];                                             // [tile-row step % AR][h, l']
+    auto b_load = [&](f16x8 (&dst)[4], int gtap) {
+        const unsigned soff = (unsigned)((size_t)min(gtap, last_tap) * tap_stride);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dst[pl * 2 + ct] = wbuf_load(w_rs, (unsigned)(b_lane + pl * PLANE_BYTES + ct * 256), soff);
+    };
+    auto a_load = [&](f16x8 (&dst)[2], const unsigned char* patch, int step) {       // step = tap * 8 + tile row
+        const int tap = step >> 3, rt = step & 7;
+        const int off = ((rt + tap / 3) * G::PW + tap % 3) * P_LDB;
+        dst[0] = *reinterpret_cast<const f16x8*>(patch + a_lane + off);
+        dst[1] = *reinterpret_cast<const f16x8*>(patch + a_lane + off + 64);
+    };
+
+    f32x4v acc[RT][CT], accx[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    patch_load(0);
+    b_load(bring[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first patch has landed (each thread reads back only its own lanes' bytes)
+    if (PRO) __syncthreads();                                      // the parameter table
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
+    __syncthreads();
+
+    // one 32-channel chunk; P0 = chunk & 1 (nine taps: the weight ring's parity flips per chunk, so the chunk loop is unrolled by two)
+    auto chunk_body = [&](int chunk, auto parity) {
+        constexpr int P0 = decltype(parity)::value;
+        const unsigned char* patch = smem_h + P0 * G::BUF;
+        const bool more = chunk + 1 < nchunks;
+        // (vmcnt retires in issue order: the next tap's weights go out BEFORE the patch loads)
+        b_load(bring[(P0 + 1) & 1], chunk * 9 + 1);
+        // hipcc's s_waitcnt pass does not count the LDS-DMA instructions: behind them every wait it computes for a weight fragment is 6 too strict
+        // and would stall tap 0 / tap 1 on the first DMAs (HBM latency).  Six counted one-dword loads of an L2-resident word sit between the
+        // weights and the DMAs in the queue, so the slack it lacks is spent on them; their values go to an empty asm at tap 2, by which time the
+        // in-order queue has retired them anyway.
+        unsigned pad[G::SLOTS];                                    // (on every chunk: a branch around them would make the pass take the stricter path's count)
+#pragma unroll
+        for (int q = 0; q < G::SLOTS; ++q) pad[q] = __builtin_amdgcn_raw_buffer_load_b32(w_rs, (unsigned)(q * 256), 0u, 0);     // (distinct, not adjacent: six instructions)
+        if (more) patch_load(chunk + 1);
+#pragma unroll
+        for (int i = 0; i < AR - 1; ++i) a_load(aring[i], patch, i);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t > 0) b_load(bring[(P0 + t + 1) & 1], chunk * 9 + t + 1);
+            if (t == 2) {
+#pragma unroll
+                for (int q = 0; q < G::SLOTS; ++q) asm volatile("" :: "v"(pad[q]));
+            }
+            const f16x8 (&B)[4] = bring[(P0 + t) & 1];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int step = t * 8 + rt;
+                if (step + AR - 1 < 72) a_load(aring[(step + AR - 1) % AR], patch, step + AR - 1);
+                const f16x8 ah = aring[step % AR][0], al = aring[step % AR][1];
+                accx[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[0], accx[rt][0], 0, 0, 0);
+                accx[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[1], accx[rt][1], 0, 0, 0);
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[0], acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[1], acc[rt][1], 0, 0, 0);
+                accx[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[2], accx[rt][0], 0, 0, 0);
+                accx[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[3], accx[rt][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t >= 1 && t <= G::SLOTS && more) {                                            // the next chunk's patch, one slot per tap
+                // slot 0 at the end of tap 1: behind its DMA the queue holds 5 more DMAs and tap 2's 4 weight fragments; from tap 2 on the wait
+                // for that tap's weights (issued behind all six DMAs, retired in order) has covered every slot
+                if (t == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                patch_store_slot((P0 + 1) & 1, t - 1);
+            }
+        }
+        __syncthreads();
+    };
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        chunk_body(chunk, std::integral_constant<int, 0>{});
+        chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: out = (acc + accx * 2^-11) / S + bias (+ residual); GroupNorm partials of the stored values (fp64 sums, rounded once)
+    const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nchunks * 9 * nb * TAP_BYTES);
+    // (buffer resources per image + a lane offset + a scalar (tile row, pixel) offset: 64-bit lane addresses for the 32 pixels of a lane cost 64
+    // registers that the chunk loop's rings need)
+    const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * p.Hout * p.Wout * p.ldc, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res + (size_t)img * p.Hout * p.Wout * p.ldr : p.out), 0, 0x7fffffff, 0x00020000);
+    const bool Res = p.res != nullptr;
+    const bool stats = p.gn_part != nullptr;
+    const int cg = p.Cout >> 5;
+    const int tile_slot = (ty * tilesX + tx) * 2;
+    // a lane's tile elements: channel lm of the 16-channel tile, pixels 4 lg .. 4 lg + 3 of tile row rt
+    auto spix = [&](int rt, int r) { return (y0 + rt) * p.Wout + x0 + r; };            // wave-uniform part of the pixel index (the lane adds 4 lg)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = __builtin_fmaf(accx[rt][ct][r], 4.8828125e-4f, acc[rt][ct][r]) * inv_s;
+    __builtin_amdgcn_sched_barrier(0);                         // (the cross accumulators are dead before the residual values arrive)
+    float rr[CT][RT][4];
+    if (Res) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int n = nblk * BN + wave * 32 + ct * 16 + lm;
+            const unsigned rv = (unsigned)(4 * lg * p.ldr + n) * 4u;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rr[ct][rt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, rv, (unsigned)(spix(rt, r) * p.ldr) * 4u, 0));
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int n = nblk * BN + wave * 32 + ct * 16 + lm;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const unsigned ov = (unsigned)(4 * lg * p.ldc + n) * 4u;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {                       // one statistics slot = 4 tile rows
+            vf_gn_acc_t s = 0, q = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rt = sl * 4 + k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[rt][ct][r] + bias;
+                    if (Res) v += rr[ct][rt][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rs, ov, (unsigned)(spix(rt, r) * p.ldc) * 4u, 0);
+                    s += (vf_gn_acc_t)v;
+                    q += (vf_gn_acc_t)v * (vf_gn_acc_t)v;
+                }
+            }
+            if (stats) {
+                for (int o = 1; o < cg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }     // the group's channels (cg <= 16 lanes)
+                s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);                                      // the four pixel groups
+                s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+                if (lg == 0 && (lm & (cg - 1)) == 0) {
+                    float* dst = p.gn_part + ((((size_t)img * p.gn_slots) + tile_slot + sl) * 32 + n / cg) * 2;
+                    dst[0] = (float)s;
+                    dst[1] = (float)q;
+                }
+            }
+        }
+    }
+}
+
 // max |w| over the tensor as the bits of a non-negative float (monotone as unsigned)
 __global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -601,8 +882,34 @@ int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
     return vf_last_status();
 }
 
+// LDS of the 16x16x32 kernel: two patch buffers, the raw-patch landing area, the GroupNorm-apply table; two workgroups must fit a CU (160 KB)
+static inline size_t vf_x3h16_lds_bytes(int pro_cin) { return (size_t)2 * Geo<false, false>::BUF + Geo<false, false>::SLOTS * 4096 + (size_t)3 * pro_cin * 4; }
+
+template <bool PRO, bool SWISH>
+int launch_halo16(const vf_igemm_args& a, hipStream_t stream) {
+    using G = Geo<false, false>;
+    const int n_img = a.M / (a.Hout * a.Wout);
+    const long long blocks = (long long)n_img * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
+    const size_t smem = vf_x3h16_lds_bytes(PRO ? a.Cin : 0);
+    static unsigned long long attr_devs = 0;          // per instantiation; bit d: raised on device d (> 64 KB of dynamic LDS)
+    if (vf_attr_needed(&attr_devs)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_x3h16_kernel<PRO, SWISH>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return (int)e;
+        vf_attr_done(&attr_devs);
+    }
+    hipLaunchKernelGGL((conv3_halo_x3h16_kernel<PRO, SWISH>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
+    return vf_last_status();
+}
+
 template <bool UP2, bool PAIR>
 int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
+    // stride 1, whole 8 x 16 tiles, an even number of 32-channel chunks, GroupNorm groups of <= 16 channels: the 16x16x32 kernel
+    // (vf_select(VF_SEL_CONV_X3H_K32, 0): the 32x32x16 kernel above — fp32-equivalent to the same bound, different last bits)
+    if (!UP2 && !PAIR && (a.Cin / CK) % 2 == 0 && (!a.gn_part || a.Cout / 32 <= 16) && vf_x3h16_lds_bytes(a.pro_mean ? a.Cin : 0) <= 80 * 1024 &&
+        vf_selected(VF_SEL_CONV_X3H_K32)) {
+        if (!a.pro_mean) return launch_halo16<false, false>(a, s);
+        return a.pro_swish ? launch_halo16<true, true>(a, s) : launch_halo16<true, false>(a, s);
+    }
     if (!a.pro_mean) return launch_halo<UP2, false, false, PAIR>(a, s);
     return a.pro_swish ? launch_halo<UP2, true, true, PAIR>(a, s) : launch_halo<UP2, true, false, PAIR>(a, s);
 }
