@@ -617,11 +617,13 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
     // The next chunk's RAW patch values do not wait in registers (6 x 4 per thread for a whole chunk: with 128 accumulator registers and the
     // fragment rings that spilled, and a spill right behind a load waits for HBM): they travel HBM -> LDS by DMA (buffer_load ... lds, 16 bytes per
     // lane, slot q of wave w at raw_l + q * 4096 + w * 1024) and each thread reads its own 16 bytes back when the slot's turn comes.
-    unsigned char* __restrict__ raw_l = smem_h + 2 * G::BUF;      // [SLOTS][256 threads][16 B] behind the two patch buffers
+    // [SLOTS][256 threads][16 B] behind the two patch buffers; the last KB (slot 5 of wave 3: pixels 184 .. 191 of a 180-pixel patch) is not
+    // allocated — with it two workgroups of a 512-channel layer (6 KB of GroupNorm-apply table) would not fit a CU's 160 KB
+    unsigned char* __restrict__ raw_l = smem_h + 2 * G::BUF;
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
     // the image's GroupNorm-apply parameters for ALL input channels, once, behind the two patch buffers: [mean | scale | beta][Cin] (the kernel
     // above keeps a chunk's twelve values per thread in registers; here those registers go to the deeper fragment rings)
-    float* __restrict__ pro_l = reinterpret_cast<float*>(smem_h + 2 * G::BUF + G::SLOTS * 4096);
+    float* __restrict__ pro_l = reinterpret_cast<float*>(smem_h + 2 * G::BUF + G::SLOTS * 4096 - 1024);
     if (PRO) {
         for (int i = tid; i < p.Cin; i += 256) {
             pro_l[i] = p.pro_mean[(size_t)img * p.Cin + i];
@@ -636,6 +638,7 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
         for (int q = 0; q < G::SLOTS; ++q) {
             bool ok;
             const int off = slot_src(q, ok);
+            if (q == G::SLOTS - 1 && wave == 3) continue;         // (no pixel of the patch; its landing KB is the table's)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (__attribute__((address_space(3))) void*)(raw_l + q * 4096 + wave * 1024), 16, (unsigned)off * 4u,
                                                      (unsigned)(chunk * CK * 4), 0, 0);
         }
@@ -749,9 +752,9 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (t >= 1 && t <= G::SLOTS && more) {                                            // the next chunk's patch, one slot per tap
-                // slot 0 at the end of tap 1: behind its DMA the queue holds 5 more DMAs and tap 2's 4 weight fragments; from tap 2 on the wait
-                // for that tap's weights (issued behind all six DMAs, retired in order) has covered every slot
-                if (t == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                // slot 0 at the end of tap 1: behind its DMA the queue holds 5 more DMAs (4 in wave 3) and tap 2's 4 weight fragments; from tap 2
+                // on the wait for that tap's weights (issued behind all the DMAs, retired in order) has covered every slot
+                if (t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 patch_store_slot((P0 + 1) & 1, t - 1);
             }
         }
@@ -883,7 +886,7 @@ int launch_halo(const vf_igemm_args& a, hipStream_t stream) {
 }
 
 // LDS of the 16x16x32 kernel: two patch buffers, the raw-patch landing area, the GroupNorm-apply table; two workgroups must fit a CU (160 KB)
-static inline size_t vf_x3h16_lds_bytes(int pro_cin) { return (size_t)2 * Geo<false, false>::BUF + Geo<false, false>::SLOTS * 4096 + (size_t)3 * pro_cin * 4; }
+static inline size_t vf_x3h16_lds_bytes(int pro_cin) { return (size_t)2 * Geo<false, false>::BUF + Geo<false, false>::SLOTS * 4096 - 1024 + (size_t)3 * pro_cin * 4; }
 
 template <bool PRO, bool SWISH>
 int launch_halo16(const vf_igemm_args& a, hipStream_t stream) {
