@@ -44,7 +44,7 @@ BF16_MFMA_POWER_LIMITED_TFLOPS = 1839.0
 
 # HBM traffic of the dominant launch: NOT measured in this run (PMC counters need rocprofv3) — taken from the committed PMC pass of a
 # 56-image launch of the same kernel and shape (2 * FETCH_SIZE with the gfx950 unit correction + WRITE_SIZE) and scaled by pixels
-PMC_SOURCE = {'x3h': ('profiles/r2_new_kernels_pmc.txt', 466930e3, 458750e3),      # the round-2 kernel (tall tile, buffer loads) 'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
+PMC_SOURCE = {'x3h': ('profiles/r4_conv_x3h16_pmc.txt', 455220e3, 485220e3),      # the round-4 kernel (16x16x32 MFMAs, raw patch by LDS-DMA) 'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
               'f32': ('profiles/r1_conv_halo_pmc.txt', 497520e3, 458750e3)}
 
 
@@ -571,7 +571,7 @@ def main():
     # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / nprod if x6 else F32_MFMA_PEAK_TFLOPS      # dense f16 peak == dense bf16 peak (2.5 PF)
     line['roofline'] = {'bound': 'mfma',
-                        'kernel': ('conv3_halo_x3h_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_32x32x16_f16 '
+                        'kernel': ('conv3_halo_x3h16_kernel<GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_16x16x32_f16 '
                                    'per fp32 product)' if nprod == 3 else
                                    'conv3_halo_x6_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 6x v_mfma_f32_32x32x16_bf16 '
                                    'per fp32 product)' if x6 else

@@ -153,6 +153,8 @@ def gemm_tf(M=65536, only=None):
             continue
         x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
         w = torch.randn(K, N, device=dev) * 0.02
+        if os.environ.get('VF_MB_ZERO') == '1':           # zero operands: how much of the time is the package power limit?
+            x.zero_(); w.zero_()
         wp = ops.pack_dense_kn_bf16(w)
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if o16 else torch.float32)

@@ -264,6 +264,9 @@ VF_REG_FLAG(VF_W2_ABL)
 #if defined(VF_X3H_LDS_PAD) && VF_X3H_LDS_PAD
 VF_REG_FLAG(VF_X3H_LDS_PAD)
 #endif
+#if defined(VF_X3H16_ABL) && VF_X3H16_ABL
+VF_REG_FLAG(VF_X3H16_ABL)
+#endif
 #ifdef VF_X3H_STAMPS
 VF_REG_FLAG(VF_X3H_STAMPS)
 #endif
