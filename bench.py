@@ -44,7 +44,8 @@ BF16_MFMA_POWER_LIMITED_TFLOPS = 1839.0
 
 # HBM traffic of the dominant launch: NOT measured in this run (PMC counters need rocprofv3) — taken from the committed PMC pass of a
 # 56-image launch of the same kernel and shape (2 * FETCH_SIZE with the gfx950 unit correction + WRITE_SIZE) and scaled by pixels
-PMC_SOURCE = {'x3h': ('profiles/r4_conv_x3h16_pmc.txt', 455220e3, 485220e3),      # the round-4 kernel (16x16x32 MFMAs, raw patch by LDS-DMA) 'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
+PMC_SOURCE = {'x3h': ('profiles/r4_conv_x3h16_pmc.txt', 455220e3, 485220e3),      # the round-4 kernel (16x16x32 MFMAs, raw patch by LDS-DMA)
+              'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
               'f32': ('profiles/r1_conv_halo_pmc.txt', 497520e3, 458750e3)}
 
 
