@@ -662,7 +662,8 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
             pscale = *reinterpret_cast<const f32x4*>(pl + p.Cin);
             pbeta = *reinterpret_cast<const f32x4*>(pl + 2 * p.Cin);
         }
-        const f32x4 raw = *reinterpret_cast<const f32x4*>(raw_l + q * 4096 + tid * 16);
+        f32x4 raw = {0.f, 0.f, 0.f, 0.f};                        // (slot 5 of wave 3 has no landing area: pixels 184 .. 191 do not exist)
+        if (!(q == G::SLOTS - 1 && wave == 3)) raw = *reinterpret_cast<const f32x4*>(raw_l + q * 4096 + tid * 16);
         f16x4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
