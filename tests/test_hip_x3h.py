@@ -26,7 +26,7 @@ def _err(out, ref, mag):
     return e.max().item(), e.pow(2).mean().sqrt().item()
 
 
-def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
+def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None, swish=True):
     from viewformer_amd import ops
     n = n or (3 if H == 8 else 2)
     x = _rand((n, cin, H, H), 11) * xscale + 0.2 * xscale
@@ -40,7 +40,8 @@ def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
         mu = mean_c.double().cpu().view(n, cin, 1, 1)
         sc = scale_c.double().cpu().view(n, cin, 1, 1)
         a = (a - mu) * sc + beta.double().view(1, cin, 1, 1)
-        a = a * torch.sigmoid(a)
+        if swish:
+            a = a * torch.sigmoid(a)
     m, Ho = {'s1': (ops.MODE_CONV3_S1, H), 'up': (ops.MODE_CONV3_UP2, 2 * H), 's2': (ops.MODE_CONV3_S2PAD, H // 2)}[mode]
     if mode == 'up':
         a = F.interpolate(a, scale_factor=2.0, mode='nearest')
@@ -54,7 +55,7 @@ def _run(dev, mode, cin, cout, H, pro, xscale=1.5, wscale=0.05, n=None):
     res = _rand((n * Ho * Ho, cout), 16) * wscale * xscale * 10
     ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + b.double() + res.double()
     mag = mag.permute(0, 2, 3, 1).reshape(-1, cout) + b.double().abs() + res.double().abs()
-    kw = dict(bias=b.to(dev), res=res.to(dev), mode=m, pro=prol, pro_swish=True, Hin=H, Win=H, Hout=Ho, Wout=Ho)
+    kw = dict(bias=b.to(dev), res=res.to(dev), mode=m, pro=prol, pro_swish=swish, Hin=H, Win=H, Hout=Ho, Wout=Ho)
     assert ops.conv3_x3h_supported(m, cin, cout, Ho, Ho)
     o3 = torch.empty((n * Ho * Ho, cout), device=dev)
     ops.igemm(xn, ops.pack_conv3_x3h(w.to(dev)), n * Ho * Ho, cin, cout, o3, x3h=True, **kw)
@@ -123,6 +124,19 @@ def test_conv3_halo_x3h_both_mfma_shapes_meet_the_same_bound(dev, cin, cout, H, 
     assert not torch.equal(outs[0], outs[1])                                    # (two kernels really ran)
     assert (outs[0] - outs[1]).abs().max().item() < 2e-6 * outs[1].abs().max().item()
     assert (stats[0][0] - stats[1][0]).abs().max().item() < 1e-6 * (1 + stats[1][0].abs().max().item())
+
+
+@pytest.mark.parametrize('k32', [1, 0])
+def test_conv3_halo_x3h_groupnorm_prologue_without_swish_and_odd_batches(dev, k32):
+    """the GroupNorm-apply prologue without the swish (Normalize alone), 5 images (an odd count of 16 x 16 maps: 10 tiles), on both MFMA shapes"""
+    from viewformer_amd import _lib
+    _lib.select(_lib.SEL_CONV_X3H_K32, k32)
+    try:
+        for cin, cout, H, n in ((128, 128, 16, 5), (64, 128, 32, 1)):
+            (mx3, rms3), (mx32, rms32) = _run(dev, 's1', cin, cout, H, True, n=n, swish=False)
+            assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9, (k32, cin, cout, H, mx3, rms3, rms32)
+    finally:
+        _lib.select(_lib.SEL_CONV_X3H_K32, 1)
 
 
 @pytest.mark.parametrize('xscale,wscale', [(1e-2, 0.05), (300.0, 0.02), (1.0, 1e-4), (1.0, 30.0), (3e-3, 2.0)])
