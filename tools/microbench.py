@@ -59,8 +59,10 @@ def conv(n_img=56, C=128, H=128, pro=True, x6=False, bf16=False, x3h=False, io16
     if io16:                                          # bf16 activations in / out (the decoder's act16 stream)
         x = x.to(torch.bfloat16)
         out = torch.empty_like(x)
-    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=x, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
-                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16, x3h=x3h, a16=io16, o16=io16))
+    part = ops.new_gn_part(n_img, H, H, dev) if os.environ.get('VF_MB_GN') == '1' else None      # fused GroupNorm partials of the output (as in the model)
+    res = None if os.environ.get('VF_MB_NORES') == '1' else x
+    ms = timeit(lambda: ops.igemm(x, wp, M, C, C, out, bias=b, res=res, mode=ops.MODE_CONV3_S1, pro=prol, pro_swish=True,
+                                  Hin=H, Win=H, Hout=H, Wout=H, x6=x6, bf16=bf16, x3h=x3h, a16=io16, o16=io16, gn_part=part))
     fl = 2.0 * M * C * C * 9
     print(f'conv3x3{" x3h" if x3h else " x6" if x6 else " bf16" if bf16 else ""}{" io16" if io16 else ""} {C}->{C} @{H}^2 x{n_img} pro={pro}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF')
 

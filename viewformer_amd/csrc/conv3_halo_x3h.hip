@@ -824,7 +824,9 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
         const unsigned ov = (unsigned)(pbase * p.ldc + n) * 4u;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {                       // one statistics slot = 4 tile rows
-            vf_gn_acc_t s = 0, q = 0;
+            // a lane's 16 values of the slot are summed in fp32 (fixed order; 16 terms: ~1e-6 of the lane's partial, the accuracy of an fp32
+            // GroupNorm) and only the lane partials go through fp64: the all-fp64 form cost 2.5 - 3.3 % of the launch in cvt / add / fma _f64
+            float s32 = 0.f, q32 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int rt = sl * 4 + k;
@@ -833,11 +835,12 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
                     float v = acc[rt][ct][r] + bias;
                     if (Res) v += rr[ct][rt][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rs, ov, (unsigned)(spix(rt, r) * p.ldc) * 4u, 0);
-                    s += (vf_gn_acc_t)v;
-                    q += (vf_gn_acc_t)v * (vf_gn_acc_t)v;
+                    s32 += v;
+                    q32 = __builtin_fmaf(v, v, q32);
                 }
             }
             if (stats) {
+                vf_gn_acc_t s = (vf_gn_acc_t)s32, q = (vf_gn_acc_t)q32;
                 for (int o = 1; o < cg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }     // the group's channels (cg <= 16 lanes)
                 s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);                                      // the four pixel groups
                 s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
