@@ -731,11 +731,12 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
         const bool more = chunk + 1 < nchunks && !(VF_X3H16_ABL & 16);
         // (vmcnt retires in issue order: the next tap's weights go out BEFORE the patch loads)
         b_load(bring[(P0 + 1) & 1], chunk * 9 + 1);
-        // hipcc's s_waitcnt pass does not count the LDS-DMA instructions: behind them every wait it computes for a weight fragment is 6 too strict
-        // and would stall tap 0 / tap 1 on the first DMAs (HBM latency).  Six counted one-dword loads of an L2-resident word sit between the
-        // weights and the DMAs in the queue, so the slack it lacks is spent on them; their values go to an empty asm at tap 2, by which time the
-        // in-order queue has retired them anyway.
-        unsigned pad[G::SLOTS];                                    // (on every chunk: a branch around them would make the pass take the stricter path's count)
+        // The DMAs sit behind `if (more)`; where that branch rejoins, hipcc's s_waitcnt pass takes the STRICTER path's pending count — the one
+        // without the six DMAs — so every wait it then computes for a weight fragment is 6 too strict and would stall tap 0 / tap 1 on the first
+        // DMAs (HBM latency).  Six counted one-dword loads of an L2-resident word, issued on BOTH paths, sit between the weights and the DMAs in
+        // the queue: the slack the pass lacks is spent on them.  Their values go to an empty asm at tap 2, by which time the in-order queue has
+        // retired them anyway.
+        unsigned pad[G::SLOTS];
 #pragma unroll
         for (int q = 0; q < G::SLOTS; ++q) pad[q] = __builtin_amdgcn_raw_buffer_load_b32(w_rs, (unsigned)(q * 256), 0u, 0);     // (distinct, not adjacent: six instructions)
         if (more) patch_load(chunk + 1);
