@@ -567,13 +567,18 @@ def main():
     x6 = args.conv_arith in ('x6', 'x3h')
     nprod = {'x3h': 3, 'x6': 6, 'f32': 1}[args.conv_arith]
     pmc_file, fetch_kb, write_kb = PMC_SOURCE[args.conv_arith]
+    from viewformer_amd import _lib as _vflib
+    k32 = bool(_vflib.load().vf_selected(_vflib.SEL_CONV_X3H_K32))
+    if args.conv_arith == 'x3h' and not k32:
+        pmc_file, fetch_kb, write_kb = 'profiles/r2_new_kernels_pmc.txt', 466930e3, 458750e3      # the 32x32x16 kernel's pass
     is_dom_shape = dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
     pmc_bytes_per_pixel = (2 * fetch_kb + write_kb) * 1.024 / (56 * 128 * 128) if is_dom_shape else None
     # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / nprod if x6 else F32_MFMA_PEAK_TFLOPS      # dense f16 peak == dense bf16 peak (2.5 PF)
     line['roofline'] = {'bound': 'mfma',
-                        'kernel': ('conv3_halo_x3h16_kernel<GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_16x16x32_f16 '
-                                   'per fp32 product)' if nprod == 3 else
+                        'kernel': (('conv3_halo_x3h16_kernel<GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_16x16x32_f16 per fp32 product)'
+                                    if k32 else 'conv3_halo_x3h_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 3x v_mfma_f32_32x32x16_f16 per fp32 '
+                                    'product; vf_select(VF_SEL_CONV_X3H_K32, 0))') if nprod == 3 else
                                    'conv3_halo_x6_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, 6x v_mfma_f32_32x32x16_bf16 '
                                    'per fp32 product)' if x6 else
                                    'conv3_halo_kernel<s1,GN+swish> (3x3 conv 128->128 @128x128, v_mfma_f32_32x32x2_f32)'),
