@@ -386,11 +386,27 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);            // keep the reads ahead of the MFMAs (the scheduler sinks them to their use)
+#ifdef G256_X_K32PROBE      // feasibility probe (WRONG results): the same operand traffic, each 32x32x16 MFMA replaced by two 16x16x32 MFMAs (same flops) on
+            // quarter accumulators — what would the deeper-K shape buy this kernel under the package power limit?
+            typedef float f32x4p __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int qd = (ks & 1) * 2 + h2;
+                        f32x4p c4 = {acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks & 1][i], b[ks & 1][j], c4, 0, 0, 0);
+                        acc[i][j][qd * 4] = c4[0]; acc[i][j][qd * 4 + 1] = c4[1]; acc[i][j][qd * 4 + 2] = c4[2]; acc[i][j][qd * 4 + 3] = c4[3];
+                    }
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 #if G256_A_VIA_REGS

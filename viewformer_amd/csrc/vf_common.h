@@ -267,6 +267,9 @@ VF_REG_FLAG(VF_X3H_LDS_PAD)
 #if defined(VF_X3H16_ABL) && VF_X3H16_ABL
 VF_REG_FLAG(VF_X3H16_ABL)
 #endif
+#ifdef G256_X_K32PROBE
+VF_REG_FLAG(G256_X_K32PROBE)
+#endif
 #ifdef VF_X3H_STAMPS
 VF_REG_FLAG(VF_X3H_STAMPS)
 #endif
