@@ -16,6 +16,8 @@
 // element when the patch is parked in LDS as [pixel][plane h|l'][32 ch] f16 (144-byte pixel stride = 9 x 16 B: conflict-free
 // ds_read_b128 for every tap shift); two weight planes streamed L2 -> VGPR in a register ring (341 B per MFMA vs 256 for x6:
 // the kernel is bound by that stream, so the gain over x6 is ~1.5x, not 2x).
+// Kernels of this file: conv3_halo_x3h_kernel (32x32x16 MFMAs: nearest-x2 form, 8x8 pair tiles, and the vf_select alternative of) conv3_halo_x3h16_kernel
+// (round 4: the stride-1 form on 16x16x32 MFMAs — the default where it applies; see the comment above it), conv3_s2_x3h_kernel (Downsample).
 // Reference call sites: torch.nn.Conv2d 3x3 pad 1 in ResnetBlock / Upsample (vqgan_th.py:23-32,60-70,197,249) with
 // GroupNorm+swish (:11-17,80-85) and the residual add (:90) fused.
 #include <type_traits>
