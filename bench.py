@@ -16,7 +16,7 @@ Other workloads through the same contract (one JSON line, barrier + max-over-ran
   --workload train    BASELINE configs[3]: one data-parallel MIGT training step (CO3D 10-cat finetune: seq 10, 3 streams, 10 scenes
                       per GPU, RCCL gradient all-reduce SUM overlapped with the backward pass); value = scenes/s, whole job
   --workload allimg   BASELINE configs[4]: the all-images evaluator loop (transformer batch 128 / decode batch 64,
-                      evaluate_transformer_multictx_allimg.py:173,177) with fp8 attention; value = generated views/s
+                      evaluate_transformer_multictx_allimg.py:173,177); bf16 attention unless --attention fp8; value = generated views/s
   --views 20 --batch 12   BASELINE configs[2]: 19-view context, image + localization heads
 
 N>1: one process per GPU, scenes sharded (weak scaling: --batch scenes per GPU per step), weights replicated, no data-path
@@ -309,7 +309,8 @@ def run_train(args, rank, local, world, dev):
             'config': {'workload': 'CO3D 10-cat training step, DP scene-batch shard + RCCL grad all-reduce (BASELINE.json configs[3])',
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'streams': 3, 'tokens_per_scene': 3 * S * 64,
                        'parallelism': f'dp{world}: per-replica mean loss, gradients SUMmed (migt.py:471-476,488), all-reduce per layer range '
-                                      'overlapped with the backward pass', 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
+                                      'overlapped with the backward pass', 'ranks': args.dist['ranks'], 'backend': args.dist['backend'],
+                       'communicator_world_size': args.dist['ranks'], 'dist': args.dist, 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
                        'dropout_note': 'the reference trains with MIGTConfig.dropout = 0.1 (models/config.py:66) at four sites (migt.py:72,216,403, '
                                        'branching_attention.py:15-17); counter-based masks recomputed in the backward pass, inside the GEMM '
                                        'epilogues / LayerNorm backward / flash attention kernels of the bf16 arm',
@@ -360,15 +361,54 @@ def run_allimg(args, rank, local, world, dev):
             'value': round(n_img / dt, 3), 'unit': 'generated views/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'fp8 attention / bf16 dense' if tr.attention == 'fp8' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'CO3D-all 128px inference, fp8 MFMA attention, large-batch decode (BASELINE.json configs[4])',
+            'config': {'workload': f'CO3D-all 128px inference, {tr.attention} MFMA attention (the arm this line ran), large-batch decode '
+                                   f'(BASELINE.json configs[4], which names fp8: --attention fp8)',
                        'attention_arm_note': 'configs[4] names fp8; reported arm = bf16 LDS-DMA attention, the faster and tighter one on MI355X '
                                              '(the kernel is softmax-VALU-bound at 64 features per head: e4m3 operands buy no time); '
                                              '--attention fp8 runs the e4m3 tolerance arm',
                        'frames_per_sequence': F, 'views_per_scene': S, 'transformer_batch': ea.TRANSFORMER_BATCH,
                        'decode_batch_scenes': ea.DECODE_BATCH, 'images_decoded_per_step': F * S, 'attention': tr.attention,
-                       'parallelism': f'sequence-shard x{world}, no collective'},
+                       'parallelism': f'sequence-shard x{world}, no collective', 'ranks': args.dist['ranks'],
+                       'backend': args.dist['backend'], 'dist': args.dist},
             'roofline': att or {}}
     print(json.dumps(line), flush=True)
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with no launcher (the driver's command form): start the N ranks here — re-run this command line under
+    ``torch.distributed.run --nnodes=1 --nproc-per-node N`` on 127.0.0.1, rank 0's JSON line passes through on stdout, the exit status is the
+    launcher's.  With fewer visible GPUs than ranks the run is REFUSED (non-zero exit, one line on stderr) instead of measuring one GPU and
+    printing it as N — unless VF_DIST_BACKEND=gloo says that ranks sharing a device is what the caller wants (the 1-GPU test boxes)."""
+    if args.gpus < 1:
+        raise SystemExit(f'bench.py: --gpus {args.gpus}: need at least one rank')
+    if args.gpus == 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return                                                  # one rank, or already inside a launcher's worker
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    backend = os.environ.get('VF_DIST_BACKEND')
+    if ndev < args.gpus and backend != 'gloo':
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to run {args.gpus} ranks (RCCL needs one device per '
+                         f'rank; VF_DIST_BACKEND=gloo lets ranks share a device for plumbing tests only)')
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))   # dmabuf IPC for RCCL
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f'bench.py: no launcher in the environment, starting {args.gpus} ranks: {" ".join(cmd[1:8])} ...\n')
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dist_info(world):
+    """what actually ran, for the line's ``config``: ranks, transport, and the communicator's own world size"""
+    import torch.distributed as dist
+    if world > 1 and dist.is_initialized():
+        return {'ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'launcher': 'torch.distributed.run, one process per rank',
+                'devices_visible': torch.cuda.device_count()}
+    return {'ranks': 1, 'backend': None, 'launcher': 'single process', 'devices_visible': torch.cuda.device_count()}
 
 
 def main():
@@ -417,10 +457,13 @@ def main():
     from viewformer_amd.evaluate import generate_batch_predictions
     from viewformer_amd.weights import synthetic_scene_batch
 
+    self_launch(args)                  # bare `python bench.py --gpus N`: N ranks under torch.distributed.run, or a loud refusal
     rank, local, world = sharding.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree, refusing to print a line '
+                         f'whose n_gpus is not the number of ranks that ran')
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback for the hot path)'
+    args.dist = dist_info(world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if args.workload != 'views':
@@ -496,6 +539,7 @@ def main():
                                 '(BASELINE.json configs[2])'),
                    'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'localization_pass': localization,
                    'target_view_encoded': True, 'parallelism': f'scene-shard x{world}, no collective',
+                   'ranks': args.dist['ranks'], 'backend': args.dist['backend'], 'dist': args.dist,
                    'io': 'inputs (uint8 frames, cameras) resident in HBM when the timed region starts; generated uint8 images stay in HBM '
                          '(see host_io for the rate with the host round trip)',
                    'precision': ('fp32 everywhere' if args.precision == 'f32' else

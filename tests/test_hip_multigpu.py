@@ -81,6 +81,47 @@ def test_two_rank_launch_line_on_one_gpu_over_gloo():
     assert half['config']['collective']['gradient_dtype_on_the_links'] == 'bf16' and half['value'] > 0
 
 
+def _bare(extra, n, backend=None, timeout=420):
+    """the DRIVER's command form: ``python bench.py --gpus N ...`` with no launcher and no WORLD_SIZE / RANK in the environment"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'VF_DIST_BACKEND')}
+    if backend:
+        env['VF_DIST_BACKEND'] = backend
+    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(n)] + extra, cwd=REPO, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(1500, method='thread')
+def test_bare_command_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` (no torch.distributed.run around it) used to run one process and print n_gpus 1.
+    Now the bare command starts the two ranks itself: n_gpus == 2, config.ranks == 2, the transport it really used is in the line —
+    for the inference line and for the training line (whose collective block needs a real process group)."""
+    r = _bare(['--steps', '2', '--warmup', '1', '--batch', '8', '--no-cpu-baseline', '--no-f32-arm'], n=2, backend='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['config']['backend'] == 'gloo'
+    assert line['config']['scenes_per_gpu_per_step'] == 8 and 'x2' in line['config']['parallelism'] and line['value'] > 0
+    r = _bare(['--workload', 'train', '--steps', '2', '--warmup', '1', '--batch', '2'], n=2, backend='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['config']['communicator_world_size'] == 2
+    assert line['config']['collective']['backend'] == 'gloo'
+    r = _bare(['--workload', 'allimg', '--steps', '1', '--warmup', '0', '--batch', '16'], n=2, backend='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason='box has >= 2 GPUs: the bare command may run')
+def test_bare_command_refuses_more_ranks_than_gpus():
+    """on a 1-GPU box, without the gloo plumbing switch, ``--gpus 2`` must fail loudly — not measure one GPU and call it two"""
+    for wl in ([], ['--workload', 'train'], ['--workload', 'allimg']):
+        r = _bare(wl + ['--steps', '1', '--warmup', '0'], n=2, timeout=300)
+        assert r.returncode != 0, wl
+        assert 'refusing' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')], r.stderr[-500:]
+
+
 RCCL_ONE = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
