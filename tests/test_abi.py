@@ -69,7 +69,9 @@ def test_library_reads_no_environment_and_its_switches_are_explicit(lib):
     """No run-time knob can change a result behind the caller's back: libvf_hip.so does not import getenv / secure_getenv at all (round 3
     shipped several per-launch getenv calls, one of which selected a kernel with wrong results); the only run-time switches are
     vf_select's — each between two kernels the GPU tests assert bit-identical, except VF_SEL_CONV_X3H_K32 (two MFMA shapes of the x3h
-    convolution: held to the same fp32-equivalence bound and the same 20 480 reference tokens) — and they validate their arguments."""
+    convolution: held to the same fp32-equivalence bound and the same 20 480 reference tokens) and VF_SEL_ATTN_DMA (the LDS-DMA attention
+    re-rounds a pre-scaled q: within 1e-2 of the register-staged kernel, both inside the bf16 arm's tolerance) — and they validate their
+    arguments."""
     import subprocess
     from viewformer_amd import _lib
     syms = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout

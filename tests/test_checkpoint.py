@@ -114,3 +114,23 @@ def test_load_model_reads_config_overrides_and_refuses_missing_dirs(tmp_path):
     ck.write_tensor_bundle(str(d / 'broken'), ck.state_dict_to_keras(sd))
     with pytest.raises(RuntimeError):
         ck.load_model(str(d / 'broken'))
+
+
+def test_optimizer_slots_key_mapping_roundtrip():
+    """the optimizer half of a compiled model's TF checkpoint: object-graph slot keys <-> the trainer's optimizer state dict"""
+    from viewformer_amd import checkpoint as ck
+    osd = {'iterations': 1234, 'lr_offset': 7, 'm/h.0.attn.c_attn.weight': np.ones((4, 12), np.float32), 'v/h.0.attn.c_attn.bias': np.arange(12, dtype=np.float32),
+           'm/wpe.embeddings': np.zeros((3, 4), np.float32), 'v/ln_f.gamma': np.full((4,), 2.0, np.float32)}
+    k = ck.optimizer_state_to_keras(osd)
+    assert 'h/0/attn/c_attn/weight/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE' in k
+    assert k['h/0/attn/c_attn/bias/.OPTIMIZER_SLOT/optimizer/v/.ATTRIBUTES/VARIABLE_VALUE'].shape == (1, 12)       # Conv1D bias [1, nf] (migt.py:87)
+    assert 'wpe/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE' in k and int(k['optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE']) == 1234
+    back = ck.keras_optimizer_state(k)
+    assert back['iterations'] == 1234 and back['lr_offset'] == 7
+    for key in osd:
+        if key.startswith(('m/', 'v/')):
+            assert np.array_equal(back[key], osd[key]) and back[key].shape == osd[key].shape, key
+    # the weights half ignores the slots, the optimizer half ignores the weights
+    both = dict(ck.state_dict_to_keras({'ln_f.gamma': np.ones(4, np.float32)}), **k)
+    assert list(ck.keras_to_state_dict(both)) == ['ln_f.gamma']
+    assert 'm/ln_f.gamma' not in ck.keras_optimizer_state(both) and 'v/ln_f.gamma' in ck.keras_optimizer_state(both)

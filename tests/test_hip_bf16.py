@@ -204,6 +204,31 @@ def test_decoder_bf16_pixels_within_stated_tolerance_and_tokens_stay_exact(dev, 
     m16.decoder_act16 = 128
 
 
+@pytest.mark.parametrize('ch', [64, 96])
+def test_decoder_bf16_arm_with_a_top_level_the_bf16_activation_stream_cannot_take(dev, ch):
+    """decoder_act16 (default 128) switched the activation stream to bf16 at the last upsample convolution without
+    asking whether the layers behind it can read bf16 — with ch = 64 (top level 64 channels: no bf16 halo packing, no fused GroupNorm
+    statistics) or ch = 96 the decode raised, where round 3's per-layer fp32 fallback ran.  The switch is now decided from the decoder plan
+    (every conv / norm / shortcut up to conv_out must qualify): such configs keep fp32 activations and decode within the bf16 arm's bound."""
+    from oracle import vqgan_oracle as vq
+    from viewformer_amd.config import VQGANConfig
+    from viewformer_amd.vqgan import VQGAN
+    from viewformer_amd.weights import make_vqgan_weights
+    cfg = VQGANConfig(ch=ch, ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[], image_size=128, z_channels=64, embed_dim=64, n_embed=128)
+    sd = make_vqgan_weights(cfg, seed=3, codebook_scale=0.05)
+    codes = torch.from_numpy(np.random.default_rng(5).integers(0, 128, size=(2, 32, 32)))
+    ref = vq.decode_code(sd, cfg, codes, dtype=torch.float64)
+    for R in (128, 64, 32, 0):
+        m = VQGAN(cfg, data_format='NCHW', decoder_precision='bf16').load_state_dict(sd).to(dev)
+        m.decoder_act16 = R
+        dec = m.decode_code(codes.to(dev)).cpu()
+        err = (dec.double() - ref).abs()
+        print(f'ch={ch} decoder_act16={R}: max |pixel err| {err.max():.3e} (mean {err.mean():.2e}), |ref| max {ref.abs().max():.2f}')
+        assert err.max() < ACT16_PIXEL_TOL_ABS * max(1.0, float(ref.abs().max())) and dec.dtype == torch.float32
+    m32 = VQGAN(cfg, data_format='NCHW').load_state_dict(sd).to(dev)
+    assert (m32.decode_code(codes.to(dev)).cpu().double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_pipeline_bf16_arm(dev, full_vq):
     """end to end with both arms on: context tokens bit-exact vs the oracle, logits within the stated tolerance"""
     from oracle import pipeline_oracle as po

@@ -91,6 +91,7 @@ MIXED_LOGIT_TOL_REL = 3e-2      # as tests/test_hip_bf16.py
 MIXED_U8_TOL_LEVELS = 10        # decoder on bf16 MFMA: final image vs the fp32 oracle's decode of the SAME codes
 MIXED_U8_MEAN_LEVELS, MIXED_U8_P99_LEVELS, MIXED_U8_P999_LEVELS = 1.0, 3, 5   # ... and its distribution (measured: mean 0.55, max 6-7)
 MIXED_POSE_TOL = 3e-2           # generated camera (position in scene units / unit quaternion)
+MIXED_POSE_TOL_WIDE = 1.5e-1    # ... at 1.5x the init scale (std 0.03): measured 1.0e-1
 
 
 @pytest.mark.parametrize('std', [0.02, 0.03])     # the reference's init scale (flat logits) and 1.5x it (per-layer gain > 1: errors grow
@@ -140,8 +141,9 @@ def test_mixed_arm_end_to_end_against_oracle(dev, full_vq, std):
     # and against the all-oracle image where the generated codes agree
     full = (got['generated_images'].cpu().int() - ref['generated_images'].int()).abs().float()
     e_cam = _maxerr(got['generated_cameras'], ref['generated_cameras'])
-    if std <= 0.02:
-        assert e_cam < MIXED_POSE_TOL, e_cam
+    # the camera head's error grows with the weight scale like the logits' (measured 0.10 at std 0.03, round 4: reported then, asserted now
+    # with its own stated bound — 5x the init-scale bound, one unit-quaternion component / scene unit in seven)
+    assert e_cam < (MIXED_POSE_TOL if std <= 0.02 else MIXED_POSE_TOL_WIDE), e_cam
     _report(test='mixed_arm_end_to_end', weight_std=std, scenes=B, views=S, logit_rel_err=rel,
             max_abs_logit=float(ref['logits_last'].abs().max()), generated_code_agreement=float(same.float().mean()),
             max_logit_gap_at_disagreement=float(gap.max()), u8_max_diff_same_codes=int(du.max()),

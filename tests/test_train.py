@@ -314,6 +314,41 @@ def test_optimizer_state_round_trip_and_finetune_schedule(dev):
 
 
 @pytest.mark.gpu
+def test_checkpoint_save_then_finetune_entry_point(dev, tmp_path):
+    """the optimizer state reaches a checkpoint and comes back through the finetune entry point.  ``save_training_checkpoint``
+    leaves what the reference's ModelCheckpoint leaves (config.json + one TF-format checkpoint of the compiled model, train/utils.py:46-86);
+    ``finetune_transformer`` (finetune_transformer.py:57-86) loads it with config overrides, restores weights AND Adam state, and starts
+    the finetune schedule at the restored iteration count.  The restored trainer's next step equals the original trainer's next step
+    under the same schedule, bit for bit."""
+    from viewformer_amd import checkpoint as ck
+    from viewformer_amd.train import finetune_transformer, learning_rate
+    cfg, sd, tokens, poses, tr = _setup(True, dev)
+    for _ in range(3):
+        tr.train_step(poses, tokens)
+    prefix = ck.save_training_checkpoint(tr, str(tmp_path / 'job'))
+    assert os.path.exists(prefix + '.index') and os.path.exists(os.path.join(str(tmp_path / 'job'), 'config.json'))
+    ft = finetune_transformer(prefix, total_steps=100, learning_rate=1e-5, device=dev, n_loss_skip=1, pose_multiplier=None)
+    assert ft.step_count == 3 and ft.lr_offset == 3 and ft.warmup_steps == 2000 and ft.lr_init == 1e-5 and ft.lr_total_steps == 100
+    assert ft.cfg.total_steps == cfg.total_steps and ft.cfg.pose_multiplier == cfg.pose_multiplier
+    assert torch.equal(ft.flat_p, tr.flat_p) and torch.equal(ft.flat_m, tr.flat_m) and torch.equal(ft.flat_v, tr.flat_v)
+    tr.begin_finetune(learning_rate=1e-5, total_steps=100, warmup_steps=2000)
+    tr.train_step(poses, tokens)                       # lr(offset) = 0: moments move, weights do not
+    ft.train_step(poses, tokens)
+    a, b = tr.train_step(poses, tokens), ft.train_step(poses, tokens)
+    assert a['loss'] == b['loss'] and torch.equal(ft.flat_p, tr.flat_p) and torch.equal(ft.flat_m, tr.flat_m)
+    assert learning_rate(4, 1e-5, 100, 2000, offset=3) == 1e-5 / 2000
+    # an override changes the model that is built (finetune_transformer.py:57-73) ...
+    ft2 = finetune_transformer(prefix, total_steps=100, device=dev, pose_multiplier=0.05, weight_decay=0.01)
+    assert ft2.cfg.pose_multiplier == 0.05 and ft2.cfg.weight_decay == 0.01 and ft2.step_count == 3
+    # ... and a weights-only checkpoint is accepted like .expect_partial() accepts it: optimizer at its initial state
+    ck.write_tensor_bundle(str(tmp_path / 'job' / 'weights.only'), ck.state_dict_to_keras(tr.state_dict()))
+    ft3 = finetune_transformer(str(tmp_path / 'job' / 'weights.only'), total_steps=100, device=dev)
+    assert ft3.step_count == 0 and float(ft3.flat_m.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ck.restore_optimizer(ft3, str(tmp_path / 'job' / 'weights.only'), strict=True)
+
+
+@pytest.mark.gpu
 def test_per_tensor_gradient_clipping(dev):
     cfg, sd, tokens, poses, tr = _setup(False, dev, clip=1e-3)
     tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
@@ -864,6 +899,46 @@ def test_bf16_training_arm_at_widths_the_tn_kernel_does_not_tile(dev, dropout):
             worst = max(worst, ((grads['bf16'][a:b] - ref).abs().max() / ref.abs().max()).item())
     print(f'd_model 384, dropout {dropout}: bf16 arm vs fp32-equivalent arm, worst per-tensor gradient difference', worst)
     assert worst < BF16_GRAD_TOL, worst
+
+
+@pytest.mark.gpu
+def test_bf16_arm_lm_head_backward_uses_current_weights_when_rows_are_not_a_multiple_of_64(dev):
+    """with d_model and n_embeddings multiples of 256 the bf16 arm keeps bf16 LM-head packings, but the step only uses
+    them when M1 = B*S*L is a multiple of 64; otherwise dH = dlogits @ wte runs on the native transposed packing — which repack() no longer
+    refreshed, so from step 2 on it held step-1 weights with no error raised.  Here M1 = 1*3*16 = 48: after two real optimizer steps the
+    third step's gradients must (a) equal, bit for bit, those of a FRESH trainer built from the updated weights and (b) sit within the bf16
+    arm's tolerance of fp64 autograd over the oracle at those weights."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    from oracle import train_oracle as to
+    cfg = MIGTConfig(n_embeddings=256, n_head=4, d_model=256, n_layer=2, token_image_size=4, sequence_size=3, dropout=0.0, n_loss_skip=1,
+                     localization_weight='2', pose_multiplier=0.2, learning_rate=2e-2, weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=6, std=0.08)
+    g = np.random.Generator(np.random.PCG64(21))
+    B, S = 1, 3
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, 4, 4)))
+    _, cams = synthetic_scene_batch(B, S, 8, 7)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev), warmup_steps=1)
+    assert tr._lm16 is not None and (B * S * 16) % 64 != 0         # bf16 LM-head packings exist, and this batch cannot use them
+    for _ in range(3):
+        tr.train_step(poses, tokens)                               # three updates (the first at warm-up lr 0; lr 2e-2: the weights really move)
+    moved = (tr.state_dict()['wte.weight'].cpu() - torch.as_tensor(sd['wte.weight'])).abs().max().item()
+    assert moved > 1e-2, moved
+    tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    got = tr.flat_g.clone()
+    sd2 = {k: v.cpu().numpy() for k, v in tr.state_dict().items()}
+    fresh = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd2).to(dev), warmup_steps=1)
+    fresh.step_count = tr.step_count
+    fresh.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert torch.equal(got, fresh.flat_g)                          # a stale transposed LM head fails here
+    grads, _ = to.gradients(sd2, cfg, poses, tokens, step=tr.step_count)
+    for name in tr.names:
+        ref = grads[name].reshape(tr.slices[name][2])
+        assert _err(tr.g(name), ref) < BF16_GRAD_TOL, name
 
 
 @pytest.mark.gpu

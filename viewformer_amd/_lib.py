@@ -29,7 +29,8 @@ class VfIgemmArgs(ctypes.Structure):
     ]
 
 
-# kernel-selection switches (include/vf_hip.h: vf_select): each chooses between two kernels with bit-identical results
+# kernel-selection switches (include/vf_hip.h: vf_select): each chooses between two kernels with bit-identical results, except the two
+# tolerance-level pairs SEL_CONV_X3H_K32 and SEL_ATTN_DMA (the DMA attention kernel re-rounds a pre-scaled q: within 1e-2 of the other)
 SEL_ATTN_DMA, SEL_GEMM_G256, SEL_LN_BWD_TWO_ROWS, SEL_ATTN_Q32 = 0, 1, 2, 3
 SEL_CONV_X3H_K32 = 4          # (the one pair that differs in the last bits: 16x16x32 vs 32x32x16 MFMAs in the x3h convolution)
 # developer convenience: these environment variables are translated into vf_select calls ONCE, when the library is loaded (the library
@@ -201,7 +202,7 @@ def load():
 
 
 def select(which, value):
-    """vf_select: switch between two bit-identical kernels (A/B runs, parity tests); returns the previous value"""
+    """vf_select: switch between two kernels (bit-identical pairs, except CONV_X3H_K32 and ATTN_DMA: tolerance-level) for A/B runs and parity tests; returns the previous value"""
     prev = load().vf_select(int(which), 1 if value else 0)
     if prev < 0:
         raise VfError(f'vf_select({which}, {value}): bad argument')

@@ -291,6 +291,78 @@ def state_dict_to_keras(sd: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarr
     return out
 
 
+# ------------------------------------------------------------------------------------------------ optimizer half of a TF checkpoint
+_SLOT = '/.OPTIMIZER_SLOT/optimizer/'
+_OPT_ITER = 'optimizer/iter' + _SUFFIX
+_OPT_OFFSET = 'optimizer/learning_rate/offset' + _SUFFIX
+
+
+def keras_optimizer_state(bundle: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """the optimizer half of ``model.save_weights`` on a compiled model (object-graph keys): Adam's slots
+    ``<variable path>/.OPTIMIZER_SLOT/optimizer/{m,v}/.ATTRIBUTES/VARIABLE_VALUE`` and ``optimizer/iter`` -> the dict
+    ``MIGTTrainer.load_optimizer_state_dict`` takes (``m/<name>``, ``v/<name>``, ``iterations``, ``lr_offset``).  This is what
+    finetune_transformer.py:76-85 relies on when it says "this restores the model and the optimizer"."""
+    out = OrderedDict()
+    for key, arr in bundle.items():
+        if key == _OPT_ITER:
+            out['iterations'] = int(np.asarray(arr).reshape(-1)[0])
+        elif key == _OPT_OFFSET:
+            out['lr_offset'] = int(np.asarray(arr).reshape(-1)[0])
+        elif _SLOT in key and key.endswith(_SUFFIX):
+            var, slot = key[:-len(_SUFFIX)].split(_SLOT)
+            if slot not in ('m', 'v'):
+                continue
+            name = next(iter(keras_to_state_dict({var + _SUFFIX: arr})), None)
+            if name is not None:
+                a = np.asarray(arr, dtype=np.float32)
+                out[f'{slot}/{name}'] = a.reshape(-1) if (name.endswith('.bias') and a.ndim == 2 and a.shape[0] == 1) else a
+    return out
+
+
+def optimizer_state_to_keras(osd: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """inverse of :func:`keras_optimizer_state`"""
+    out = OrderedDict()
+    out[_OPT_ITER] = np.asarray(int(osd.get('iterations', 0)), dtype=np.int64)
+    out[_OPT_OFFSET] = np.asarray(int(osd.get('lr_offset', 0)), dtype=np.int64)
+    for k, arr in osd.items():
+        if not k.startswith(('m/', 'v/')):
+            continue
+        slot, name = k[0], k[2:]
+        var = next(iter(state_dict_to_keras({name: arr})))[:-len(_SUFFIX)]
+        a = np.asarray(arr.detach().cpu().numpy() if hasattr(arr, 'detach') else arr, dtype=np.float32)
+        if name.endswith('.bias') and '.c_' in name:
+            a = a.reshape(1, -1)
+        out[var + _SLOT + slot + _SUFFIX] = a
+    return out
+
+
+def save_training_checkpoint(trainer, job_dir: str, name: str = 'weights.model.000-last') -> str:
+    """what the reference's ``ModelCheckpoint`` callback leaves in ``job_dir`` (train/utils.py:46-86): ``config.json`` (the model's config,
+    :63-69) and ``model.save_weights(job_dir + '/weights.model.<epoch>-last')`` of the COMPILED model — weights and optimizer (Adam moments,
+    iteration count) in one TF-format checkpoint.  Returns the checkpoint prefix ``load_model`` / ``finetune_transformer`` take."""
+    os.makedirs(job_dir, exist_ok=True)
+    with open(os.path.join(job_dir, 'config.json'), 'w') as f:
+        json.dump({k: (v if isinstance(v, (int, float, str, bool, list, type(None))) else str(v))
+                   for k, v in trainer.cfg.asdict().items()}, f)
+    bundle = state_dict_to_keras(trainer.state_dict())
+    bundle.update(optimizer_state_to_keras(trainer.optimizer_state_dict()))
+    prefix = os.path.join(job_dir, name)
+    write_tensor_bundle(prefix, bundle)
+    return prefix
+
+
+def restore_optimizer(trainer, checkpoint: str, strict: bool = True):
+    """``model.load_weights(checkpoint)`` on a compiled model, optimizer half (finetune_transformer.py:84): the trainer was built on
+    ``load_model(checkpoint)``'s weights; this restores Adam's moments and ``optimizer.iterations`` from the same TF-format checkpoint.
+    ``strict=False`` mirrors ``.expect_partial()`` (a weights-only checkpoint leaves the optimizer at its initial state)."""
+    osd = keras_optimizer_state(read_tensor_bundle(checkpoint))
+    if not any(k.startswith(('m/', 'v/')) for k in osd):
+        if strict:
+            raise RuntimeError(f'{checkpoint}: no optimizer slots in this checkpoint')
+        return trainer
+    return trainer.load_optimizer_state_dict(osd, strict=strict)
+
+
 # ------------------------------------------------------------------------------------------------ torch checkpoints
 def read_torch_checkpoint(path: str) -> "OrderedDict[str, np.ndarray]":
     """``torch.load(path)['state_dict']`` (Lightning ``.ckpt``; a bare state dict ``.pth`` is accepted too) as numpy"""

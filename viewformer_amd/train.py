@@ -273,6 +273,9 @@ class MIGTTrainer:
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T (kept fresh for
         if not lm16:                                                                                      # whoever reads the model afterwards)
             self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
+            self._lm_T_stale = False
+        else:
+            self._lm_T_stale = True           # the step's own predicate also needs M1 % 64 == 0: its fallback must re-pack from THESE weights
 
     # ------------------------------------------------------------------ building blocks
     def _linear(self, x, name, M, res=None):
@@ -416,6 +419,7 @@ class MIGTTrainer:
     bf16_lm_head = True               # bf16 arm: the tied LM head (logits, dH, dwte) on the bf16 pipe like every other wide layer (the native-f32
                                       # GEMMs it replaces were 0.8 ms of a 21 ms step); False: native f32 MFMA
     _lm16 = None
+    _lm_T_stale = True
     one_launch_repack = True          # bf16 arm: all weight packings refreshed by one launch per step
     _pack16 = None
     _pack16_keep = None
@@ -567,7 +571,10 @@ class MIGTTrainer:
                   and all(ops.gemm_tn_bf16_shape_ok(M, k_, n_) and ops.gemm_g256_shape_ok(M, n_, k_) for k_, n_ in block_shapes))
         # the LayerNorm backward hands the projection layers' backward GEMMs a bf16 copy of the residual-stream gradient (with dropout: under
         # the consuming layer's output mask, which only the fused form applies there)
-        res16 = grad16 and self.bf16_residual_gradient and self.fuse_gelu_backward and (rate == 0.0 or self.fuse_dropout)
+        # (with dropout the masks ride in layernorm_bwd(drop=...), which indexes 32-bit mask groups: the same bound gemm_drop_supported puts on the
+        # forward — a global batch so large that (M + row0) / 4 * d passes 2^32 falls back to the dropout_add passes instead of raising)
+        res16 = (grad16 and self.bf16_residual_gradient and self.fuse_gelu_backward
+                 and (rate == 0.0 or (self.fuse_dropout and row0 % 4 == 0 and ((M + row0 + 3) // 4) * d < 2 ** 32)))
         drop_of = lambda site: (rate, seed, site, row0)                              # noqa: E731  (elementwise sites: row offset)
         drop_attn = lambda i_: (rate, seed, site_attn(i_), plane0)                   # noqa: E731  (attention: plane offset)
         for i in range(c.n_layer):
@@ -668,8 +675,10 @@ class MIGTTrainer:
             # dwte[:nE] = dlogits^T @ H straight from the row-major operands (the TN kernel: x = dlogits as bf16, dy = H)
             ops.gemm_tn_bf16(dlogits.to(torch.bfloat16), hmask, M1, nE, d, gwte[:nE], None)
         else:
-            if getattr(self, 'lm_T', None) is None:                                   # (bf16_lm_head off, or M1 % 64 != 0, after a repack that
-                self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0)              # skipped it: build the transposed LM-head packing here)
+            if getattr(self, 'lm_T', None) is None or self._lm_T_stale:               # (M1 % 64 != 0 in the bf16 arm: repack() skipped the native
+                self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0,              # transposed packing — build it from the CURRENT weights, every
+                                     out=getattr(self, 'lm_T', None))                 # step: a packing cached from step 1 would be silently stale)
+                self._lm_T_stale = False
             ops.igemm(dlogits, self.lm_T, M1, nE, d, dhm)
             dlt = T.transpose(dlogits, M1, nE)
             hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
@@ -889,3 +898,25 @@ class MIGTTrainer:
         self.warmup_steps = int(warmup_steps)
         self.lr_offset = int(self.step_count)
         return self
+
+
+def finetune_transformer(checkpoint: str, total_steps: int, learning_rate: float = 1e-5, device='cuda', precision: str = 'f32',
+                         process_group=None, **transformer_config) -> MIGTTrainer:
+    """The model-and-optimizer setup of ``viewformer/train/finetune_transformer.py:57-86`` (the data loop and callbacks around it are the
+    caller's): config overrides (pose_multiplier, localization_weight, sequence_size, n_loss_skip, weight_decay, gradient_clip_val,
+    augment_poses — only those given) go into ``load_model`` BEFORE the model is built (:57-73); the optimizer is created with the finetune
+    learning rate over the finetune run's ``total_steps`` and 2000 warm-up steps, weight decay from the loaded config (:78-82);
+    ``model.load_weights(checkpoint).expect_partial()`` restores weights AND optimizer (:84); ``lr_schedule.offset`` is set to the restored
+    iteration count (:85).  ``precision='bf16'`` is the driver's ``--fp16`` (:53-55)."""
+    from . import checkpoint as ck
+    overrides = {k: v for k, v in transformer_config.items() if v is not None}
+    model = ck.load_model(checkpoint, device=None, **overrides)
+    if not isinstance(model, MIGT):
+        raise RuntimeError('finetune_transformer needs a transformer checkpoint')
+    if precision != model.precision:
+        model = MIGT(model.config, precision=precision).load_state_dict(model._sd_host)
+    trainer = MIGTTrainer(model.to(device), process_group=process_group)
+    if not checkpoint.endswith(('.pth', '.ckpt')):
+        ck.restore_optimizer(trainer, checkpoint, strict=False)             # .expect_partial(): a weights-only checkpoint is accepted
+    return trainer.begin_finetune(learning_rate=learning_rate, total_steps=total_steps, warmup_steps=2000)
+

@@ -127,6 +127,7 @@ class VQGAN:
         dev = self.device
         h = self._sd_host
         self._conv, self._norm, self._qkv = {}, {}, {}
+        self._act16_cache = {}
 
         def dev_t(name):
             return torch.from_numpy(h[name]).to(dev, torch.float32).contiguous()
@@ -296,8 +297,48 @@ class VQGAN:
                   stride_out=HW * C)
         return self._conv1(a, name + '.proj_out', M, res=x)
 
+    def _act16_plan_ok(self, plan, idx, H, W):
+        """can the activation stream switch to bf16 at the 'up' convolution ``plan[idx]`` (output H x W)?  Only if EVERY layer from there to
+        conv_out can take it: each 3x3 convolution on the bf16 halo arm (``wp16``: cin % 32 == 0, cout % 128 == 0, tile-aligned output) or
+        the small-cout kernel (conv_out), each GroupNorm fed by fused partial statistics (producer cout in 128 / 256 / 512 / 1024), each
+        nin_shortcut on the plain bf16 GEMM, no AttnBlock in the bf16 stretch.  Otherwise (e.g. ch = 64 or 96: a 64- or 384-channel top
+        level) the decoder keeps fp32 activations and the per-layer choice of arithmetic, as before decoder_act16 existed."""
+        key = (id(plan), idx, H, W)
+        hit = self._act16_cache.get(key)
+        if hit is not None:
+            return hit
+
+        def conv_ok(name, mode, h, w, feeds_norm=True):
+            c = self._conv[name]
+            ho, wo = (h * 2, w * 2) if mode == ops.MODE_CONV3_UP2 else (h, w)
+            if ops.conv3_small_cout_supported(mode, c.cin, c.cout, ho, wo):
+                return True                                              # conv_out: reads bf16, writes the fp32 image
+            return (c.wp16 is not None and ho % 8 == 0 and wo % 16 == 0 and (not feeds_norm or c.cout in (128, 256, 512, 1024)))
+
+        ok = self.fuse_gn_stats and conv_ok(plan[idx][1], ops.MODE_CONV3_UP2, H // 2, W // 2)
+        h, w = H, W
+        for kind, name, args in plan[idx + 1:]:
+            if not ok:
+                break
+            if kind == 'res':
+                ok = conv_ok(name + '.conv1', ops.MODE_CONV3_S1, h, w) and conv_ok(name + '.conv2', ops.MODE_CONV3_S1, h, w)
+                if ok and args[0] != args[1]:
+                    sc = self._conv[name + '.nin_shortcut']
+                    ok = sc.wp16 is not None and sc.k == 1
+            elif kind == 'up':
+                ok = conv_ok(name, ops.MODE_CONV3_UP2, h, w)
+                h, w = h * 2, w * 2
+            elif kind == 'conv3':
+                ok = conv_ok(name, ops.MODE_CONV3_S1, h, w, feeds_norm=False)
+            elif kind == 'norm_swish':
+                ok = True                                                # statistics come from the producing convolution (checked there)
+            else:                                                        # 'attn' (fp32 q | k | v), 'down': no bf16-activation form
+                ok = False
+        self._act16_cache[key] = bool(ok)
+        return bool(ok)
+
     def _run_plan(self, plan, x, n, H, W, first_is_image=False):
-        for kind, name, args in plan:
+        for idx, (kind, name, args) in enumerate(plan):
             if kind == 'conv3':
                 c = self._conv[name]
                 if c.wp is None:      # 3-channel conv_in (fused uint8 -> [-1,1])
@@ -320,14 +361,16 @@ class VQGAN:
             elif kind == 'up':
                 # decoder_act16 = R > 0: from the first upsample whose output is R x R or larger (R >= 32) the activations stay bf16 in HBM
                 # to conv_out; the stages below keep fp32 activations
-                o16 = (self.decoder_act16 and self.decoder_precision == 'bf16' and self.fuse_gn_stats and name.startswith('decoder.')
-                       and H * 2 >= max(32, int(self.decoder_act16)) and (H * 2) % 8 == 0 and (W * 2) % 16 == 0)
+                o16 = bool(self.decoder_act16 and self.decoder_precision == 'bf16' and self.fuse_gn_stats and name.startswith('decoder.')
+                           and H * 2 >= max(32, int(self.decoder_act16)) and (H * 2) % 8 == 0 and (W * 2) % 16 == 0
+                           and x.dtype != torch.bfloat16 and self._act16_plan_ok(plan, idx, H * 2, W * 2))
                 x, H, W = self._conv3(x, name, n, H, W, mode=ops.MODE_CONV3_UP2, o16=o16)
             elif kind == 'norm_swish':
                 self._pending_pro = self._gn(x, name, n, H * W, args[0])   # folded into the next conv
         return x, H, W
 
     _pending_pro = None
+    _act16_cache = None
 
     # ------------------------------------------------------------------ encoder / decoder on NHWC
     def _encode_nhwc(self, img):
