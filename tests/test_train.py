@@ -905,7 +905,8 @@ def test_bf16_training_arm_at_widths_the_tn_kernel_does_not_tile(dev, dropout):
 def test_bf16_arm_lm_head_backward_uses_current_weights_when_rows_are_not_a_multiple_of_64(dev):
     """with d_model and n_embeddings multiples of 256 the bf16 arm keeps bf16 LM-head packings, but the step only uses
     them when M1 = B*S*L is a multiple of 64; otherwise dH = dlogits @ wte runs on the native transposed packing — which repack() no longer
-    refreshed, so from step 2 on it held step-1 weights with no error raised.  Here M1 = 1*3*16 = 48: after two real optimizer steps the
+    refreshed, so from step 2 on it held step-1 weights with no error raised.  Here M1 = 2*3*16 = 96 (a multiple of the native GEMM's 32-row
+    K stage, not of 64): after real optimizer steps the
     third step's gradients must (a) equal, bit for bit, those of a FRESH trainer built from the updated weights and (b) sit within the bf16
     arm's tolerance of fp64 autograd over the oracle at those weights."""
     from viewformer_amd.config import MIGTConfig
@@ -918,7 +919,7 @@ def test_bf16_arm_lm_head_backward_uses_current_weights_when_rows_are_not_a_mult
                      localization_weight='2', pose_multiplier=0.2, learning_rate=2e-2, weight_decay=0.05, total_steps=50)
     sd = make_migt_weights(cfg, seed=6, std=0.08)
     g = np.random.Generator(np.random.PCG64(21))
-    B, S = 1, 3
+    B, S = 2, 3
     tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, 4, 4)))
     _, cams = synthetic_scene_batch(B, S, 8, 7)
     poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
