@@ -204,11 +204,11 @@ def test_decoder_bf16_pixels_within_stated_tolerance_and_tokens_stay_exact(dev, 
     m16.decoder_act16 = 128
 
 
-@pytest.mark.parametrize('ch', [64, 96])
+@pytest.mark.parametrize('ch', [64])       # (ch = 96: the standalone GroupNorm kernel takes power-of-two channel counts only — that config never ran)
 def test_decoder_bf16_arm_with_a_top_level_the_bf16_activation_stream_cannot_take(dev, ch):
     """decoder_act16 (default 128) switched the activation stream to bf16 at the last upsample convolution without
     asking whether the layers behind it can read bf16 — with ch = 64 (top level 64 channels: no bf16 halo packing, no fused GroupNorm
-    statistics) or ch = 96 the decode raised, where round 3's per-layer fp32 fallback ran.  The switch is now decided from the decoder plan
+    statistics) the decode raised, where round 3's per-layer fp32 fallback ran.  The switch is now decided from the decoder plan
     (every conv / norm / shortcut up to conv_out must qualify): such configs keep fp32 activations and decode within the bf16 arm's bound."""
     from oracle import vqgan_oracle as vq
     from viewformer_amd.config import VQGANConfig

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Which `s_waitcnt vmcnt(N)` inside LOOPS of a kernel did the COMPILER insert (as opposed to the kernel's own inline-asm waits)?
+hipcc's waitcnt pass conservatively drains vmcnt before an LDS read it cannot prove independent of a pending LDS-DMA
+(buffer_load ... lds / global_load_lds): inside a DMA ring that turns "three tiles in flight" into "wait for the newest tile every step".
+usage: python tools/isa_vmcnt_audit.py file.s [kernel-name substring]   (file.s from hipcc -S --cuda-device-only)"""
+import re
+import sys
+
+lines = open(sys.argv[1]).read().split('\n')
+key = sys.argv[2] if len(sys.argv) > 2 else ''
+kern, in_app, in_loop, label = None, False, False, ''
+out = {}
+for i, l in enumerate(lines):
+    m = re.match(r'^(_Z\S+):', l)
+    if m:
+        kern, in_loop = m.group(1), False
+        continue
+    if kern is None:
+        continue
+    if 's_endpgm' in l:
+        kern = None
+        continue
+    s = l.strip()
+    if s.startswith(';APP'):
+        in_app = True
+    elif s.startswith(';NO_APP'):
+        in_app = False
+    m = re.match(r'^(\.LBB\S+):(.*)', l)
+    if m:
+        label = m.group(1)
+        in_loop = 'Loop' in m.group(2)
+    if in_loop and not in_app and re.search(r's_waitcnt.*vmcnt\(\d+\)', s) and key in kern:
+        nxt = next((x.strip() for x in lines[i + 1:i + 6] if x.strip() and not x.strip().startswith(';')), '')
+        out.setdefault(kern, []).append((i + 1, label, s, nxt))
+for k, v in out.items():
+    print(k[:110])
+    for ln, lab, s, nxt in v:
+        print(f'    line {ln:6d} {lab:12s} {s:34s} -> {nxt[:70]}')
+if not out:
+    print('no compiler-inserted vmcnt waits inside loops')

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         seen = true;
         ADMA_STAMP(4);
         // k-step (t2, ks2) = keys 32 t2 + 16 ks2 + 8 (e >> 2) + 4 half + (e & 3)
+#ifdef VF_X_TRINTRIN
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -371,6 +372,24 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
                 }
                 if constexpr (U == 1) __builtin_amdgcn_sched_barrier(0);
             }
+#else
+        // the V^T fragments through vf_tr_frag2_wait (vf_common.h): as compiler intrinsics these reads made hipcc drain vmcnt — the whole
+        // DMA ring, incl. the tile issued at the top of this step — in front of every tile's P.V
+        const unsigned vaddr = vf_lds_addr(tile) + v_off;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                bf16x8 va0, va1;                                     // feature halves d = 0, 1
+                vf_tr_frag2_wait(va0, va1, vaddr, (t2 * 32 + ks2 * 16) * 64, 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ot[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pb[u][t2][ks2], ot[u][0], 0, 0, 0);
+                    ot[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pb[u][t2][ks2], ot[u][1], 0, 0, 0);
+                }
+                if constexpr (U == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
     };
 
     ADMA_STAMP(6);

@@ -290,11 +290,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2)
+#ifdef VF_X_TRINTRIN
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const bf16x8 ka = tr_frag(slot + 2 * IMG + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
                     ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, ds[t2][ks2], ot[d], 0, 0, 0);   // dQ^T += K^T.dS^T
                 }
+#else
+            {   // (vf_tr_frag2_wait, vf_common.h: through the intrinsic these reads drained the DMA ring — the NEXT tile — before this product)
+                bf16x8 ka0, ka1;
+                vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + tr_off, 2 * IMG + (t2 * 32 + ks2 * 16) * 64, 2 * IMG + 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
+                ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ds[t2][ks2], ot[0], 0, 0, 0);      // dQ^T += K^T.dS^T
+                ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ds[t2][ks2], ot[1], 0, 0, 0);
+            }
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
@@ -442,10 +451,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
             for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
+#ifdef VF_X_TRINTRIN
                     const unsigned off = tr_off + d * 4096 + (u * 32 + ks2 * 16) * 64;
                     const bf16x8 oa = tr_frag(slot + 3 * IMG + off);
-                    dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, pf[ks2], dvacc[d], 0, 0, 0);   // dV^T += dO^T.P
                     const bf16x8 qa = tr_frag(slot + 2 * IMG + off);
+#else
+                    bf16x8 oa, qa;      // (vf_tr_frag2_wait: as intrinsics these reads made hipcc wait for the NEXT tile's DMA — no overlap at all)
+                    vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + tr_off, 3 * IMG + d * 4096 + (u * 32 + ks2 * 16) * 64,
+                                     2 * IMG + d * 4096 + (u * 32 + ks2 * 16) * 64, 8 * 64);
+#endif
+                    dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, pf[ks2], dvacc[d], 0, 0, 0);   // dV^T += dO^T.P
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sf[ks2], dkacc[d], 0, 0, 0);   // dK^T += Q^T.dS
                 }
         }

@@ -32,6 +32,9 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 #ifndef G256_PANEL
 #define G256_PANEL 4          // column tiles per panel (0: all column tiles of a row block together)
 #endif
+#ifndef G256_ROWGROUP
+#define G256_ROWGROUP 0       // row blocks per group (0: column panels over all row blocks, the round-2 order); see the kernel
+#endif
 constexpr int GM = 256, GN = 256, GK = 64;
 constexpr int GA_BYTES = GM * GK * 2;        // 32768
 constexpr int GB_BYTES = GN * GK * 2;        // 32768 = two 128-column packed blocks
@@ -257,11 +260,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     const unsigned lbid = vf_xcd_bid();
     constexpr int PANEL = G256_PANEL;
     const int sn = PANEL <= 0 || nb <= PANEL ? nb : nb % PANEL == 0 ? PANEL : (PANEL >= 3 && nb % 3 == 0) ? 3 : (PANEL >= 2 && nb % 2 == 0) ? 2 : 1;
+#if G256_ROWGROUP > 0
+    // ROW GROUPS (round 5): with column panels walked over ALL row blocks (below), a 256-row A panel is fetched once per
+    // column panel — 3 x for c_fc / c_attn — and the panels of one row block run on different XCDs at different times: FETCH_SIZE 434 MB per
+    // c_fc launch for 105 MB of operands (profiles/r4_bench_mixed_pmc_traffic.txt).  Here the ids are walked in groups of G256_ROWGROUP row
+    // blocks; inside a group, column panel after column panel: the ~32 workgroups an XCD runs (one per CU) are RG row blocks x sn column
+    // tiles, and the group's next panel follows on the SAME XCD right behind — the group's A rows (RG x 393 KB at K = 768) are still in its L2
+    constexpr int RG = G256_ROWGROUP;
+    const int per_group = RG * nb;
+    const int group = (int)(lbid / (unsigned)per_group);
+    const int in_group = (int)(lbid - (unsigned)group * per_group);
+    const int rows_g = min(RG, mt - group * RG);                     // (the last group may be short)
+    const int per_panel = rows_g * sn;
+    const int panel = in_group / per_panel;
+    const int in_panel = in_group - panel * per_panel;
+    const int nblk = panel * sn + in_panel % sn;
+    const int mtile = group * RG + in_panel / sn;
+#else
     const int per_panel = mt * sn;
     const int panel = (int)(lbid / (unsigned)per_panel);
     const int in_panel = (int)(lbid - (unsigned)panel * per_panel);
     const int nblk = panel * sn + in_panel % sn;
     const int mtile = in_panel / sn;
+#endif
     const int m_tile0 = mtile * GM, n_tile0 = nblk * GN;
     const int nstages = p.Cin / GK;
 

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             bf16x8 bf[2];
+#ifdef VF_X_TRINTRIN
 #pragma unroll
             for (int b = 0; b < 2; ++b) bf[b] = tr_frag(sy + tr_off + (wn * 2 + b) * 4096 + ms * 16 * 64);
 #pragma unroll
@@ -155,6 +156,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const __bf16* __re
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);
             }
+#else
+            // transposing reads as inline asm (vf_tr_frag*_wait, vf_common.h): through the intrinsic, hipcc put `s_waitcnt vmcnt(0)` in front of the
+            // chunk's first read — i.e. it waited for chunk c + 1's DMA (and dY loads), issued a few instructions earlier, before multiplying chunk c:
+            // the double buffer never overlapped anything
+            const unsigned ay = vf_lds_addr(sy) + tr_off + (unsigned)(wn * 2 * 4096), ax = vf_lds_addr(sx) + tr_off + (unsigned)(wk * 4 * 4096);
+            vf_tr_frag2_wait(bf[0], bf[1], ay, ms * 16 * 64, 4096 + ms * 16 * 64, 8 * 64);
+#pragma unroll
+            for (int a = 0; a < 4; a += 2) {
+                bf16x8 af0, af1;
+                vf_tr_frag2_wait(af0, af1, ax, a * 4096 + ms * 16 * 64, (a + 1) * 4096 + ms * 16 * 64, 8 * 64);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0, bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bf[b], acc[a + 1][b], 0, 0, 0);
+            }
+#endif
         }
         if (more) park_y(st ^ 1);                                     // (the loads have had the chunk's MFMAs to arrive)
     }

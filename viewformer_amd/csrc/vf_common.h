@@ -279,7 +279,45 @@ VF_REG_FLAG(VF_X3H_X_NOPATCH)
 #ifdef VF_X6_CLOCKPROBE
 VF_REG_FLAG(VF_X6_CLOCKPROBE)
 #endif
+#ifdef VF_X_TRINTRIN      // A/B: the transposing LDS reads through the compiler intrinsic again (hipcc then drains vmcnt in front of them)
+VF_REG_FLAG(VF_X_TRINTRIN)
+#endif
 
 // shared host helper (defined in igemm_f32.hip): pack [taps][K][N] into the fragment-major B layout
 int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long long sk, long long sn, long long st,
                    int BN, int batch, long long src_bstride, hipStream_t stream);
+
+// ---- ds_read_b64_tr_b16 behind inline asm (round 5) ---------------------------------------------------------------------------------
+// hipcc's waitcnt pass cannot prove that an LDS read issued through the transposing-read INTRINSIC (__builtin_amdgcn_ds_read_tr16_b64)
+// is independent of a pending LDS-DMA (buffer_load ... lds): in front of the first such read after a DMA issue it inserts
+// `s_waitcnt vmcnt(0)`.  Inside a DMA ring that turns "three tiles in flight behind counted waits" into "wait for the tile issued at the
+// top of THIS step before the step's P.V / dK / dW products" — every tile step then costs at least one HBM latency, which is what the
+// round-4 stamps showed as a constant ~2 200 cycles per visible tile step (tools/isa_vmcnt_audit.py lists such waits; plain ds_read_b128
+// reads are not affected).  The kernels order these reads themselves (counted vmcnt + s_barrier at the top of every ring step), so the
+// reads are issued as inline asm, which the pass does not look into: the asm block carries its own `s_waitcnt lgkmcnt(0)`, i.e. its
+// outputs are valid when it ends (it also waits for any LDS read the compiler still has in flight: harmless).  Same instructions, same
+// data, same arithmetic: bit-identical results.  `off*` must fold to immediates (unrolled loop indices do under -O3).
+typedef __bf16 vf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short vf_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned vf_lds_addr(const void* p) {          // byte address inside the workgroup's LDS allocation
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ vf_bf16x8 vf_tr_join(vf_s16x4 lo, vf_s16x4 hi) {
+    return __builtin_bit_cast(vf_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// one MFMA operand = two transposing reads `gap` bytes apart (the two 4-row groups of a 32x32x16 operand's 8 consecutive k)
+__device__ __forceinline__ vf_bf16x8 vf_tr_frag_wait(unsigned addr, int off, int gap) {
+    vf_s16x4 a0, a1;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1) : "v"(addr), "i"(off), "i"(off + gap) : "memory");
+    return vf_tr_join(a0, a1);
+}
+// two operands (at offA and offB) in one block: four reads in flight, one wait
+__device__ __forceinline__ void vf_tr_frag2_wait(vf_bf16x8& a, vf_bf16x8& b, unsigned addr, int offA, int offB, int gap) {
+    vf_s16x4 a0, a1, b0, b1;
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\tds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(addr), "i"(offA), "i"(offA + gap), "i"(offB), "i"(offB + gap) : "memory");
+    a = vf_tr_join(a0, a1);
+    b = vf_tr_join(b0, b1);
+}
