@@ -52,17 +52,24 @@ def main():
                 lines.append(f'  -- (per-shape breakdown unavailable: {e})')
             continue
         pe, ip = T('rocpd_pmc_event'), T('rocpd_info_pmc')
-        q = (f"select s.kernel_name, p.name, d.id, sum(e.value) from {pe} e join {ip} p on e.pmc_id=p.id "
+        q = (f"select s.kernel_name, p.name, d.id, sum(e.value), count(*) from {pe} e join {ip} p on e.pmc_id=p.id "
              f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name, d.id")
         acc = defaultdict(lambda: defaultdict(list))
-        for n, pn, did, v in c.execute(q):
+        ninst = {}
+        for n, pn, did, v, cnt in c.execute(q):
             acc[n][pn].append(v)
+            ninst[pn] = cnt
         dur = {r[0]: r[2] for r in rows}
         lines.append(f'== {tag}: rocprofv3 --pmc, per-dispatch totals (sum over instances), mean over dispatches')
         for n, d in acc.items():
             if any(f in n for f in filt):
                 lines.append(f'  {short(n)}  avg_us={dur.get(n, 0) / 1e3:.2f}')
                 lines.append('      ' + ', '.join(f'{k}={sum(v) / len(v):.5g}' for k, v in sorted(d.items())))
+                if 'GRBM_GUI_ACTIVE' in d and dur.get(n):
+                    # effective shader clock of the dispatch: busy cycles (per counter instance) / wall time of the dispatch
+                    g = sum(d['GRBM_GUI_ACTIVE']) / len(d['GRBM_GUI_ACTIVE']) / max(ninst.get('GRBM_GUI_ACTIVE', 1), 1)
+                    lines.append(f'      GRBM_GUI_ACTIVE per instance ({ninst.get("GRBM_GUI_ACTIVE", 1)} instances) = {g:.5g} cycles -> '
+                                 f'{g / (dur[n] / 1e3) / 1e3:.3f} GHz effective clock over the dispatch')
     open(os.path.join(out, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 

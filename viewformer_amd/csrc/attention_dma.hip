@@ -66,6 +66,15 @@ constexpr int K_BYTES = KT * DH * 2;         // 8192
 constexpr int TILE_BYTES = 2 * K_BYTES;      // K image then V image
 constexpr int RING = 4;
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ADMA_PSWAP
+#define ADMA_PSWAP 1
+#endif
+#ifndef ADMA_SKEW_DROP
+#define ADMA_SKEW_DROP 0
+#endif
+#ifndef ADMA_SKEW
+#define ADMA_SKEW 1          // U = 1: waves 4-7 run half a tile step behind waves 0-3 (see the tile loop)
+#endif
 constexpr float ADMA_THR = 8.0f;             // a query's reference maximum moves when a tile exceeds it by more than this (exponent-of-2 units)
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
@@ -90,6 +99,26 @@ __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// the two half-waves of a lane pair (lane, lane ^ 32) hold the two key halves of one query: their maximum / sum through
+// v_permlane32_swap (one VALU instruction, gfx950) instead of ds_bpermute (an LDS round trip in the middle of the softmax's serial chain
+// plus six address instructions).  Both operands = x: r[0] = x of the low half-wave in all 64 lanes, r[1] = x of the high one
+__device__ __forceinline__ float xhalf_max(float x) {
+#if ADMA_PSWAP
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+#if ADMA_PSWAP
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);          // (low + high in every lane: the same sum the shuffle form makes in both half-waves)
+#else
+    return x + __shfl_xor(x, 32, 64);
+#endif
 }
 
 #ifdef ADMA_STAMPS       // phase timeline (tools/microbench.py attn_stamps): per wave, cycles summed over its tile steps
@@ -320,7 +349,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, stu[t2][r]), stu[t2][r + 1]);   // v_max3_f32
-        return fmaxf(mx, __shfl_xor(mx, 32, 64));
+        return xhalf_max(mx);
     };
     // ---- online softmax + O^T += V^T . P^T of one tile (lane = one query of each of the wave's tiles; its 32 keys of the key tile per half-wave)
     auto softmax_pv = [&](f32x16 (&st)[U][2], const unsigned char* tile, int tcur) {
@@ -392,15 +421,36 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
 #endif
     };
 
+    // SKEW (round 5, U = 1).  A SIMD hosts waves w and w + 4 of the workgroup.  Released by the same barrier they ran the same phase at the
+    // same time — S MFMAs against S MFMAs, then softmax against softmax (the vector unit serves the older wave first: the round-4 stamps
+    // show waves 4-7 taking 3 300 cycles per tile step where waves 0-3 take 2 300 and then sit ~1 400 cycles at the barrier), then P.V
+    // against P.V: the matrix pipe idles while both do exponentials and the vector unit idles while both multiply.  Now waves 4-7 ("late")
+    // run HALF A STEP BEHIND: after barrier kt they first finish tile kt - 1 (softmax + P.V from the scores they kept in registers), then
+    // compute the scores of tile kt and carry them across the next barrier — so right after a barrier one wave of the SIMD issues MFMAs
+    // (S of tile kt) while the other does vector work (softmax of tile kt - 1), and later the roles swap.  Per wave the sequence of
+    // operations and operands is unchanged: bit-identical results.  What it costs: a late wave still reads V of tile kt - 1 between
+    // barriers kt and kt + 1, so that slot may only be refilled after barrier kt + 1 — the ring runs TWO tiles ahead instead of three
+    // (the DMA was never what the waves waited for: profiles/r4_attention_study.txt).
+    // (with dropout the late loop needs two more registers than the 128 of four waves per SIMD: a spill reload inside the loop would wait on
+    // vmcnt and drain the ring — ADMA_SKEW_DROP keeps that variant measurable)
+    constexpr bool SKEW = ADMA_SKEW && U == 1 && (!DROP || ADMA_SKEW_DROP);
+    const bool late = SKEW && wave >= 4;
     ADMA_STAMP(6);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
-        // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
+    // the head of a tile step, common to both schedules: wait, barrier, refill the ring; returns the key view in ring slot kt % RING and
+    // whether this wave's queries see it (a tile masked for all of the wave's queries contributes exactly 0.0f)
+    auto head = [&](int kt, int& tcur) -> bool {
+        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight — one with SKEW), its LDS reads of tile
+        // kt - 1 (and of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (SKEW: kt - 2; kt = 0:
+        // the Q slots)
         ADMA_STAMP(0);
-        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
-        if (last_issued - kt >= 2) wait_vm_lgkm0<2 * LPT>();
-        else if (last_issued - kt == 1) wait_vm_lgkm0<LPT>();
-        else wait_vm_lgkm0<0>();
+        if constexpr (SKEW) {
+            if (kt + 1 < ntiles) wait_vm_lgkm0<LPT>(); else wait_vm_lgkm0<0>();
+        } else {
+            const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
+            if (last_issued - kt >= 2) wait_vm_lgkm0<2 * LPT>();
+            else if (last_issued - kt == 1) wait_vm_lgkm0<LPT>();
+            else wait_vm_lgkm0<0>();
+        }
         ADMA_STAMP(1);
         __builtin_amdgcn_s_barrier();
         ADMA_STAMP(2);
@@ -412,31 +462,62 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         if (kt == 0) { issue_tile(ntiles > 2 ? 2 : 0); issue_tile(ntiles > 3 ? 3 : 0); }
         else if (kt + 3 < ntiles) { asm volatile("s_nop 0"); }
 #else
-        if (kt == 0) {
+        if constexpr (SKEW) {
+            if (kt + 2 < ntiles) issue_tile(kt + 2);                 // into the slot of tile kt - 2 (kt < 2: the Q slots, free since barrier 0)
+        } else if (kt == 0) {
             if (ntiles > 2) issue_tile(2);
             if (ntiles > 3) issue_tile(3);
         } else if (kt + 3 < ntiles) {
             issue_tile(kt + 3);
         }
 #endif
+        tcur = pop(rem_use, kt);
 #ifdef ADMA_X_NOCOMPUTE
-        continue;
+        return false;
 #endif
-        const int tcur = pop(rem_use, kt);                           // the key view in ring slot kt % RING
-        // (a tile masked for all of the wave's queries contributes exactly 0.0f)
-        const bool vis = dense ? (active && visible(qview, tcur)) : ((mine >> tcur) & 1ull) != 0ull;
-        if (!vis) continue;
-        f32x16 st[U][2];                                             // [query tile][key half]
-        ADMA_STAMP(3);
-        scores(smem + (kt % RING) * TILE_BYTES, st);
-        softmax_pv(st, smem + (kt % RING) * TILE_BYTES, tcur);
+        return dense ? (active && visible(qview, tcur)) : ((mine >> tcur) & 1ull) != 0ull;
+    };
+    if (!late) {
+        for (int kt = 0; kt < ntiles; ++kt) {
+            int tcur;
+            if (!head(kt, tcur)) continue;
+            f32x16 st[U][2];                                         // [query tile][key half]
+            ADMA_STAMP(3);
+            scores(smem + (kt % RING) * TILE_BYTES, st);
+            softmax_pv(st, smem + (kt % RING) * TILE_BYTES, tcur);
 #ifdef ADMA_STAMPS
-        ADMA_STAMP(5);
-        acc_t[2] += (unsigned)(tt[3] - tt[2]);                       // DMA issue + bookkeeping
-        acc_t[3] += (unsigned)(tt[4] - tt[3]);                       // S MFMAs issued + softmax done (the MFMAs' results consumed)
-        acc_t[4] += (unsigned)(tt[5] - tt[4]);                       // V^T reads + P.V MFMAs issued
-        acc_t[5] += 1u;                                              // visible tile steps of this wave
+            ADMA_STAMP(5);
+            acc_t[2] += (unsigned)(tt[3] - tt[2]);                   // DMA issue + bookkeeping
+            acc_t[3] += (unsigned)(tt[4] - tt[3]);                   // S MFMAs issued + softmax done (the MFMAs' results consumed)
+            acc_t[4] += (unsigned)(tt[5] - tt[4]);                   // V^T reads + P.V MFMAs issued
+            acc_t[5] += 1u;                                          // visible tile steps of this wave
 #endif
+        }
+    } else {
+        // the late half's loop (its own code, so that the scores carried from one step to the next only cost registers here): one more
+        // pass than there are tiles — the last one only finishes the last tile, without a barrier
+        f32x16 st[U][2];
+        int pend_seq = -1, pend_t = 0;                               // the tile whose scores wait in st
+        for (int kt = 0; kt <= ntiles; ++kt) {
+            int tcur = 0;
+            const bool vis = kt < ntiles ? head(kt, tcur) : false;
+            if (pend_seq >= 0) {
+                ADMA_STAMP(3);
+                softmax_pv(st, smem + (pend_seq % RING) * TILE_BYTES, pend_t);
+                pend_seq = -1;
+#ifdef ADMA_STAMPS
+                ADMA_STAMP(5);
+                acc_t[3] += (unsigned)(tt[4] - tt[3]);
+                acc_t[4] += (unsigned)(tt[5] - tt[4]);
+                acc_t[5] += 1u;
+#endif
+            }
+            if (vis) {
+                scores(smem + (kt % RING) * TILE_BYTES, st);
+                pend_seq = kt;
+                pend_t = tcur;
+            }
+        }
     }
 
     // ---- normalise, round, transpose through the wave's slice of the (now idle) ring, store whole rows
@@ -459,7 +540,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     unsigned char* Os = smem + wave * QB;                            // [32 U queries][128 B], chunk c stored at c ^ ((row >> 1) & 7)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        const float l_tot = xhalf_sum(l_run[u]);
         const float inv_l = (DROP ? drop_scale : 1.0f) / l_tot;
         const int row = u * 32 + l31;
 #ifndef ADMA_STAMPS
