@@ -69,12 +69,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_PSWAP
 #define ADMA_PSWAP 1
 #endif
-#ifndef ADMA_SKEW_DROP
-#define ADMA_SKEW_DROP 0
-#endif
-#ifndef ADMA_SKEW
-#define ADMA_SKEW 1          // U = 1: waves 4-7 run half a tile step behind waves 0-3 (see the tile loop)
-#endif
 constexpr float ADMA_THR = 8.0f;             // a query's reference maximum moves when a tile exceeds it by more than this (exponent-of-2 units)
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
@@ -421,36 +415,20 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
 #endif
     };
 
-    // SKEW (round 5, U = 1).  A SIMD hosts waves w and w + 4 of the workgroup.  Released by the same barrier they ran the same phase at the
-    // same time — S MFMAs against S MFMAs, then softmax against softmax (the vector unit serves the older wave first: the round-4 stamps
-    // show waves 4-7 taking 3 300 cycles per tile step where waves 0-3 take 2 300 and then sit ~1 400 cycles at the barrier), then P.V
-    // against P.V: the matrix pipe idles while both do exponentials and the vector unit idles while both multiply.  Now waves 4-7 ("late")
-    // run HALF A STEP BEHIND: after barrier kt they first finish tile kt - 1 (softmax + P.V from the scores they kept in registers), then
-    // compute the scores of tile kt and carry them across the next barrier — so right after a barrier one wave of the SIMD issues MFMAs
-    // (S of tile kt) while the other does vector work (softmax of tile kt - 1), and later the roles swap.  Per wave the sequence of
-    // operations and operands is unchanged: bit-identical results.  What it costs: a late wave still reads V of tile kt - 1 between
-    // barriers kt and kt + 1, so that slot may only be refilled after barrier kt + 1 — the ring runs TWO tiles ahead instead of three
-    // (the DMA was never what the waves waited for: profiles/r4_attention_study.txt).
-    // (with dropout the late loop needs two more registers than the 128 of four waves per SIMD: a spill reload inside the loop would wait on
-    // vmcnt and drain the ring — ADMA_SKEW_DROP keeps that variant measurable)
-    constexpr bool SKEW = ADMA_SKEW && U == 1 && (!DROP || ADMA_SKEW_DROP);
-    const bool late = SKEW && wave >= 4;
+    // (Round 5 measured a SKEWED form of this loop and removed it again: waves 4-7 — the second wave of every SIMD — ran half a step behind
+    // waves 0-3 (after barrier kt: softmax + P.V of tile kt - 1 from scores carried across the barrier, then the S MFMAs of tile kt), so
+    // that one wave of a SIMD multiplies while the other exponentiates; ring two tiles ahead instead of three.  Bit-identical outputs,
+    // 128 registers, and 2.3 % SLOWER in an in-process alternation (112.2 vs 109.7 us at the bench shape, 208 vs 204 us at S = 21):
+    // profiles/r5_attention_ab.txt, commit "attention: skewed half-step schedule" in the history.)
     ADMA_STAMP(6);
-    // the head of a tile step, common to both schedules: wait, barrier, refill the ring; returns the key view in ring slot kt % RING and
-    // whether this wave's queries see it (a tile masked for all of the wave's queries contributes exactly 0.0f)
-    auto head = [&](int kt, int& tcur) -> bool {
-        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight — one with SKEW), its LDS reads of tile
-        // kt - 1 (and of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (SKEW: kt - 2; kt = 0:
-        // the Q slots)
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
+        // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
         ADMA_STAMP(0);
-        if constexpr (SKEW) {
-            if (kt + 1 < ntiles) wait_vm_lgkm0<LPT>(); else wait_vm_lgkm0<0>();
-        } else {
-            const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
-            if (last_issued - kt >= 2) wait_vm_lgkm0<2 * LPT>();
-            else if (last_issued - kt == 1) wait_vm_lgkm0<LPT>();
-            else wait_vm_lgkm0<0>();
-        }
+        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
+        if (last_issued - kt >= 2) wait_vm_lgkm0<2 * LPT>();
+        else if (last_issued - kt == 1) wait_vm_lgkm0<LPT>();
+        else wait_vm_lgkm0<0>();
         ADMA_STAMP(1);
         __builtin_amdgcn_s_barrier();
         ADMA_STAMP(2);
@@ -462,62 +440,31 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         if (kt == 0) { issue_tile(ntiles > 2 ? 2 : 0); issue_tile(ntiles > 3 ? 3 : 0); }
         else if (kt + 3 < ntiles) { asm volatile("s_nop 0"); }
 #else
-        if constexpr (SKEW) {
-            if (kt + 2 < ntiles) issue_tile(kt + 2);                 // into the slot of tile kt - 2 (kt < 2: the Q slots, free since barrier 0)
-        } else if (kt == 0) {
+        if (kt == 0) {
             if (ntiles > 2) issue_tile(2);
             if (ntiles > 3) issue_tile(3);
         } else if (kt + 3 < ntiles) {
             issue_tile(kt + 3);
         }
 #endif
-        tcur = pop(rem_use, kt);
 #ifdef ADMA_X_NOCOMPUTE
-        return false;
+        continue;
 #endif
-        return dense ? (active && visible(qview, tcur)) : ((mine >> tcur) & 1ull) != 0ull;
-    };
-    if (!late) {
-        for (int kt = 0; kt < ntiles; ++kt) {
-            int tcur;
-            if (!head(kt, tcur)) continue;
-            f32x16 st[U][2];                                         // [query tile][key half]
-            ADMA_STAMP(3);
-            scores(smem + (kt % RING) * TILE_BYTES, st);
-            softmax_pv(st, smem + (kt % RING) * TILE_BYTES, tcur);
+        const int tcur = pop(rem_use, kt);                           // the key view in ring slot kt % RING
+        // (a tile masked for all of the wave's queries contributes exactly 0.0f)
+        const bool vis = dense ? (active && visible(qview, tcur)) : ((mine >> tcur) & 1ull) != 0ull;
+        if (!vis) continue;
+        f32x16 st[U][2];                                             // [query tile][key half]
+        ADMA_STAMP(3);
+        scores(smem + (kt % RING) * TILE_BYTES, st);
+        softmax_pv(st, smem + (kt % RING) * TILE_BYTES, tcur);
 #ifdef ADMA_STAMPS
-            ADMA_STAMP(5);
-            acc_t[2] += (unsigned)(tt[3] - tt[2]);                   // DMA issue + bookkeeping
-            acc_t[3] += (unsigned)(tt[4] - tt[3]);                   // S MFMAs issued + softmax done (the MFMAs' results consumed)
-            acc_t[4] += (unsigned)(tt[5] - tt[4]);                   // V^T reads + P.V MFMAs issued
-            acc_t[5] += 1u;                                          // visible tile steps of this wave
+        ADMA_STAMP(5);
+        acc_t[2] += (unsigned)(tt[3] - tt[2]);                       // DMA issue + bookkeeping
+        acc_t[3] += (unsigned)(tt[4] - tt[3]);                       // S MFMAs issued + softmax done (the MFMAs' results consumed)
+        acc_t[4] += (unsigned)(tt[5] - tt[4]);                       // V^T reads + P.V MFMAs issued
+        acc_t[5] += 1u;                                              // visible tile steps of this wave
 #endif
-        }
-    } else {
-        // the late half's loop (its own code, so that the scores carried from one step to the next only cost registers here): one more
-        // pass than there are tiles — the last one only finishes the last tile, without a barrier
-        f32x16 st[U][2];
-        int pend_seq = -1, pend_t = 0;                               // the tile whose scores wait in st
-        for (int kt = 0; kt <= ntiles; ++kt) {
-            int tcur = 0;
-            const bool vis = kt < ntiles ? head(kt, tcur) : false;
-            if (pend_seq >= 0) {
-                ADMA_STAMP(3);
-                softmax_pv(st, smem + (pend_seq % RING) * TILE_BYTES, pend_t);
-                pend_seq = -1;
-#ifdef ADMA_STAMPS
-                ADMA_STAMP(5);
-                acc_t[3] += (unsigned)(tt[4] - tt[3]);
-                acc_t[4] += (unsigned)(tt[5] - tt[4]);
-                acc_t[5] += 1u;
-#endif
-            }
-            if (vis) {
-                scores(smem + (kt % RING) * TILE_BYTES, st);
-                pend_seq = kt;
-                pend_t = tcur;
-            }
-        }
     }
 
     // ---- normalise, round, transpose through the wave's slice of the (now idle) ring, store whole rows
