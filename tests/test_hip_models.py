@@ -156,6 +156,44 @@ def test_migt_full_config_matches_oracle(dev):
     assert agree > 0.98, agree
 
 
+def test_migt_matches_hugging_face_gpt2_golden(dev):
+    """the HIP transformer against outputs of a THIRD-PARTY implementation: ``transformers``' GPT-2 run on MIGT weights
+    (tests/golden/migt_hf_gpt2.npz, written by tests/golden/make_hf_gpt2_golden.py: no score scaling, (V, Q, K) split, block-causal 0 / -1e4
+    mask, pose MLPs on transformers' Conv1D; the multi-context pass as one GPT-2 call per view).  Tiny shape: logits of every view on the
+    fp32-equivalent arm, the multi-context pass's MASK-stream logits and LOC-stream camera predictions; full size (12 layers, d = 768):
+    last-view logits on the fp32-equivalent arm (stated fp32 tolerance) and on the bf16 arm the bench times (stated bf16 tolerance)."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights
+    from conftest import load_golden
+    g = load_golden('migt_hf_gpt2.npz')
+    cfg = MIGTConfig(n_embeddings=64, n_head=2, d_model=128, n_layer=2, token_image_size=4, sequence_size=4, localization_weight='1', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=int(g['tiny_seed']), std=float(g['tiny_std']))
+    ids, cams = torch.from_numpy(g['tiny_ids']).to(dev), torch.from_numpy(g['tiny_cams']).to(dev)
+    m = MIGT(cfg).load_state_dict(sd).to(dev)
+    out = m(dict(input_ids=ids, poses=cams))
+    e1 = _maxerr(out['logits'], torch.from_numpy(g['tiny_logits']))
+    S = ids.shape[1]
+    in_ids = torch.cat([ids[:, :-1], torch.full_like(ids[:, :1], cfg.n_embeddings)], 1)
+    ctx = torch.cat([cams[:, :-1], torch.zeros_like(cams[:, :1])], 1)
+    multi = m(dict(input_ids=in_ids, poses=ctx, localization_tokens=ids[:, -1:].expand(-1, S, -1, -1).contiguous(),
+                   output_poses=cams[:, -1:].expand(-1, S, -1).contiguous()), training=False)
+    e2 = _maxerr(multi['logits'], torch.from_numpy(g['tiny_multi_logits']))
+    e3 = _maxerr(multi['pose_prediction'], torch.from_numpy(g['tiny_multi_pose']))
+    print(f'HIP vs HF GPT-2 golden (tiny): logits {e1:.2e}, multi-context logits {e2:.2e}, camera predictions {e3:.2e}')
+    assert e1 < 2e-4 and e2 < 2e-4 and e3 < 2e-4
+    fcfg = MIGTConfig(sequence_size=6, n_loss_skip=1, pose_multiplier=0.2, localization_weight='cosine(0,1,120000)')
+    fsd = make_migt_weights(fcfg, seed=int(g['full_seed']))
+    ref = torch.from_numpy(g['full_logits_last'])
+    fids, fcams = torch.from_numpy(g['full_ids']).to(dev), torch.from_numpy(g['full_cams']).to(dev)
+    for arm, tol in (('f32', 1e-3), ('bf16', 3e-2 * float(ref.abs().max()))):
+        mm = MIGT(fcfg, precision=arm).load_state_dict(fsd).to(dev)
+        last = mm(dict(input_ids=fids, poses=fcams), last_view_logits_only=True)['logits_last']
+        err = _maxerr(last.reshape(ref.shape), ref)
+        print(f'HIP vs HF GPT-2 golden (full size, {arm} arm): {err:.2e} of |logit| max {float(ref.abs().max()):.3f}')
+        assert err < tol, (arm, err)
+
+
 # ------------------------------------------------------------------------------------------------ pipeline
 @pytest.mark.parametrize('B,S', [(2, 3), (1, 2), (3, 5)])          # (1, 2): a single context view; odd image counts hit the pair tiles' tail
 def test_generate_batch_predictions_matches_oracle(dev, full_vq, B, S):

@@ -198,3 +198,52 @@ def test_independent_numpy64_camera_frames_agree():
     assert np.abs(mg.normalize_cameras(rel).numpy() - n64.normalize_cameras(rel2)).max() < 1e-12
     x = torch.randn(2, 3, 16, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
     assert np.abs(mg.reduce_cameras(x, -2).numpy() - n64.reduce_cameras(x.numpy(), -2)).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- third-party anchor (Hugging Face GPT-2)
+def _hf():
+    from conftest import load_golden
+    return load_golden('migt_hf_gpt2.npz')
+
+
+def test_oracle_matches_hugging_face_gpt2_on_migt_weights():
+    """tests/golden/migt_hf_gpt2.npz holds outputs of ``transformers``' GPT-2 (an independent, third-party implementation of the architecture
+    migt.py is built from) run on MIGT weights with the reference's three deviations expressed through GPT-2's own config / inputs — no
+    score scaling, (V, Q, K) split, block-causal 0 / -1e4 mask — and the pose MLPs evaluated with transformers' Conv1D
+    (tests/golden/make_hf_gpt2_golden.py).  The oracle reproduces them to fp32 storage precision: single-stream logits of every view, the
+    multi-context pass's MASK-stream logits and LOC-stream camera predictions (one GPT-2 call per view there: the branch semantics of
+    branching_attention.py:82-126), the relative-camera transform, and the full-size 12-layer model's last-view logits.  (Not the reference
+    itself: the MIGT oracle stays formally 'parity unpinned' — this replaces agreement between two restatements by one author with
+    agreement with somebody else's code.)"""
+    g = _hf()
+    cfg = MIGTConfig(n_embeddings=64, n_head=2, d_model=128, n_layer=2, token_image_size=4, sequence_size=4, localization_weight='1', pose_multiplier=0.2)
+    sd = make_migt_weights(cfg, seed=int(g['tiny_seed']), std=float(g['tiny_std']))
+    ids = torch.from_numpy(g['tiny_ids'])
+    cams = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(g['tiny_cams_raw']).double())[0])
+    assert (cams - torch.from_numpy(g['tiny_cams']).double()).abs().max() < 1e-6          # camera frame change vs plain quaternion algebra
+    cams = cams.float()
+    out = mg.migt_forward(sd, cfg, ids, cams, dtype=torch.float64)
+    e1 = (out['logits'] - torch.from_numpy(g['tiny_logits']).double()).abs().max().item()
+    in_ids = torch.cat([ids[:, :-1], torch.full_like(ids[:, :1], cfg.n_embeddings)], 1)
+    ctx = torch.cat([cams[:, :-1], torch.zeros_like(cams[:, :1])], 1)
+    S = ids.shape[1]
+    multi = mg.migt_forward(sd, cfg, in_ids, ctx, localization_tokens=ids[:, -1:].expand(-1, S, -1, -1), output_poses=cams[:, -1:].expand(-1, S, -1),
+                            dtype=torch.float64)
+    e2 = (multi['logits'] - torch.from_numpy(g['tiny_multi_logits']).double()).abs().max().item()
+    e3 = (multi['pose_prediction'] - torch.from_numpy(g['tiny_multi_pose']).double()).abs().max().item()
+    scale = float(np.abs(g['tiny_logits']).max())
+    print(f'oracle vs HF GPT-2 (tiny): logits {e1:.2e}, multi-stream logits {e2:.2e}, pose prediction {e3:.2e} (|logit| max {scale:.2f})')
+    assert e1 < 2e-6 * scale and e2 < 2e-6 * scale and e3 < 2e-6 * max(1.0, float(np.abs(g['tiny_multi_pose']).max()))
+
+
+def test_oracle_full_size_matches_hugging_face_gpt2():
+    """the bench's transformer (12 layers, d = 768, 12 heads, 6 context views + the MASK view): last-view logits of the fp64 oracle against
+    the fp64 GPT-2 run stored as fp32"""
+    g = _hf()
+    cfg = MIGTConfig(sequence_size=6, n_loss_skip=1, pose_multiplier=0.2, localization_weight='cosine(0,1,120000)')
+    sd = make_migt_weights(cfg, seed=int(g['full_seed']))
+    out = mg.migt_forward(sd, cfg, torch.from_numpy(g['full_ids']), torch.from_numpy(g['full_cams']), dtype=torch.float64)['logits'][:, -1]
+    ref = torch.from_numpy(g['full_logits_last']).double()
+    err = (out - ref).abs().max().item()
+    print(f'oracle vs HF GPT-2 (full size): {err:.2e} of |logit| max {ref.abs().max().item():.3f}')
+    assert err < 2e-6 * max(1.0, ref.abs().max().item())
