@@ -21,9 +21,9 @@ for i, l in enumerate(lines):
         kern = None
         continue
     s = l.strip()
-    if s.startswith(';APP'):
+    if s.startswith((';APP', ';;#ASMSTART')):
         in_app = True
-    elif s.startswith(';NO_APP'):
+    elif s.startswith((';NO_APP', ';;#ASMEND')):
         in_app = False
     m = re.match(r'^(\.LBB\S+):(.*)', l)
     if m:

@@ -4,7 +4,7 @@
 set -u
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r5_clock; mkdir -p $O
+O=$R/gpurun_out/prof_clock; mkdir -p $O
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_instep -o p -- python $R/bench.py --no-cpu-baseline --no-f32-arm --steps 2 --warmup 1 > $O/instep.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_isolated -o p -- python $R/tools/microbench.py attnbf16_io16 vqf convx3h > $O/isolated.log 2>&1
