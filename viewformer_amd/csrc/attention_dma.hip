@@ -69,6 +69,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_PSWAP
 #define ADMA_PSWAP 1
 #endif
+#ifndef ADMA_PAIRGRID
+#define ADMA_PAIRGRID 0     // the query blocks of a (scene, head) adjacent on one XCD (round 5 A/B; 0 = all first blocks, then all second blocks)
+#endif
 constexpr float ADMA_THR = 8.0f;             // a query's reference maximum moves when a tile exceeds it by more than this (exponent-of-2 units)
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
@@ -139,9 +142,27 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     const int half = lane >> 5, l31 = lane & 31;
     // grid (H, B, query blocks): all first blocks (4 key tiles), then all second blocks (8) — measured faster than interleaving the two
     // kinds on a CU (145 us) although the second kind re-reads tiles 0-3 from HBM
+#if ADMA_PAIRGRID
+    // the query blocks of one (scene, head) on ONE XCD, dispatched back to back (heavy block first): the light block's key tiles are then L2 hits
+    int qblk = (int)blockIdx.z, h = (int)blockIdx.x;
+    size_t b = blockIdx.y;
+    {
+        const unsigned NQ = gridDim.z, BH = gridDim.x * gridDim.y;
+        if (NQ > 1 && (BH & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      // dispatch order: XCD = lin % 8
+            const unsigned x = lin & 7u, sl = lin >> 3;
+            const unsigned pr = sl / NQ, zz = sl - pr * NQ;
+            const unsigned bh = x + 8u * pr;
+            qblk = (int)(NQ - 1u - zz);
+            h = (int)(bh % gridDim.x);
+            b = bh / gridDim.x;
+        }
+    }
+#else
     const int qblk = (int)blockIdx.z;
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
+#endif
     const int q0 = qblk * QT;
     // U = 2: wave w is view w of the block.  U = 1: waves w and 7 - w share view min(w, 7 - w) (first / second 32 queries): with waves going
     // to SIMDs round-robin, every SIMD of the CU then hosts an early (few visible tiles) and a late view of the block
