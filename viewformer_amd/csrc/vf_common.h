@@ -305,14 +305,8 @@ __device__ __forceinline__ unsigned vf_lds_addr(const void* p) {          // byt
 __device__ __forceinline__ vf_bf16x8 vf_tr_join(vf_s16x4 lo, vf_s16x4 hi) {
     return __builtin_bit_cast(vf_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// one MFMA operand = two transposing reads `gap` bytes apart (the two 4-row groups of a 32x32x16 operand's 8 consecutive k)
-__device__ __forceinline__ vf_bf16x8 vf_tr_frag_wait(unsigned addr, int off, int gap) {
-    vf_s16x4 a0, a1;
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a0), "=&v"(a1) : "v"(addr), "i"(off), "i"(off + gap) : "memory");
-    return vf_tr_join(a0, a1);
-}
-// two operands (at offA and offB) in one block: four reads in flight, one wait
+// two MFMA operands (at offA and offB), each = two transposing reads `gap` bytes apart (the two 4-row groups of a 32x32x16 operand's 8 consecutive k),
+// in one block: four reads in flight, one wait
 __device__ __forceinline__ void vf_tr_frag2_wait(vf_bf16x8& a, vf_bf16x8& b, unsigned addr, int offA, int offB, int gap) {
     vf_s16x4 a0, a1, b0, b1;
     asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\tds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
