@@ -43,6 +43,11 @@ def worker(rank, n_iter):
             names.sort(key=lambda t: -t[1])
             dm = {k: (mi[k], m0[k]) for k in mi if mi[k] != m0.get(k)}
             print(f'rank {rank} repeat {it}: {len(names)} of {len(tr.slices)} tensors differ; worst {names[:4]}; metrics that differ: {dm}', flush=True)
+            same = [n for n, (a, b, _) in tr.slices.items() if torch.equal(gi[a:b], g0[a:b])]
+            dec_diff = [n for n, _ in sorted(names) if n.startswith(('decoder', 'post_quant'))]
+            dec_same = [n for n in same if n.startswith(('decoder', 'post_quant'))]
+            print(f'   decoder tensors that differ: {dec_diff}', flush=True)
+            print(f'   decoder tensors that are equal: {dec_same}', flush=True)
     print(f'rank {rank}: {bad} of {n_iter - 1} repeats differ from the first', flush=True)
 
 
