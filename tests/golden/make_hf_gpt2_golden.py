@@ -155,6 +155,77 @@ def run(cfg, sd, ids, cams, multi):
     return out
 
 
+def train_graph(cfg, sd, ids, cams):
+    """MIGT.train_step's forward + losses (migt.py:371-448,464-476) on GPT-2 with AUTOGRAD: main stream, MASK stream (output_poses = poses) and
+    LOC stream (localization_tokens = the tokens) — one GPT-2 call per view and branch, as in run(); token cross-entropy on the MASK stream and
+    position / orientation MSE on the LOC stream over views >= n_loss_skip, per-scene means, batch mean.  Returns the loss terms and the
+    gradient w.r.t. every MIGT variable (GPT-2's c_attn gradient permuted back to the reference's (V, Q, K) column order)."""
+    B, S = ids.shape[:2]
+    L = ids.shape[2] * ids.shape[3]
+    m = build_gpt2(cfg, sd)
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    nE, d = cfg.n_embeddings, cfg.d_model
+    mask_tok, loc_tok = nE, nE + 1
+
+    def conv(name):
+        w, b = t(sd, f'{name}.weight'), t(sd, f'{name}.bias').reshape(-1)
+        c = Conv1D(w.shape[1], w.shape[0]).double()
+        with torch.no_grad():
+            c.weight.copy_(w)
+            c.bias.copy_(b)
+        return c
+    mods = {n: conv(n) for n in ('pose_embedding.c_fc', 'pose_embedding.c_proj', 'pose_criterion.pose_classifier.c_fc',
+                                 'pose_criterion.pose_classifier.c_proj')}
+
+    def mlp(name, x):
+        return mods[name + '.c_proj'](torch.nn.functional.gelu(mods[name + '.c_fc'](x.contiguous())))
+    wte = m.wte.weight
+    pin = torch.cat([cams[..., :3] * cfg.pose_multiplier, cams[..., 3:]], -1)
+    pose = mlp('pose_embedding', pin)[:, :, None, :]
+    posv = torch.arange(L).repeat(S)[None].expand(B, -1)
+    idl = ids.reshape(B, S, L)
+
+    def gpt2(emb_views):
+        V = emb_views.shape[1]
+        view = torch.arange(V).repeat_interleave(L)
+        mask = torch.where(view[:, None] >= view[None, :], 0.0, -1e4).double()[None, None].expand(B, 1, -1, -1)
+        return m(inputs_embeds=emb_views.reshape(B, V * L, -1), position_ids=posv[:, :V * L], attention_mask=mask).last_hidden_state.reshape(B, V, L, -1)
+    main = wte[idl] + pose
+    mask_stream = wte[mask_tok].reshape(1, 1, 1, -1) + pose.expand(B, S, L, -1)
+    loc_stream = wte[idl] + wte[loc_tok].reshape(1, 1, 1, -1)
+    skip = cfg.n_loss_skip
+    ce_v, pos_v, ori_v = [], [], []
+    y = cams.unsqueeze(-2) * torch.tensor([cfg.pose_multiplier] * 3 + [1.0] * 4, dtype=F64)
+    for i in range(S):
+        hm = gpt2(torch.cat([main[:, :i], mask_stream[:, i:i + 1]], 1))[:, -1]            # [B,L,d]
+        hl = gpt2(torch.cat([main[:, :i], loc_stream[:, i:i + 1]], 1))[:, -1]
+        lg = (hm @ wte.t())[..., :nE]
+        ce_v.append(torch.nn.functional.cross_entropy(lg.reshape(-1, nE), idl[:, i].reshape(-1), reduction='none').reshape(B, L))
+        raw = mlp('pose_criterion.pose_classifier', hl)
+        pos_v.append(((y[:, i, :, :3] - raw[..., :3]) ** 2).mean(-1))
+        ori_v.append(((y[:, i, :, 3:] - raw[..., 3:]) ** 2).mean(-1))
+    ce = torch.stack(ce_v, 1)[:, skip:].mean((1, 2))
+    pos = torch.stack(pos_v, 1)[:, skip:].mean((1, 2))
+    ori = torch.stack(ori_v, 1)[:, skip:].mean((1, 2))
+    w = float(cfg.localization_weight)
+    loss = (ce * cfg.image_generation_weight + (pos + ori) * w).mean()
+    loss.backward()
+    g = {'wte.weight': m.wte.weight.grad, 'wpe.embeddings': m.wpe.weight.grad, 'ln_f.gamma': m.ln_f.weight.grad, 'ln_f.beta': m.ln_f.bias.grad}
+    for i in range(cfg.n_layer):
+        blk, p_ = m.h[i], f'h.{i}.'
+        gw, gb = blk.attn.c_attn.weight.grad, blk.attn.c_attn.bias.grad
+        g[p_ + 'attn.c_attn.weight'] = torch.cat([gw[:, 2 * d:], gw[:, :d], gw[:, d:2 * d]], 1)        # (Q, K, V) -> (V, Q, K)
+        g[p_ + 'attn.c_attn.bias'] = torch.cat([gb[2 * d:], gb[:d], gb[d:2 * d]])
+        for a, mod in (('ln_1', blk.ln_1), ('ln_2', blk.ln_2)):
+            g[p_ + a + '.gamma'], g[p_ + a + '.beta'] = mod.weight.grad, mod.bias.grad
+        for a, mod in (('attn.c_proj', blk.attn.c_proj), ('mlp.c_fc', blk.mlp.c_fc), ('mlp.c_proj', blk.mlp.c_proj)):
+            g[p_ + a + '.weight'], g[p_ + a + '.bias'] = mod.weight.grad, mod.bias.grad
+    for n, c in mods.items():
+        g[n + '.weight'], g[n + '.bias'] = c.weight.grad, c.bias.grad
+    return dict(loss=float(loss), ce=float(ce.mean()), pos=float(pos.mean()), ori=float(ori.mean())), g
+
+
 def main():
     res = {}
     # ---- tiny: the HIP kernels' small test shape (tests/conftest.py TINY_MIGT + a localization head)
@@ -170,6 +241,18 @@ def main():
     mo = run(cfg, sd, ids, cams, True)
     res['tiny_multi_logits'] = mo['logits'].numpy().astype(np.float32)
     res['tiny_multi_pose'] = mo['pose_prediction'].numpy().astype(np.float32)
+    # ---- the training graph with autograd (tiny shape, constant localization weight): loss terms, and per variable the gradient's L2 norm and 48
+    # entries at fixed pseudo-random positions (the whole gradient would be 3.4 MB)
+    tcfg = MIGTConfig(**dict(tiny, localization_weight='2', n_loss_skip=1))
+    lossd, grads = train_graph(tcfg, sd, ids, cams)
+    rng = np.random.default_rng(77)
+    res.update(train_loss=lossd['loss'], train_ce=lossd['ce'], train_pos=lossd['pos'], train_ori=lossd['ori'])
+    names = sorted(grads)
+    res['train_names'] = np.array(names)
+    res['train_norms'] = np.array([float(grads[n].norm()) for n in names])
+    idx = [rng.integers(0, grads[n].numel(), size=48) for n in names]
+    res['train_idx'] = np.stack(idx)
+    res['train_samples'] = np.stack([grads[n].reshape(-1)[torch.from_numpy(i)].numpy() for n, i in zip(names, idx)])
     # ---- full size: the bench's transformer (SM7: 6 context views + the MASK view), last-view logits
     cfg = MIGTConfig(sequence_size=6, n_loss_skip=1, pose_multiplier=0.2, localization_weight='cosine(0,1,120000)')
     sd = make_migt_weights(cfg, seed=0)

@@ -247,3 +247,30 @@ def test_oracle_full_size_matches_hugging_face_gpt2():
     err = (out - ref).abs().max().item()
     print(f'oracle vs HF GPT-2 (full size): {err:.2e} of |logit| max {ref.abs().max().item():.3f}')
     assert err < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_training_losses_and_gradients_match_hugging_face_gpt2_autograd():
+    """the TRAINING graph (MIGT.train_step: main + MASK + LOC stream, token cross-entropy and pose MSE over views >= n_loss_skip, batch mean) built
+    on ``transformers``' GPT-2 with torch autograd (tests/golden/make_hf_gpt2_golden.py::train_graph: one GPT-2 call per view and branch, losses
+    written out there independently of oracle/): the loss terms and the gradient of EVERY variable — L2 norm and 48 sampled entries per tensor,
+    GPT-2's c_attn gradient permuted back to (V, Q, K) — against fp64 autograd over oracle/train_oracle.py.  The HIP training step is tested
+    against that oracle (tests/test_train.py), so its forward, losses and backward now hang on a third-party implementation too."""
+    from oracle import train_oracle as to
+    g = _hf()
+    cfg = MIGTConfig(n_embeddings=64, n_head=2, d_model=128, n_layer=2, token_image_size=4, sequence_size=4, localization_weight='2', pose_multiplier=0.2,
+                     n_loss_skip=1, dropout=0.0)
+    sd = make_migt_weights(cfg, seed=int(g['tiny_seed']), std=float(g['tiny_std']))
+    grads, met = to.gradients(sd, cfg, torch.from_numpy(g['tiny_cams']), torch.from_numpy(g['tiny_ids']), step=0)
+    assert abs(met['loss'] - float(g['train_loss'])) < 1e-6 and abs(met['ce_loss'] - float(g['train_ce'])) < 1e-6
+    assert abs(met['pose_pos_loss'] - float(g['train_pos'])) < 1e-6 and abs(met['pose_ori_loss'] - float(g['train_ori'])) < 1e-6
+    names = [str(n) for n in g['train_names']]
+    assert set(names) == {k for k in sd if k != 'pose_loss_weighting_criterion.pos_ori_weights'}
+    worst = 0.0
+    for i, n in enumerate(names):
+        ref_norm = float(g['train_norms'][i])
+        got = grads[n].reshape(-1).double()
+        samp = got[torch.from_numpy(g['train_idx'][i])]
+        e = max(abs(float(got.norm()) - ref_norm), float((samp - torch.from_numpy(g['train_samples'][i]).double()).abs().max()))
+        worst = max(worst, e / max(ref_norm, 1e-12))
+        assert e <= 2e-6 * max(ref_norm, 1e-9) + 1e-12, (n, e, ref_norm)
+    print(f'oracle autograd vs HF GPT-2 autograd: loss {met["loss"]:.6f} == {float(g["train_loss"]):.6f}; worst gradient deviation {worst:.2e} of the tensor norm over {len(names)} variables')

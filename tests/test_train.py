@@ -250,6 +250,36 @@ def test_train_step_gradients_match_autograd(dev, loc, arith):
 
 
 @pytest.mark.gpu
+def test_train_step_matches_hugging_face_gpt2_autograd_golden(dev):
+    """the HIP training step against a THIRD-PARTY graph: tests/golden/migt_hf_gpt2.npz holds the loss terms and, per variable, the gradient's
+    norm and 48 sampled entries of MIGT.train_step's forward + losses built on ``transformers``' GPT-2 with torch autograd
+    (tests/golden/make_hf_gpt2_golden.py::train_graph).  fp32-equivalent arm, dropout 0, constant localization weight."""
+    from conftest import load_golden
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    g = load_golden('migt_hf_gpt2.npz')
+    cfg = MIGTConfig(n_embeddings=64, n_head=2, d_model=128, n_layer=2, token_image_size=4, sequence_size=4, localization_weight='2', pose_multiplier=0.2,
+                     n_loss_skip=1, dropout=0.0, learning_rate=1e-3, weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=int(g['tiny_seed']), std=float(g['tiny_std']))
+    tr = MIGTTrainer(MIGT(cfg).load_state_dict(sd).to(dev), warmup_steps=4)
+    met = tr.train_step(torch.from_numpy(g['tiny_cams']), torch.from_numpy(g['tiny_ids']), reduce_gradients=False, apply_update=False)
+    assert abs(float(met['loss']) - float(g['train_loss'])) < 1e-4 * float(g['train_loss'])
+    assert abs(float(met['ce_loss']) - float(g['train_ce'])) < 1e-4 * float(g['train_ce'])
+    assert abs(float(met['pose_pos_loss']) - float(g['train_pos'])) < 1e-4 and abs(float(met['pose_ori_loss']) - float(g['train_ori'])) < 1e-4
+    worst = ('', 0.0)
+    for i, n in enumerate(str(x) for x in g['train_names']):
+        got = tr.g(n).reshape(-1).double().cpu()
+        ref_norm = float(g['train_norms'][i])
+        e = max(abs(float(got.norm()) - ref_norm), float((got[torch.from_numpy(g['train_idx'][i])] - torch.from_numpy(g['train_samples'][i]).double()).abs().max()))
+        if e / max(ref_norm, 1e-12) > worst[1]:
+            worst = (n, e / max(ref_norm, 1e-12))
+        assert e < 2e-3 * max(ref_norm, 1e-9), (n, e, ref_norm)
+    print('HIP training step vs HF GPT-2 autograd golden: worst gradient deviation (of the tensor norm)', worst)
+
+
+@pytest.mark.gpu
 def test_train_steps_follow_the_optimizer_restatement(dev):
     """3 full steps (forward, backward, AdamWeightDecay with warm-up) vs autograd + numpy optimizer on the oracle"""
     from oracle import train_oracle as to
