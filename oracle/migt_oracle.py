@@ -12,6 +12,13 @@ cannot be checked against the reference's own outputs.  It follows the
 reference line by line (citations below) and is pinned only by the structural
 invariants of SURVEY.md §8(c) (tests/test_oracle_migt.py): single-stream ==
 dense masked attention, branch equivalence, train/infer consistency, fp64 arm.
+Since round 5 it is additionally ANCHORED TO A THIRD-PARTY IMPLEMENTATION (still
+not the reference): tests/golden/migt_hf_gpt2.npz holds outputs of Hugging Face
+``transformers``' GPT-2 on MIGT weights — no score scaling, (V, Q, K) split,
+block-causal 0 / -1e4 mask expressed through GPT-2's own config and inputs
+(tests/golden/make_hf_gpt2_golden.py) — which this file reproduces to 2e-7
+(single-stream and multi-stream logits, camera predictions, full-size logits)
+and, through train_oracle.py, to 1e-8 of every gradient of the training graph.
 Third-party arithmetic restated from its documented behaviour: tf.nn.gelu
 (exact erf form), LayerNormalization(eps=1e-5), tf.nn.softmax,
 tf.linalg.l2_normalize(eps=1e-12): x * rsqrt(max(sum(x^2), eps)).

@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, NOT product code) — CPU restatement of one MIGT training step.
 
-Only ``tests/`` may import this module.  PARITY UNPINNED (TensorFlow absent, see migt_oracle.py): the
+Only ``tests/`` may import this module.  PARITY UNPINNED (TensorFlow absent, see migt_oracle.py; anchored since round 5 to torch autograd
+over Hugging Face GPT-2 on the same graph: loss terms to 1e-6, every gradient to 1e-8 — tests/golden/make_hf_gpt2_golden.py::train_graph): the
 losses restate viewformer/models/migt.py:416-448 and QuaternionPoseRepresentation.call :156-177 on top of the
 multi-stream forward of migt_oracle.migt_forward; gradients come from torch autograd (fp64) over that
 restatement, and the optimizer restates AdamWeightDecay / WarmUp / CosineDecay / Keras Adam
