@@ -46,8 +46,11 @@ def worker(rank, n_iter):
             same = [n for n, (a, b, _) in tr.slices.items() if torch.equal(gi[a:b], g0[a:b])]
             dec_diff = [n for n, _ in sorted(names) if n.startswith(('decoder', 'post_quant'))]
             dec_same = [n for n in same if n.startswith(('decoder', 'post_quant'))]
-            print(f'   decoder tensors that differ: {dec_diff}', flush=True)
-            print(f'   decoder tensors that are equal: {dec_same}', flush=True)
+            # backward order = reverse of the forward's parameter order: the LAST name (in state-dict order) that differs is where the error entered
+            order = list(tr.slices)
+            differing = {n for n, _ in names}
+            last = max(i for i, n in enumerate(order) if n in differing)
+            print(f'   entered at: {order[last]}  (next in forward order, equal: {order[last + 1:last + 4]})', flush=True)
     print(f'rank {rank}: {bad} of {n_iter - 1} repeats differ from the first', flush=True)
 
 
