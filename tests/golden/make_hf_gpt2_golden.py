@@ -262,6 +262,22 @@ def main():
     cams = relative_normalized(cams_raw)
     full = run(cfg, sd, ids, cams, False)['logits'][:, -1]
     res.update(full_seed=0, full_ids=ids.numpy(), full_cams=cams.numpy().astype(np.float32), full_logits_last=full.numpy().astype(np.float32))
+    # ---- full size, the LOCALIZATION pass of the evaluator (evaluate_transformer.py:134-140; migt.py:369,387-390,430-451): real codes in every view,
+    # cameras of the 6 context views only — the last view carries the LOC token's embedding instead of a pose embedding — and the camera head on it
+    codes = torch.from_numpy(g.integers(0, 1024, size=(1, 7, 8, 8)))
+    m = build_gpt2(cfg, sd)
+    wte = t(sd, 'wte.weight')
+    pin = torch.cat([cams[:, :-1, :3] * cfg.pose_multiplier, cams[:, :-1, 3:]], -1)
+    pe = torch.cat([hf_mlp(sd, 'pose_embedding', pin), wte[cfg.n_embeddings + 1].reshape(1, 1, -1)], 1)[:, :, None, :]        # [1,7,1,d]
+    emb = wte[codes.reshape(1, 7, 64)] + pe
+    view = torch.arange(7).repeat_interleave(64)
+    mask = torch.where(view[:, None] >= view[None, :], 0.0, -1e4).double()[None, None]
+    with torch.no_grad():
+        h = m(inputs_embeds=emb.reshape(1, 448, -1), position_ids=torch.arange(64).repeat(7)[None], attention_mask=mask).last_hidden_state.reshape(1, 7, 64, -1)
+    y = hf_mlp(sd, 'pose_criterion.pose_classifier', h[:, -1])
+    qn = y[..., 3:] * torch.rsqrt((y[..., 3:] ** 2).sum(-1, keepdim=True).clamp_min(1e-12))
+    qn = qn * (2 * (qn[..., :1] >= 0).double() - 1)
+    res.update(full_loc_codes=codes.numpy(), full_loc_pose_last=torch.cat([y[..., :3] / cfg.pose_multiplier, qn], -1).numpy().astype(np.float32))
     out = os.path.join(REPO, 'tests', 'golden', 'migt_hf_gpt2.npz')
     np.savez_compressed(out, **res)
     print('wrote', out, {k: getattr(v, 'shape', v) for k, v in res.items()})

@@ -192,6 +192,11 @@ def test_migt_matches_hugging_face_gpt2_golden(dev):
         err = _maxerr(last.reshape(ref.shape), ref)
         print(f'HIP vs HF GPT-2 golden (full size, {arm} arm): {err:.2e} of |logit| max {float(ref.abs().max()):.3f}')
         assert err < tol, (arm, err)
+        # the localization pass (evaluate_transformer.py:134-140): LOC embedding on the last view, camera head on its tokens
+        loc = mm(dict(input_ids=torch.from_numpy(g['full_loc_codes']).to(dev), poses=fcams[:, :-1].contiguous()))['pose_prediction'][:, -1]
+        e_loc = _maxerr(loc, torch.from_numpy(g['full_loc_pose_last']))
+        print(f'   localization pass, camera head: {e_loc:.2e}')
+        assert e_loc < (2e-4 if arm == 'f32' else 5e-2), (arm, e_loc)
 
 
 # ------------------------------------------------------------------------------------------------ pipeline

@@ -247,6 +247,12 @@ def test_oracle_full_size_matches_hugging_face_gpt2():
     err = (out - ref).abs().max().item()
     print(f'oracle vs HF GPT-2 (full size): {err:.2e} of |logit| max {ref.abs().max().item():.3f}')
     assert err < 2e-6 * max(1.0, ref.abs().max().item())
+    # the evaluator's localization pass (evaluate_transformer.py:134-140): real codes everywhere, cameras of the context views only, LOC embedding
+    # on the last view, camera head on its 64 tokens
+    loc = mg.migt_forward(sd, cfg, torch.from_numpy(g['full_loc_codes']), torch.from_numpy(g['full_cams'])[:, :-1], dtype=torch.float64)
+    e_loc = (loc['pose_prediction'][:, -1] - torch.from_numpy(g['full_loc_pose_last']).double()).abs().max().item()
+    print(f'oracle vs HF GPT-2 (full size, localization pass): camera head {e_loc:.2e}')
+    assert e_loc < 2e-6
 
 
 def test_training_losses_and_gradients_match_hugging_face_gpt2_autograd():
