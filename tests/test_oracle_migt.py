@@ -280,3 +280,29 @@ def test_training_losses_and_gradients_match_hugging_face_gpt2_autograd():
         worst = max(worst, e / max(ref_norm, 1e-12))
         assert e <= 2e-6 * max(ref_norm, 1e-9) + 1e-12, (n, e, ref_norm)
     print(f'oracle autograd vs HF GPT-2 autograd: loss {met["loss"]:.6f} == {float(g["train_loss"]):.6f}; worst gradient deviation {worst:.2e} of the tensor norm over {len(names)} variables')
+
+
+def test_relative_camera_frame_change_matches_scipy_rotations():
+    """evaluate_transformer.py:70-94 / geometry_tf.py:6-13,53-68 restated in oracle/ and in viewformer_amd/geometry.py against a third-party
+    implementation: scipy.spatial.transform.Rotation (positions rotated by the inverse of the first view's rotation after subtracting its
+    position; orientations composed with that inverse; unit quaternion with w >= 0).  Quaternions are (w, x, y, z) in the reference, (x, y, z, w)
+    in scipy."""
+    from scipy.spatial.transform import Rotation as R
+    from viewformer_amd import geometry
+    _, cams = synthetic_scene_batch(3, 6, 8, 17)
+    cams = torch.from_numpy(cams).double()
+    rel, _ = mg.to_relative_cameras(cams)
+    rel = mg.normalize_cameras(rel)
+    rel_p = geometry.normalize_cameras(geometry.to_relative_cameras(cams.float())[0]).double()
+    for b in range(cams.shape[0]):
+        q = cams[b, :, 3:].numpy()
+        rot = R.from_quat(np.concatenate([q[:, 1:], q[:, :1]], 1))             # scipy: scalar last
+        r0inv = rot[0].inv()
+        pos = r0inv.apply((cams[b, :, :3] - cams[b, :1, :3]).numpy())
+        qq = (r0inv * rot).as_quat()
+        qq = np.concatenate([qq[:, 3:], qq[:, :3]], 1)
+        qq = qq * np.where(qq[:, :1] >= 0, 1.0, -1.0)
+        want = torch.from_numpy(np.concatenate([pos, qq], 1))
+        # (the inputs' quaternions are unit to fp32 precision only: the reference rotates by the CONJUGATE, scipy by the normalised inverse: 1e-7)
+        assert (rel[b] - want).abs().max() < 1e-6, (rel[b] - want).abs().max()
+        assert (rel_p[b] - want).abs().max() < 3e-6
