@@ -134,3 +134,80 @@ def test_optimizer_slots_key_mapping_roundtrip():
     both = dict(ck.state_dict_to_keras({'ln_f.gamma': np.ones(4, np.float32)}), **k)
     assert list(ck.keras_to_state_dict(both)) == ['ln_f.gamma']
     assert 'm/ln_f.gamma' not in ck.keras_optimizer_state(both) and 'v/ln_f.gamma' in ck.keras_optimizer_state(both)
+
+
+def _bundle_classes():
+    """BundleHeaderProto / BundleEntryProto / TensorShapeProto / VersionDef rebuilt from descriptors (tensorflow/core/protobuf/tensor_bundle.proto,
+    framework/tensor_shape.proto, framework/versions.proto — message and field numbers as published) for the OFFICIAL protobuf runtime"""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name='vf_bundle.proto', package='tensorflow', syntax='proto3')
+    F = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, parent=None):
+        m = (parent.nested_type if parent is not None else fd.message_type).add()
+        m.name = name
+        return m
+
+    def field(m, name, number, ftype, label=F.LABEL_OPTIONAL, type_name=None):
+        f = m.field.add(name=name, number=number, type=ftype, label=label)
+        if type_name:
+            f.type_name = type_name
+    shape = msg('TensorShapeProto')
+    dim = msg('Dim', shape)
+    field(dim, 'size', 1, F.TYPE_INT64)
+    field(dim, 'name', 2, F.TYPE_STRING)
+    field(shape, 'dim', 2, F.TYPE_MESSAGE, F.LABEL_REPEATED, '.tensorflow.TensorShapeProto.Dim')
+    field(shape, 'unknown_rank', 3, F.TYPE_BOOL)
+    ver = msg('VersionDef')
+    field(ver, 'producer', 1, F.TYPE_INT32)
+    field(ver, 'min_consumer', 2, F.TYPE_INT32)
+    hdr = msg('BundleHeaderProto')
+    field(hdr, 'num_shards', 1, F.TYPE_INT32)
+    field(hdr, 'endianness', 2, F.TYPE_INT32)            # (an enum on the wire is a varint)
+    field(hdr, 'version', 3, F.TYPE_MESSAGE, type_name='.tensorflow.VersionDef')
+    ent = msg('BundleEntryProto')
+    field(ent, 'dtype', 1, F.TYPE_INT32)                 # DataType enum
+    field(ent, 'shape', 2, F.TYPE_MESSAGE, type_name='.tensorflow.TensorShapeProto')
+    field(ent, 'shard_id', 3, F.TYPE_INT32)
+    field(ent, 'offset', 4, F.TYPE_INT64)
+    field(ent, 'size', 5, F.TYPE_INT64)
+    field(ent, 'crc32c', 6, F.TYPE_FIXED32)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, 'GetMessageClass', None) or (lambda d: message_factory.MessageFactory(pool).GetPrototype(d))
+    return get(pool.FindMessageTypeByName('tensorflow.BundleHeaderProto')), get(pool.FindMessageTypeByName('tensorflow.BundleEntryProto'))
+
+
+def test_bundle_protos_match_the_protobuf_runtime(tmp_path):
+    """the proto layer of the TensorBundle reader / writer against the official protobuf runtime (the SSTable layer under it and TensorFlow's own
+    files remain unpinned: f2 stays partial): entries and the header as this module writes them are byte-identical to the runtime's serialisation
+    of the published messages, the reader parses what the runtime writes, and the entries of a bundle written here parse with the runtime."""
+    from viewformer_amd import checkpoint as ck
+    Header, Entry = _bundle_classes()
+    cases = [(1, (768, 2304), 0, 0, 768 * 2304 * 4, 0xdeadbeef), (9, (), 0, 4096, 8, 1), (1, (1, 3072), 2, 123456789012, 12288, 0xffffffff),
+             (3, (0,), 0, 7, 0, 0)]
+    for dtype, shape, shard, off, size, crc in cases:
+        e = Entry(dtype=dtype, shard_id=shard, offset=off, size=size, crc32c=crc)
+        for d in shape:
+            e.shape.dim.add(size=d)
+        if not shape:
+            e.shape.SetInParent()
+        official = e.SerializeToString(deterministic=True)
+        mine = ck._entry_proto(dtype, shape, shard, off, size, crc)
+        back = Entry.FromString(mine)
+        assert (back.dtype, [d.size for d in back.shape.dim], back.shard_id, back.offset, back.size, back.crc32c) == (dtype, list(shape), shard, off, size, crc)
+        p = ck._parse_entry(official)
+        assert (p['dtype'], p['shape'], p['shard'], p['offset'], p['size']) == (dtype, list(shape), shard, off, size)
+        assert p['crc'] == (crc if crc else None)             # (proto3 omits a zero crc: the reader then has nothing to check)
+        if crc:                                            # (proto3 omits zero scalars; this writer always emits size and crc: equal bytes when non-zero)
+            assert mine == official or size == 0, (mine.hex(), official.hex())
+    h = Header(num_shards=1)
+    h.version.producer = 1
+    prefix = str(tmp_path / 'm')
+    ck.write_tensor_bundle(prefix, {'a/b': np.arange(6, dtype=np.float32).reshape(2, 3), 'c': np.array(7, dtype=np.int64)})
+    table = ck._read_table(prefix + '.index')
+    assert table[b''] == h.SerializeToString(deterministic=True)              # the header entry, byte for byte
+    for key, raw in table.items():
+        if key:
+            ent = Entry.FromString(raw)
+            assert ent.size == {b'a/b': 24, b'c': 8}[key] and ent.dtype in (1, 9) and ent.crc32c != 0

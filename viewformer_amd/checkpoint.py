@@ -15,8 +15,10 @@ with ``.config`` populated and weights loaded through ``load_state_dict`` (missi
 
 PINNING: the torch half is pinned by ``tests/golden/vqgan_tiny_model/`` (config.json + model.ckpt), written by the
 reference's own classes (``tests/golden/make_ckpt_golden.py``).  The TensorBundle half is **parity unpinned**: TensorFlow is not in the image, so the
-reader is checked against this module's own writer, the published format constants (table magic, block trailer, proto
-field numbers of tensor_bundle.proto) and the CRCs; it has never seen a file written by TensorFlow itself.
+reader is checked against this module's own writer, the published format constants (table magic, block trailer) and the CRCs, and —
+round 5 — its proto layer (BundleHeaderProto / BundleEntryProto / TensorShapeProto) against the OFFICIAL protobuf runtime with the messages rebuilt
+from descriptors (byte-identical header and entries, cross-parsing both ways: tests/test_checkpoint.py); the SSTable layer under it has never seen
+a file written by TensorFlow itself.
 """
 import json
 import os
