@@ -184,3 +184,22 @@ def test_bare_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'], cwd=repo,
                        env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bare_bench_with_the_gloo_switch_reaches_the_launcher():
+    """the other branch of bench.py's self-launch on a box without GPUs: with VF_DIST_BACKEND=gloo the bare ``--gpus 2`` is NOT refused — it starts
+    ``torch.distributed.run`` with two ranks (announced on stderr), each of which then fails loudly because the hot path has no CPU fallback; the
+    parent returns the launcher's non-zero status and prints no JSON line.  (On a GPU box the same command produces the n_gpus = 2 line:
+    tests/test_hip_multigpu.py.)"""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip('CPU-box branch')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['VF_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '1'], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert 'starting 2 ranks' in r.stderr and '--nproc-per-node=2' in r.stderr, r.stderr[-800:]
+    assert r.returncode != 0 and 'bench.py needs the MI355X' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
