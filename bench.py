@@ -325,14 +325,14 @@ def run_train(args, rank, local, world, dev):
     grad_mb = sum(int(t.numel()) for t in [tr.flat_g]) * 4 / 2 ** 20
     peak = BF16_MFMA_PEAK_TFLOPS if arm == 'bf16' else BF16_MFMA_PEAK_TFLOPS / 6
     line = {'metric': 'MIGT training scenes/sec (3-stream forward, losses, backward, AdamWeightDecay), CO3D 10-cat finetune config',
-            'value': round(scenes / dt, 3), 'unit': 'scenes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(scenes / dt, 3), 'unit': 'scenes/s', 'n_gpus': world, 'shared_device': args.dist['shared_device'], 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if arm == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'CO3D 10-cat training step, DP scene-batch shard + RCCL grad all-reduce (BASELINE.json configs[3])',
                        'scenes_per_gpu_per_step': B, 'views_per_scene': S, 'streams': 3, 'tokens_per_scene': 3 * S * 64,
                        'parallelism': f'dp{world}: per-replica mean loss, gradients SUMmed (migt.py:471-476,488), all-reduce per layer range '
                                       'overlapped with the backward pass', 'ranks': args.dist['ranks'], 'backend': args.dist['backend'],
-                       'communicator_world_size': args.dist['ranks'], 'dist': args.dist, 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
+                       'communicator_world_size': args.dist['communicator_world_size'], 'dist': args.dist, 'gradient_mib': round(grad_mb, 1), 'dropout': args.dropout,
                        'dropout_note': 'the reference trains with MIGTConfig.dropout = 0.1 (models/config.py:66) at four sites (migt.py:72,216,403, '
                                        'branching_attention.py:15-17); counter-based masks recomputed in the backward pass, inside the GEMM '
                                        'epilogues / LayerNorm backward / flash attention kernels of the bf16 arm',
@@ -387,7 +387,7 @@ def run_allimg(args, rank, local, world, dev):
     att = prof.attn_entry()
     prof.uninstall()
     line = {'metric': 'generated views/sec, all-images evaluator loop (encode sequence -> multi-context transformer -> decode), 128px',
-            'value': round(n_img / dt, 3), 'unit': 'generated views/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(n_img / dt, 3), 'unit': 'generated views/s', 'n_gpus': world, 'shared_device': args.dist['shared_device'], 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'fp8 attention / bf16 dense' if tr.attention == 'fp8' else 'bf16', 'data': 'synthetic',
             'config': {'workload': f'CO3D-all 128px inference, {tr.attention} MFMA attention (the arm this line ran), large-batch decode '
@@ -417,27 +417,95 @@ def self_launch(args):
     if ndev < args.gpus and backend != 'gloo':
         raise SystemExit(f'bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to run {args.gpus} ranks (RCCL needs one device per '
                          f'rank; VF_DIST_BACKEND=gloo lets ranks share a device for plumbing tests only)')
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))   # dmabuf IPC for RCCL
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous picks a free port itself (no bind-close-reuse race under parallel runs), on 127.0.0.1
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write(f'bench.py: no launcher in the environment, starting {args.gpus} ranks: {" ".join(cmd[1:8])} ...\n')
     sys.stderr.flush()
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def dist_info(world):
-    """what actually ran, for the line's ``config``: ranks, transport, and the communicator's own world size"""
+    """what actually ran, for the line's ``config``: ranks, transport, the communicator's OWN world size (queried from the process group, not
+    copied from the flags) and whether ranks shared a device (the gloo plumbing configuration of the 1-GPU test boxes)"""
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()
     if world > 1 and dist.is_initialized():
-        return {'ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'launcher': 'torch.distributed.run, one process per rank',
-                'devices_visible': torch.cuda.device_count()}
-    return {'ranks': 1, 'backend': None, 'launcher': 'single process', 'devices_visible': torch.cuda.device_count()}
+        return {'ranks': world, 'communicator_world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                'launcher': 'torch.distributed.run, one process per rank', 'devices_visible': ndev, 'shared_device': ndev < world}
+    return {'ranks': 1, 'communicator_world_size': 1, 'backend': None, 'launcher': 'single process', 'devices_visible': ndev,
+            'shared_device': False}
+
+
+LAYER_GRADIENT_FLOATS = 12 * 768 * 768 + 13 * 768                # one transformer layer's range of the flat gradient buffer: 28.4 MB fp32
+ENCODER_LIVE_BYTES_PER_IMAGE = 50.3e6                            # DESIGN §5: 896 images = one encoder chunk ~ 45 GB of live fp32 activations
+
+
+def preflight(args, rank, local, world, dev, iters=None):
+    """Multi-GPU pre-flight — everything a first run on an N-GPU node depends on that a 1-GPU box never exercised, in a few
+    seconds and BEFORE the timed run: this rank's device binding, the communicator (RCCL unless VF_DIST_BACKEND=gloo; created here also at world
+    1), ``iters`` SUM all-reduces of one layer's gradient range (28 MB fp32 — the training step's collective unit, train.py) timed with HIP
+    events, and the HBM headroom for one encoder chunk.  Returns the dict rank 0 prints (one JSON line); fields: DESIGN §8."""
+    import torch.distributed as dist
+    made_group = False
+    if not dist.is_initialized():                                 # world 1: still build a communicator — RCCL must load and reduce on this box
+        import tempfile
+        backend = os.environ.get('VF_DIST_BACKEND') or 'nccl'
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        store = tempfile.NamedTemporaryFile(prefix='vf_preflight_', delete=False)
+        store.close()
+        os.unlink(store.name)
+        dist.init_process_group(backend, init_method=f'file://{store.name}', rank=0, world_size=1)
+        made_group = True
+    backend = dist.get_backend()
+    n = dist.get_world_size()
+    iters = iters or (100 if backend == 'nccl' else 10)
+    buf = torch.ones(LAYER_GRADIENT_FLOATS, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.fill_(1.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    # correctness of the reduction itself: iters SUMs of a buffer of ones = n ** iters (exact in fp32 while it stays below 2 ** 24 — checked on a
+    # fresh buffer with one reduction, which every world size passes exactly)
+    chk = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    sum_ok = bool((chk == n * (n + 1) / 2).all().item())
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    S = args.views or 7
+    B = args.batch or (128 if S == 7 else -(-900 // S))
+    chunk_images = min(B * S, args.encoder_chunk)
+    need = chunk_images * ENCODER_LIVE_BYTES_PER_IMAGE + 1.3e9          # + replicated weights and packed copies
+    mine = {'rank': rank, 'device': torch.cuda.current_device(), 'device_name': torch.cuda.get_device_name(dev),
+            'hbm_free_gb': round(free_b / 1e9, 1), 'hbm_total_gb': round(total_b / 1e9, 1),
+            'hbm_headroom_gb_after_encoder_chunk': round((free_b - need) / 1e9, 1)}
+    allr = [None] * n
+    dist.all_gather_object(allr, mine)
+    t = torch.tensor([ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst_ms = float(t.item())
+    nbytes = LAYER_GRADIENT_FLOATS * 4
+    algbw = nbytes / (worst_ms * 1e-3) / 1e9
+    out = {'preflight': 'ok' if sum_ok and all(r['hbm_headroom_gb_after_encoder_chunk'] > 0 for r in allr) else 'FAILED',
+           'ranks': n, 'backend': backend, 'devices_visible': torch.cuda.device_count(), 'shared_device': torch.cuda.device_count() < n,
+           'allreduce': {'bytes': nbytes, 'iters': iters, 'ms_max_over_ranks': round(worst_ms, 4), 'algbw_gbs': round(algbw, 2),
+                         'busbw_gbs': round(algbw * 2 * (n - 1) / n, 2) if n > 1 else None, 'sum_exact': sum_ok,
+                         'note': 'one transformer layer range of the gradient buffer, SUM, fp32; busbw = algbw x 2(n-1)/n (ring accounting); '
+                                 'DESIGN §8: the per-layer all-reduce hides behind the next layer\'s backward above ~50 GB/s busbw'},
+           'encoder_chunk': {'images': chunk_images, 'estimated_live_gb': round(need / 1e9, 1)},
+           'per_rank': allr}
+    if made_group:
+        dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -479,6 +547,10 @@ def main():
     ap.add_argument('--serial-wgrad', action='store_true',
                     help='train: keep the weight-gradient GEMMs on the main stream in every step (for kernel traces whose durations are not '
                          'stretched by a concurrent kernel; the default overlaps them with the dX GEMMs on a second stream)')
+    ap.add_argument('--preflight', action='store_true',
+                    help='multi-GPU pre-flight only: bind devices, create the communicator, time 100 all-reduces of one layer\'s 28 MB gradient '
+                         'range, report bus GB/s and per-rank HBM headroom for one encoder chunk, print ONE JSON line and exit (with N > 1 ranks the '
+                         'same line goes to stderr before every timed run)')
     ap.add_argument('--batch-sweep', default=None,
                     help='views workload: comma-separated scenes-per-step list (SURVEY 8d: 1,8,64,256,1024); prints ONE JSON line with the '
                          'views/s of every batch size (same models, inputs resident in HBM, --steps timed steps each)')
@@ -498,6 +570,18 @@ def main():
     args.dist = dist_info(world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if args.preflight or world > 1:
+        pf = preflight(args, rank, local, world, dev)
+        if rank == 0:
+            (sys.stdout if args.preflight else sys.stderr).write(json.dumps(pf) + '\n')
+            (sys.stdout if args.preflight else sys.stderr).flush()
+        if args.preflight:
+            sharding.barrier()
+            if world > 1:
+                torch.distributed.destroy_process_group()
+            if pf['preflight'] != 'ok':
+                raise SystemExit(1)
+            return
     if args.workload != 'views':
         (run_train if args.workload == 'train' else run_allimg)(args, rank, local, world, dev)
         sharding.barrier()
@@ -565,7 +649,7 @@ def main():
     gf = flops_per_view(S, localization)
     line = {
         'metric': f'novel views/sec (encode->AR transformer->decode), 128px {S - 1}-ctx',
-        'value': round(value, 3), 'unit': 'novel views/s', 'n_gpus': world, 'steps': args.steps,
+        'value': round(value, 3), 'unit': 'novel views/s', 'n_gpus': world, 'shared_device': args.dist['shared_device'], 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32' if args.precision == 'f32' else 'bf16'), 'data': 'synthetic',
         'config': {'workload': ('SM7 codebook+transformer, 6 context views -> 1 novel view, 128x128 '

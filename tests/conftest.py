@@ -27,6 +27,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(600, method='thread'))
 
 
+def parity_report(**kw):
+    """one line of gpurun_out/parity_report.jsonl (the per-round copy lives under profiles/) and on stdout"""
+    import json
+    try:
+        os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(REPO, 'gpurun_out', 'parity_report.jsonl'), 'a') as f:
+            f.write(json.dumps(kw, default=str) + '\n')
+    except OSError:
+        pass
+    print(json.dumps(kw, default=str))
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 

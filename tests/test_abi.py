@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_queries(lib):
-    assert lib.vf_abi_version() == 18
+    assert lib.vf_abi_version() == 19
     # the struct mirrors of the binding have the library's layout (checked again at load time: a mismatch raises)
     import ctypes
     from viewformer_amd import _lib as L
@@ -79,7 +79,7 @@ def test_library_reads_no_environment_and_its_switches_are_explicit(lib):
     csrc = os.path.join(REPO, 'viewformer_amd', 'csrc')
     for f in os.listdir(csrc):
         assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
-    n = 5
+    n = 6                                                                    # VF_SEL_COUNT (round 6: + VF_SEL_GEMM_TAIL, bit-identical pair)
     for which in range(n):
         assert lib.vf_selected(which) == 1                                   # defaults: the faster kernel of each pair
         assert lib.vf_select(which, 0) == 1 and lib.vf_selected(which) == 0

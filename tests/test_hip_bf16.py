@@ -452,6 +452,67 @@ def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N):
     assert _rel(plain, ref64) < 2e-6
 
 
+@pytest.mark.parametrize('M,K,N,tail', [(19200, 768, 3072, (64, 15, 3)), (19200, 768, 2304, (56, 26, 3)), (57344, 3072, 768, (170, 72, 3)),
+                                        (19200 - 70, 128, 3072, (64, 15, 3)), (16384 + 4000, 64, 2048, (64, 32, 2)), (19200, 768, 768, None),
+                                        (65536, 64, 3072, None)])
+def test_gemm_bf16_tail_tiles_are_bit_identical_to_the_plain_grid(dev, M, K, N, tail):
+    """round 6: launches whose last round of the 256 CUs would be partly filled end with one round of 192- / 128-row TAIL tiles instead
+    (csrc/gemm_bf16_g256.hip: g256_tail_policy; vf_select(VF_SEL_GEMM_TAIL)).  K is never split, so every output element keeps its k order:
+    the two grids must agree bit for bit — every epilogue form of the kernel, ragged ends inside a tail tile, no row written twice or left out
+    (NaN-filled outputs), and the training / inference shapes the policy exists for really take it (`tail` = the expected (full row tiles,
+    tail row tiles, 32-row blocks per wave group) per column; None = the plain grid)."""
+    from viewformer_amd import _lib, ops
+    mt, nb = -(-M // 256), N // 256
+    ntiles = mt * nb
+    # the policy, restated (csrc/gemm_bf16_g256.hip): the test pins which shapes take it
+    exp = None
+    last = ntiles % 256
+    if ntiles > 256 and 16 <= last <= 184:
+        f = (ntiles // 256) * 256 // nb
+        rem = -(-(M - f * 256) // 32)
+        for ic in (2, 3):
+            h = -(-rem // (2 * ic))
+            if h * nb <= 256:
+                exp = (f, h, ic)
+                break
+    assert exp == tail, (exp, tail)
+    x = _rand((M, K), 171).to(dev).to(torch.bfloat16)
+    w, b = _rand((K, N), 172, 0.05).to(dev), _rand((N,), 173).to(dev)
+    r, u16 = _rand((M, N), 174).to(dev), _rand((M, N), 175).to(dev).to(torch.bfloat16)
+    wp = ops.pack_dense_kn_bf16(w)
+
+    def run(form):
+        o16 = form in ('bf16', 'gelu16', 'dual16', 'gbwd')
+        out = torch.full((M, N), float('nan'), dtype=torch.bfloat16 if o16 else torch.float32, device=dev)
+        aux = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=dev) if form in ('dual16', 'dual32') else None
+        if form == 'f32res':
+            ops.igemm(x, wp, M, K, N, out, bias=b, res=r, bf16=True, a16=True)
+        elif form == 'drop':
+            ops.igemm(x, wp, M, K, N, out, bias=b, res=r, bf16=True, a16=True, drop=(0.1, 11, 2, 8))
+        elif form == 'bf16':
+            ops.igemm(x, wp, M, K, N, out, bias=b, bf16=True, a16=True, o16=True)
+        elif form == 'gelu16':
+            ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=ops.EPI_GELU, bf16=True, a16=True, o16=True)
+        elif form in ('dual16', 'dual32'):
+            ops.igemm(x, wp, M, K, N, out, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=o16, out_aux=aux)
+        elif form == 'gbwd':
+            ops.igemm(x, wp, M, K, N, out, res=u16, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True)
+        return out, aux
+    for form in ('f32res', 'drop', 'bf16', 'gelu16', 'dual16', 'dual32', 'gbwd'):
+        new, new_aux = run(form)
+        prev = _lib.select(_lib.SEL_GEMM_TAIL, 0)
+        try:
+            old, old_aux = run(form)
+        finally:
+            _lib.select(_lib.SEL_GEMM_TAIL, prev)
+        assert not torch.isnan(new.float()).any() and not torch.isnan(old.float()).any(), form
+        assert torch.equal(new, old), (form, (new.float() - old.float()).abs().max().item())
+        if new_aux is not None:
+            assert not torch.isnan(new_aux.float()).any() and torch.equal(new_aux, old_aux), form
+    ref64 = x[-300:].double().cpu() @ _bf(w.cpu()) + b.double().cpu()                 # the last rows (tail tiles, ragged end) against fp64
+    assert _rel(run('bf16')[0][-300:].float().cpu(), ref64) < 1e-2
+
+
 @pytest.mark.parametrize('M,K,N', [(8192, 768, 1024), (1000, 768, 1024), (77, 128, 256)])
 def test_fused_lmhead_argmax_equals_argmax_of_the_gemm_logits(dev, M, K, N):
     """vf_lmhead_argmax_bf16 (arg-max in the LM head's epilogue, logits never written) == vf_argmax_rows_f32(vf_gemm_bf16 logits), bit

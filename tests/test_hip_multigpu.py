@@ -164,3 +164,34 @@ def test_rccl_communicator_of_one_rank_runs_the_products_collectives():
     r = subprocess.run([sys.executable, '-c', RCCL_ONE, REPO, str(_port())], cwd=REPO, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0 and 'rccl-one ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def _preflight_line(text):
+    lines = [l for l in text.splitlines() if l.startswith('{') and '"preflight"' in l]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900, method='thread')
+def test_preflight_world1_rccl_and_world2_gloo():
+    """``bench.py --gpus N --preflight`` — device binding, communicator, 28 MB all-reduces timed, per-rank HBM headroom for one
+    encoder chunk — so that the first run on a multi-GPU node is not also the first debug session.  On a 1-GPU box: world 1 over RCCL (the
+    communicator is created although one rank needs none) and world 2 over gloo (ranks share cuda:0); and the bare ``--gpus 2`` run prints
+    the same line on stderr BEFORE its timed run."""
+    r = _bare(['--preflight'], n=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    pf = _preflight_line(r.stdout)
+    assert pf['preflight'] == 'ok' and pf['ranks'] == 1 and pf['backend'] == 'nccl' and pf['allreduce']['sum_exact']
+    assert pf['allreduce']['bytes'] == (12 * 768 * 768 + 13 * 768) * 4 and pf['allreduce']['iters'] == 100 and pf['allreduce']['ms_max_over_ranks'] > 0
+    assert pf['encoder_chunk']['images'] == 896 and pf['per_rank'][0]['hbm_headroom_gb_after_encoder_chunk'] > 0
+    r = _bare(['--preflight'], n=2, backend='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    pf = _preflight_line(r.stdout)
+    assert pf['preflight'] == 'ok' and pf['ranks'] == 2 and pf['backend'] == 'gloo' and pf['allreduce']['sum_exact']
+    assert pf['allreduce']['busbw_gbs'] > 0 and len(pf['per_rank']) == 2 and {p['rank'] for p in pf['per_rank']} == {0, 1}
+    assert pf['shared_device'] == (torch.cuda.device_count() < 2)
+    r = _bare(['--steps', '1', '--warmup', '0', '--batch', '4', '--no-cpu-baseline', '--no-f32-arm'], n=2, backend='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert _preflight_line(r.stderr)['ranks'] == 2                       # before the timed run, on stderr: stdout stays ONE JSON line
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['shared_device'] == (torch.cuda.device_count() < 2)

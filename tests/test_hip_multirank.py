@@ -93,6 +93,7 @@ def _migt_worker(rank, world, port, q):
 def _vq_worker(rank, world, port, q):
     try:
         dev, dist = _init(rank, world, port)
+        sharing = torch.cuda.device_count() < world          # ranks time-sliced on one GPU: the triple-launch detector rides along
         from viewformer_amd.config import VQGANConfig
         from viewformer_amd.vq_train import QuantizeEMATrainer
         from viewformer_amd.vqgan import VQGAN
@@ -109,6 +110,7 @@ def _vq_worker(rank, world, port, q):
         model = VQGAN(cfg, device=dev)
         model.load_state_dict(sd)
         tr = VQGANTrainer(model)
+        tr.debug_triple_groupnorm_bwd = sharing
         state0 = {k: v.clone() for k, v in tr.quantizer_state().items()} if hasattr(tr, 'quantizer_state') else None
         tr.train_step(images(50 + rank), reduce_gradients=False, apply_update=False)
         g_local = tr.flat_g.clone()
@@ -117,6 +119,7 @@ def _vq_worker(rank, world, port, q):
         model2 = VQGAN(cfg, device=dev)
         model2.load_state_dict(sd)
         tr2 = VQGANTrainer(model2)
+        tr2.debug_triple_groupnorm_bwd = sharing
         tr2.train_step(images(50 + rank), reduce_gradients=True, apply_update=False)
         e_mean = _rel(tr2.flat_g, sum(locs) / world)
         for s in range(2):
@@ -140,7 +143,8 @@ def _vq_worker(rank, world, port, q):
         for s in range(2):
             ref(torch.cat([zbatch(300 + 10 * s + r) for r in range(world)], 0))
         e_ema = _rel(qt.embeddings, ref.embeddings)
-        q.put((rank, 'ok', dict(e_mean=e_mean, in_sync=in_sync, q_sync=q_sync, e_ema=e_ema, backend=dist.get_backend())))
+        q.put((rank, 'ok', dict(e_mean=e_mean, in_sync=in_sync, q_sync=q_sync, e_ema=e_ema, backend=dist.get_backend(),
+                                transient_events=tr.transient_events + tr2.transient_events)))
         del state0
         dist.destroy_process_group()
     except Exception as e:      # noqa: BLE001
@@ -167,29 +171,43 @@ def _run(worker, world=2):
     return res
 
 
-def _run_retry_when_sharing(worker, ok):
-    """Two ranks on ONE GPU is a test-only configuration (the product runs one rank per GPU), and it has shown transient, non-reproducible
-    mismatches twice: round 3 traced one to interleaved ds_bpermute wave sums that are not bit-reproducible while a second process shares the GPU
-    (now DPP adds), round 5 saw the codebook trainers' reduced gradient 1.8e-3 off once in ~70 runs (tools/flaky_vq_dist_probe.py: 0 of 120 repeats,
-    6 of 6 reruns of the test clean).  When the ranks share a device and the first run misses its bound, the run is repeated ONCE and must then
-    pass; the event is printed and written to the parity report.  With one GPU per rank (RCCL) nothing is retried."""
-    res = _run(worker)
-    if ok(res) or torch.cuda.device_count() >= 2:
-        return res
-    msg = dict(test=worker.__name__, note='first run missed its bound while two ranks shared cuda:0; repeated once', first=res)
-    print('RETRY', msg)
+def _report(msg):
+    print('TRANSIENT', msg)
     try:
         import json
         from conftest import REPO
+        os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(REPO, 'gpurun_out', 'parity_report.jsonl'), 'a') as f:
             f.write(json.dumps(msg, default=str) + '\n')
     except OSError:
         pass
+
+
+def _run_proving_the_known_transient(worker, ok):
+    """No blind retry.  Two ranks on ONE GPU is a test-only configuration in which this code base has shown
+    exactly one transient: with several processes time-sliced on the device, one of three identical GroupNorm-backward launches returns lanes
+    48-63 of one accumulator wrong (profiles/r5_gpu_sharing_transient.txt, r6_gpu_sharing_transient.txt).  The codebook-trainer workers
+    therefore run with ``VQGANTrainer.debug_triple_groupnorm_bwd`` on whenever the ranks share a device: every GroupNorm backward is issued
+    three times and compared on the spot, launch #0's result is used as the product would use it, and events travel back with the result.
+    A missed bound is FATAL unless that very run recorded an event whose outlier was launch #0 (the one the step consumed) — i.e. unless the
+    run itself proved that the known transient, and nothing else, hit it.  Only then is the run repeated, once, and must pass.  With one GPU
+    per rank (RCCL) the detector is off and nothing is ever repeated."""
+    res = _run(worker)
+    if ok(res):
+        evs = [e for m in res.values() for e in m.get('transient_events', [])]
+        if evs:
+            _report(dict(test=worker.__name__, note='bounds met; GroupNorm-backward repeats disagreed in launches the step did not consume', events=evs))
+        return res
+    consumed = [e for m in res.values() for e in m.get('transient_events', []) if e.get('outlier_launch') == 0]
+    assert torch.cuda.device_count() < 2 and consumed, \
+        f'bound missed and the run recorded no consumed triple-launch outlier: not the known GPU-sharing transient -> a real failure: {res}'
+    _report(dict(test=worker.__name__, note='bound missed; the same run caught the known transient in a launch the step consumed; repeated once',
+                 first=res))
     return _run(worker)
 
 
 def test_migt_trainer_world2_sum_allreduce():
-    res = _run_retry_when_sharing(_migt_worker, lambda r: all(m['e_sum'] < 1e-6 and m['e_cat'] < 1e-4 for m in r.values()))
+    res = _run(_migt_worker)                     # never repeated: no known transient touches the transformer trainer
     print(res)
     for r, m in res.items():
         assert m['e_sum'] < 1e-6, m             # overlapped per-layer all-reduce == sum of the ranks' gradients
@@ -198,7 +216,7 @@ def test_migt_trainer_world2_sum_allreduce():
 
 
 def test_codebook_trainers_world2_mean_and_ema_allreduce():
-    res = _run_retry_when_sharing(_vq_worker, lambda r: all(m['e_mean'] < 1e-6 and m['e_ema'] < 1e-5 for m in r.values()))
+    res = _run_proving_the_known_transient(_vq_worker, lambda r: all(m['e_mean'] < 1e-6 and m['e_ema'] < 1e-5 for m in r.values()))
     print(res)
     for r, m in res.items():
         assert m['e_mean'] < 1e-6, m            # DDP mean of the replicas' gradients

@@ -33,10 +33,11 @@ class VfIgemmArgs(ctypes.Structure):
 # tolerance-level pairs SEL_CONV_X3H_K32 and SEL_ATTN_DMA (the DMA attention kernel re-rounds a pre-scaled q: within 1e-2 of the other)
 SEL_ATTN_DMA, SEL_GEMM_G256, SEL_LN_BWD_TWO_ROWS, SEL_ATTN_Q32 = 0, 1, 2, 3
 SEL_CONV_X3H_K32 = 4          # (the one pair that differs in the last bits: 16x16x32 vs 32x32x16 MFMAs in the x3h convolution)
+SEL_GEMM_TAIL = 5             # 256-tile bf16 GEMM: tail tiles in the last round (bit-identical)
 # developer convenience: these environment variables are translated into vf_select calls ONCE, when the library is loaded (the library
 # itself reads no environment variable)
 _ENV_SELECT = {'VF_ATTN_DMA': SEL_ATTN_DMA, 'VF_GEMM_G256': SEL_GEMM_G256, 'VF_LN_BWD_TWO_ROWS': SEL_LN_BWD_TWO_ROWS, 'VF_ATTN_Q32': SEL_ATTN_Q32,
-               'VF_CONV_X3H_K32': SEL_CONV_X3H_K32}
+               'VF_CONV_X3H_K32': SEL_CONV_X3H_K32, 'VF_GEMM_TAIL': SEL_GEMM_TAIL}
 
 PACK_DESC_BYTES = 40          # vf_pack_desc (ops.pack_bf16_multi builds the table as a numpy record array of this item size)
 P = c_void_p
@@ -175,6 +176,38 @@ class VfError(RuntimeError):
     pass
 
 
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_variant(path):
+    """a SECOND handle on a side-by-side build of the same ABI (viewformer_amd.build.build_variant): tests and in-process A/B tools only"""
+    return _bind(os.path.abspath(path))
+
+
+class use:
+    """``with _lib.use(handle): ...`` — route every op of this module's callers through another build of the library for the block (tests / A/B)"""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.prev, _lib = _lib, self.handle
+        return self.handle
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
 def load():
     """Load libvf_hip.so (building nothing: see viewformer_amd.build).  Raises if missing."""
     global _lib
@@ -183,11 +216,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VfError(f'{LIB_PATH} not found — run `python -m viewformer_amd.build` (hipcc --offload-arch=gfx950). '
                       'There is no CPU/PyTorch fallback for the hot path.')
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in EXPORTS.items():
-        fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
-        fn.restype = res
-        fn.argtypes = args
+    lib = _bind(LIB_PATH)
     # the two structs that cross the boundary by pointer: this module's mirrors must have the library's layout
     if int(lib.vf_sizeof_igemm_args()) != ctypes.sizeof(VfIgemmArgs):
         raise VfError(f'vf_igemm_args is {int(lib.vf_sizeof_igemm_args())} bytes in {LIB_PATH} and {ctypes.sizeof(VfIgemmArgs)} in '

@@ -61,5 +61,42 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# side-by-side builds of the same ABI that tests load next to the product library (never the product): name -> (extra flags, source stems)
+VARIANTS = {
+    # the transposing LDS reads of the DMA-ring kernels through the compiler intrinsic again instead of inline asm (vf_common.h: vf_tr_frag2_wait):
+    # hipcc then orders them behind the ring with its own `s_waitcnt vmcnt(0)` — the slow but compiler-ordered reference of
+    # tests/test_hip_ring_stress.py, which compares the two builds' results bit for bit
+    'trintrin': (['-DVF_X_TRINTRIN'], ['attention_dma', 'attention_train_bf16', 'gemm_tn_bf16']),
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(HERE, 'variants', f'libvf_{name}.so')
+
+
+def build_variant(name: str, force: bool = False) -> str:
+    """libvf_<name>.so under viewformer_amd/variants/: the product objects, with the variant's sources recompiled under its flags"""
+    flags, stems = VARIANTS[name]
+    build()
+    out = variant_path(name)
+    srcs = [os.path.join(CSRC, st + '.hip') for st in stems]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in srcs + hdrs + [LIB]):
+        return out
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    procs, vobjs = [], []
+    for st, src in zip(stems, srcs):
+        obj = os.path.join(HERE, 'variants', f'{st}.{name}.o')
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-w', '-c', src, '-o', obj] + EXTRA_FLAGS.get(st, []) + flags
+        procs.append(subprocess.Popen(cmd))
+        vobjs.append(obj)
+    if any(p.wait() != 0 for p in procs):
+        raise RuntimeError(f'hipcc failed on variant {name}')
+    objs = [os.path.join(HERE, 'build', os.path.basename(s)[:-4] + '.o') for s in sources() if os.path.basename(s)[:-4] not in stems]
+    subprocess.check_call([hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', out] + objs + vobjs)
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

@@ -339,9 +339,16 @@ def optimizer_state_to_keras(osd: Dict[str, np.ndarray]) -> "OrderedDict[str, np
 
 
 def save_training_checkpoint(trainer, job_dir: str, name: str = 'weights.model.000-last') -> str:
-    """what the reference's ``ModelCheckpoint`` callback leaves in ``job_dir`` (train/utils.py:46-86): ``config.json`` (the model's config,
-    :63-69) and ``model.save_weights(job_dir + '/weights.model.<epoch>-last')`` of the COMPILED model — weights and optimizer (Adam moments,
-    iteration count) in one TF-format checkpoint.  Returns the checkpoint prefix ``load_model`` / ``finetune_transformer`` take."""
+    """The layout the reference's ``ModelCheckpoint`` callback leaves in ``job_dir`` (train/utils.py:46-86) — ``config.json`` (the model's
+    config, :63-69) beside one TensorBundle ``weights.model.<epoch>-last`` holding weights and optimizer (Adam moments, iteration count) under
+    the object-graph key names — written for THIS project's reader (``load_model`` / ``restore_optimizer`` / ``finetune_transformer``), which
+    returns the prefix it takes.  It is NOT a checkpoint TensorFlow's ``load_weights`` would restore: the bundle carries no
+    ``_CHECKPOINTABLE_OBJECT_GRAPH`` proto (TF would fall back to name-based matching and skip the optimizer) and none of Keras Adam's
+    hyper variables (``beta_1``, ``beta_2``, ``decay``, ``learning_rate``); ``optimizer/learning_rate/offset`` is this project's own key for
+    the WarmUp schedule's offset — the reference's schedule is a plain Python object, not a Trackable, and finetune_transformer.py:79-86
+    overwrites the offset anyway.  The variable half follows the reference's names (``keras_to_state_dict`` reads TF-written bundles of the
+    published checkpoints' layout); the optimizer half is parity-unpinned — no TF-written compiled-model checkpoint exists offline
+    (tests/test_checkpoint.py checks it against this module's own reader only)."""
     os.makedirs(job_dir, exist_ok=True)
     with open(os.path.join(job_dir, 'config.json'), 'w') as f:
         json.dump({k: (v if isinstance(v, (int, float, str, bool, list, type(None))) else str(v))

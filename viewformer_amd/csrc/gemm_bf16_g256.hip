@@ -26,47 +26,28 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-#ifndef G256_A_VIA_REGS
-#define G256_A_VIA_REGS 0
-#endif
 #ifndef G256_PANEL
 #define G256_PANEL 4          // column tiles per panel (0: all column tiles of a row block together)
 #endif
-#ifndef G256_ROWGROUP
-#define G256_ROWGROUP 0       // row blocks per group (0: column panels over all row blocks, the round-2 order); see the kernel
-#endif
+// (Measured and removed, in the history with their numbers: the A tile through VGPRs (round 2), a persistent one-workgroup-per-CU form that
+// issues the next tile's first stage before its epilogue — a wash, round 3 —, row groups inside an XCD — more FETCH, 4-5 % slower, round 5,
+// profiles/r5_gemm_g256_tile_order.txt —, a 16x16x32-MFMA feasibility probe.)
 constexpr int GM = 256, GN = 256, GK = 64;
 constexpr int GA_BYTES = GM * GK * 2;        // 32768
 constexpr int GB_BYTES = GN * GK * 2;        // 32768 = two 128-column packed blocks
 constexpr int GSTAGE = GA_BYTES + GB_BYTES;  // 65536
 
-#ifndef G256_AUX_A
-#define G256_AUX_A 0        // cache-policy bits of the A pieces' DMA (2 = nt)
-#endif
-#ifndef G256_AUX_W
-#define G256_AUX_W 0
-#endif
-#ifndef G256_PERSIST
-#define G256_PERSIST 0       // workgroups of the persistent form (256 = one per CU).  A/B at M = 65 536: c_attn 241 vs 247 us, c_fc 391 vs 381,
-                             // mlp.c_proj 312 vs 308 — a wash: the hidden first-stage flight is paid back by the lost overlap of tile tails -> off
-#endif
-#ifndef G256_BUFFER
-#define G256_BUFFER 1       // buffer_load_dwordx4 ... lds (SGPR resource + 32-bit lane offsets) instead of global_load_lds_dwordx4 (64-bit lane
-                            // addresses): the address path is part of what a piece costs — mlp.c_proj 325 -> 304 us, c_attn 261 -> 244 us
-#endif
+// LDS-DMA through an SGPR buffer resource + 32-bit lane offsets (buffer_load_dwordx4 ... lds) instead of global_load_lds_dwordx4's 64-bit lane
+// addresses: the address path is part of what a piece costs — mlp.c_proj 325 -> 304 us, c_attn 261 -> 244 us (round 2)
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
-}
-template <int AUX = 0>
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
 // fp32 output: bias, optional GELU, optional residual.  One code path with wave-uniform flags (eight template instantiations of the
 // unrolled 8-tile store made the compiler hoist every tile's addresses and spill 350 registers around the 128 accumulators); a tile is
 // still handled as ONE block of 16 back-to-back loads / stores (epilogue.h).
-template <bool DROP>
-__device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
+template <bool DROP, int IC>
+__device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32x16 (&acc)[IC][2], int m_tile0, int n_tile0, int wrow0,
                                                int wave_n, int half, int l31, bool full, bool gelu) {
     const long long ldc = p.ldc, ldr = p.ldr;
     const bool has_res = p.res != nullptr;
@@ -79,8 +60,8 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
         const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+        for (int i = 0; i < IC; ++i) {
+            int m0 = m_tile0 + wrow0 + i * 32 + 4 * half;
             // (DROP instantiation: the tile's row index passes through an opaque asm, so the eight tiles' addresses and mask words are
             // formed tile by tile — hoisted together beside the 128 accumulators they cost 43 spilled registers)
             if constexpr (DROP) asm volatile("" : "+v"(m0) :: "memory");
@@ -151,8 +132,8 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
 // rows and every lane stores two adjacent columns of one row (4 bytes) — same scheme as gemm_bf16_direct_kernel
 // EPI: 0 = bias, 1 = bias + GELU (forward), 2 = VF_EPI_GELU_BWD: (acc + bias) * gelu'(u), u = p.res[m][n] the saved fp32 pre-activation —
 // gemm_bf16_direct_kernel's expression (vf_gelu_grad_fast, explicitly rounded): the same bits as that kernel and as the stand-alone pass
-template <int EPI, bool FULL>
-__device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f32x16 (&acc)[4][2], int m_tile0, int n_tile0, int wave_m,
+template <int EPI, bool FULL, int IC>
+__device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f32x16 (&acc)[IC][2], int m_tile0, int n_tile0, int wrow0,
                                                 int wave_n, int half, int l31) {
     __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.out);
     const int odd = l31 & 1;
@@ -161,8 +142,8 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
         const int n = n_tile0 + wave_n * 64 + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m0 = m_tile0 + wave_m * 128 + i * 32 + 4 * half;
+        for (int i = 0; i < IC; ++i) {
+            const int m0 = m_tile0 + wrow0 + i * 32 + 4 * half;
             float t[16];
             if (EPI == 2) {
                 // u through an SGPR buffer resource based at the tile's first row (32-bit lane offsets, no 64-bit lane addresses) that ends
@@ -242,103 +223,50 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
     }
 }
 
-template <bool O16, bool DROP = false>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
-
-    const int tid = threadIdx.x;
+// One output tile: R = 2 IC row blocks of 32 rows (IC = 4: the 256 x 256 tile; IC = 3 / 2: the 192- / 128-row TAIL tiles below) x 256
+// columns.  The two wave_m groups take IC blocks each, so every SIMD keeps its two waves whatever the height; the k order of every output
+// element is the full tile's (K is never split): a tail tile's results are bit-identical to the full tile's.
+template <bool O16, bool DROP, int IC>
+__device__ __forceinline__ void g256_tile(const vf_igemm_args& p, unsigned char* smem_b, int m_tile0, int nblk, int tid) {
+    constexpr int TROWS = 2 * IC * 32;                     // rows of this tile
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
     const int half = lane >> 5, l31 = lane & 31;
-
-    const int nb = p.Cout / GN;
-    const int mt = (p.M + GM - 1) / GM;
-    // XCD-contiguous logical workgroup id (vf_common.h), walked in column PANELS of sn tiles: the ~32 workgroups an XCD runs at a time
-    // are then ~8 row blocks x sn column tiles, whose weight panel (sn x 393 KB at K = 768) stays in the XCD's 4 MB L2 for the whole
-    // pass over the rows — with all nb column tiles in flight (12 for c_fc: 4.7 MB of weights) the weights thrash it (L2 hit rate 69 %)
-    const unsigned lbid = vf_xcd_bid();
-    constexpr int PANEL = G256_PANEL;
-    const int sn = PANEL <= 0 || nb <= PANEL ? nb : nb % PANEL == 0 ? PANEL : (PANEL >= 3 && nb % 3 == 0) ? 3 : (PANEL >= 2 && nb % 2 == 0) ? 2 : 1;
-#if G256_ROWGROUP > 0
-    // ROW GROUPS (round 5): with column panels walked over ALL row blocks (below), a 256-row A panel is fetched once per
-    // column panel — 3 x for c_fc / c_attn — and the panels of one row block run on different XCDs at different times: FETCH_SIZE 434 MB per
-    // c_fc launch for 105 MB of operands (profiles/r4_bench_mixed_pmc_traffic.txt).  Here the ids are walked in groups of G256_ROWGROUP row
-    // blocks; inside a group, column panel after column panel: the ~32 workgroups an XCD runs (one per CU) are RG row blocks x sn column
-    // tiles, and the group's next panel follows on the SAME XCD right behind — the group's A rows (RG x 393 KB at K = 768) are still in its L2
-    constexpr int RG = G256_ROWGROUP;
-    const int per_group = RG * nb;
-    const int group = (int)(lbid / (unsigned)per_group);
-    const int in_group = (int)(lbid - (unsigned)group * per_group);
-    const int rows_g = min(RG, mt - group * RG);                     // (the last group may be short)
-    const int per_panel = rows_g * sn;
-    const int panel = in_group / per_panel;
-    const int in_panel = in_group - panel * per_panel;
-    const int nblk = panel * sn + in_panel % sn;
-    const int mtile = group * RG + in_panel / sn;
-#else
-    const int per_panel = mt * sn;
-    const int panel = (int)(lbid / (unsigned)per_panel);
-    const int in_panel = (int)(lbid - (unsigned)panel * per_panel);
-    const int nblk = panel * sn + in_panel % sn;
-    const int mtile = in_panel / sn;
-#endif
-    const int m_tile0 = mtile * GM, n_tile0 = nblk * GN;
+    const int wrow0 = wave_m * (IC * 32);                  // this wave's first row inside the tile
+    const int n_tile0 = nblk * GN;
     const int nstages = p.Cin / GK;
 
-    // ---- LDS-DMA sources.  A: wave w moves rows [32 w, 32 w + 32) of the tile, 8 rows (1 KB) per instruction; lane -> row (lane >> 3),
-    // LDS chunk c' = lane & 7, global chunk c = c' ^ ((row >> 1) & 7).  W: the 32 KB of the stage are contiguous, wave w moves 4 KB.
-    const unsigned char* asrc[4];
+    // ---- LDS-DMA sources.  A: wave w moves rows [32 w, 32 w + 32) of the tile (waves past the tile's height move none), 8 rows (1 KB) per
+    // instruction; lane -> row (lane >> 3), LDS chunk c' = lane & 7, global chunk c = c' ^ ((row >> 1) & 7).  W: the 32 KB of the stage are
+    // contiguous, wave w moves 4 KB.
+    const bool a_mover = wave * 32 < TROWS;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_packed), 0, 0x7fffffff, 0x00020000);
+    unsigned avoff[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = wave * 32 + q * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int m = m_tile0 + r;
         m = m < p.M ? m : p.M - 1;
-        asrc[q] = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)m * p.lda) * 2 + c * 16;
+        avoff[q] = (unsigned)(((size_t)m * p.lda) * 2 + c * 16);
     }
-#if G256_BUFFER
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_packed), 0, 0x7fffffff, 0x00020000);
-    unsigned avoff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) avoff[q] = (unsigned)(asrc[q] - reinterpret_cast<const unsigned char*>(p.x));
     const unsigned wvoff = (unsigned)((size_t)nblk * GB_BYTES + wave * 4096 + lane * 16);
-#endif
     const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
-    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)nblk * GB_BYTES + wave * 4096 + lane * 16;
-#if G256_A_VIA_REGS      // experiment: the A tile through VGPRs (global_load_dwordx4 + ds_write_b128 into the same swizzled image), W by DMA
-    f32x4 areg[4];
-    auto a_fetch = [&](int s) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) areg[q] = *reinterpret_cast<const f32x4*>(asrc[q] + (size_t)s * (GK * 2));
-    };
-    auto a_park = [&](int s) {
-        unsigned char* dst = smem_b + (s & 1) * GSTAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + (wave * 32 + q * 8) * 128 + lane * 16) = areg[q];
-    };
-#endif
     auto issue = [&](int s) {
         unsigned char* dst = smem_b + (s & 1) * GSTAGE;
-#if G256_BUFFER
+        if (IC == 4 || a_mover) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bufds16(a_rsrc, dst + (wave * 32 + q * 8) * 128, avoff[q], (unsigned)(s * (GK * 2)));
+            for (int q = 0; q < 4; ++q) bufds16(a_rsrc, dst + (wave * 32 + q * 8) * 128, avoff[q], (unsigned)(s * (GK * 2)));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) bufds16(w_rsrc, dst + GA_BYTES + wave * 4096 + q * 1024, wvoff + q * 1024, (unsigned)((size_t)s * w_stage_stride));
-#else
-#if !G256_A_VIA_REGS
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16<G256_AUX_A>(asrc[q] + (size_t)s * (GK * 2), dst + (wave * 32 + q * 8) * 128);
-#endif
-        const unsigned char* ws = wsrc + (size_t)s * w_stage_stride;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16<G256_AUX_W>(ws + q * 1024, dst + GA_BYTES + wave * 4096 + q * 1024);
-#endif
     };
 
-    // ---- fragment addresses: A row = wave_m * 128 + i * 32 + l31, chunk (ks * 2 + half) ^ ((l31 >> 1) & 7)
-    const unsigned a_row_off = (unsigned)((wave_m * 128 + l31) * 128);
+    // ---- fragment addresses: A row = wrow0 + i * 32 + l31, chunk (ks * 2 + half) ^ ((l31 >> 1) & 7)   (wrow0 is a multiple of 32: the
+    // swizzle bits of the row are l31's)
+    const unsigned a_row_off = (unsigned)((wrow0 + l31) * 128);
     const unsigned a_swz = (unsigned)((l31 >> 1) & 7);
     unsigned a_off[4];
 #pragma unroll
@@ -346,9 +274,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     // W image: [block (2)][ks][half][n (128)][16 B]; this wave's columns: block wave_n >> 1, n = (wave_n & 1) * 64 + j * 32 + l31
     const unsigned b_off = (unsigned)(GA_BYTES + (wave_n >> 1) * (GK * 128 * 2) + ((half * 128) + (wave_n & 1) * 64 + l31) * 16);
 
-    f32x16 acc[4][2];
+    f32x16 acc[IC][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IC; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -365,10 +293,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
     // (A first-round stagger — four groups of CUs 4 000-16 000 cycles apart, so that the 256 epilogues of a round do not reach the memory system
     // together — was measured in round 3 and removed: 388 -> 397-400 us for c_fc at M = 65 536, the tail it adds outweighs what it spreads.)
     issue(0);
-#if G256_A_VIA_REGS
-    a_fetch(0);
-    a_park(0);
-#endif
     for (int s = 0; s < nstages; ++s) {
         // stage s has landed (this wave's pieces: vmcnt; everyone's: the barrier); every wave has finished reading stage s - 1
         // (lgkmcnt: the compiler may leave the last ds_reads in flight up to their MFMA), whose buffer the next DMA overwrites
@@ -383,18 +307,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         if (s > 0) acc_t[2] += (unsigned)(tt[3] - tt[2]);  // MFMA phase of the previous stage
 #endif
         if (s + 1 < nstages) issue(s + 1);
-#if G256_A_VIA_REGS
-        if (s + 1 < nstages) a_fetch(s + 1);
-#endif
         G256_STAMP(1);                                     // DMA issued
         const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
-        // fragments of k-step ks + 1 are read while the 8 MFMAs of k-step ks run (two register sets)
-        bf16x8 a[2][4], b[2][2];
-        auto frags = [&](int ks, bf16x8 (&af)[4], bf16x8 (&bf)[2]) {
+        // fragments of k-step ks + 1 are read while the 2 IC MFMAs of k-step ks run (two register sets)
+        bf16x8 a[2][IC], b[2][2];
+        auto frags = [&](int ks, bf16x8 (&af)[IC], bf16x8 (&bf)[2]) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (ks * 2 * 128 + j * 32) * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
+            for (int i = 0; i < IC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
         };
         frags(0, a[0], b[0]);
 #ifdef G256_STAMPS
@@ -407,32 +328,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);            // keep the reads ahead of the MFMAs (the scheduler sinks them to their use)
-#ifdef G256_X_K32PROBE      // feasibility probe (WRONG results): the same operand traffic, each 32x32x16 MFMA replaced by two 16x16x32 MFMAs (same flops) on
-            // quarter accumulators — what would the deeper-K shape buy this kernel under the package power limit?
-            typedef float f32x4p __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int qd = (ks & 1) * 2 + h2;
-                        f32x4p c4 = {acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
-                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks & 1][i], b[ks & 1][j], c4, 0, 0, 0);
-                        acc[i][j][qd * 4] = c4[0]; acc[i][j][qd * 4 + 1] = c4[1]; acc[i][j][qd * 4 + 2] = c4[2]; acc[i][j][qd * 4 + 3] = c4[3];
-                    }
-#else
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IC; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#if G256_A_VIA_REGS
-        if (s + 1 < nstages) a_park(s + 1);                // the idle buffer: last read in stage s - 1
-#endif
     }
 
 #ifdef G256_STAMPS
@@ -444,25 +346,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
         o[5] = (unsigned)(tt[3] - tt[5]);                  // kernel entry -> end of the main loop
     }
 #endif
-    const bool full = m_tile0 + GM <= p.M;
+    const bool full = m_tile0 + TROWS <= p.M;
     const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
     if (O16) {
         const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
         const bool dual16 = p.epilogue == VF_EPI_GELU_DUAL;
         if (dual16) {
-            if (full) g256_store_bf16<3, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else g256_store_bf16<3, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            if (full) g256_store_bf16<3, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else g256_store_bf16<3, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
         } else if (full) {
-            if (gbwd) g256_store_bf16<2, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else if (gelu) g256_store_bf16<1, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else g256_store_bf16<0, true>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            if (gbwd) g256_store_bf16<2, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else if (gelu) g256_store_bf16<1, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else g256_store_bf16<0, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
         } else {
-            if (gbwd) g256_store_bf16<2, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else if (gelu) g256_store_bf16<1, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
-            else g256_store_bf16<0, false>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31);
+            if (gbwd) g256_store_bf16<2, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else if (gelu) g256_store_bf16<1, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else g256_store_bf16<0, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
         }
     } else {
-        g256_store_f32<DROP>(p, acc, m_tile0, n_tile0, wave_m, wave_n, half, l31, full, gelu);
+        g256_store_f32<DROP, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31, full, gelu);
     }
 #ifdef G256_STAMPS
     {   // epilogue: [6] = bias / convert / store instructions issued, [7] = the stores drained (vmcnt 0)
@@ -479,136 +381,76 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p)
 #endif
 }
 
-#if G256_PERSIST
-// ---- persistent form: one workgroup per CU walks the tiles (tile = blockIdx.x + k * gridDim.x, same XCD / panel order) and issues the
-// NEXT tile's first stage before its epilogue: the DMA's flight (~3500 cycles, a whole stage-time for which a fresh workgroup sits idle)
-// passes under the bias / GELU / store work of the tile that just finished.  Buffer-resource DMA only; needs an even stage count (the
-// last stage then reads buffer 1 and buffer 0 is free for the prefetch).
-template <bool O16>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_g256p_kernel(vf_igemm_args p, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 2, wave_n = wave & 3;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int nb = p.Cout / GN;
-    const int mt = (p.M + GM - 1) / GM;
+// column panels of sn column tiles over mt row tiles (the round-2 order): logical id -> (row tile, column tile).  The ~32 workgroups an XCD
+// runs at a time are then ~8 row blocks x sn column tiles, whose weight panel (sn x 393 KB at K = 768) stays in the XCD's 4 MB L2 for the
+// whole pass over the rows — with all nb column tiles in flight (12 for c_fc: 4.7 MB of weights) the weights thrash it (L2 hit rate 69 %)
+__device__ __forceinline__ void g256_panel_order(unsigned lbid, int mt, int nb, int& mtile, int& nblk) {
     constexpr int PANEL = G256_PANEL;
     const int sn = PANEL <= 0 || nb <= PANEL ? nb : nb % PANEL == 0 ? PANEL : (PANEL >= 3 && nb % 3 == 0) ? 3 : (PANEL >= 2 && nb % 2 == 0) ? 2 : 1;
     const int per_panel = mt * sn;
-    const int nstages = p.Cin / GK;
-    const size_t w_stage_stride = (size_t)(p.Cout / 128) * (GK * 128 * 2);
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_packed), 0, 0x7fffffff, 0x00020000);
-
-    // tile id -> (row block, column tile): XCD-contiguous ids (vf_xcd_bid's map for an arbitrary id), then column panels
-    auto tile_of = [&](unsigned t, int& m_tile0, int& n_tile0) {
-        const unsigned n = (unsigned)ntiles, q = n >> 3, r = n & 7u, x = t & 7u, i = t >> 3;
-        const unsigned lbid = x * q + (x < r ? x : r) + i;
-        const int panel = (int)(lbid / (unsigned)per_panel);
-        const int in_panel = (int)(lbid - (unsigned)panel * per_panel);
-        n_tile0 = (panel * sn + in_panel % sn) * GN;
-        m_tile0 = (in_panel / sn) * GM;
-    };
-    unsigned avoff[4], wvoff = 0;
-    auto sources = [&](int m_tile0, int n_tile0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave * 32 + q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int m = m_tile0 + r;
-            m = m < p.M ? m : p.M - 1;
-            avoff[q] = (unsigned)(((size_t)m * p.lda) * 2 + c * 16);
-        }
-        wvoff = (unsigned)((size_t)(n_tile0 / GN) * GB_BYTES + wave * 4096 + lane * 16);
-    };
-    auto issue = [&](int s) {
-        unsigned char* dst = smem_b + (s & 1) * GSTAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bufds16(a_rsrc, dst + (wave * 32 + q * 8) * 128, avoff[q], (unsigned)(s * (GK * 2)));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bufds16(w_rsrc, dst + GA_BYTES + wave * 4096 + q * 1024, wvoff + q * 1024, (unsigned)((size_t)s * w_stage_stride));
-    };
-    const unsigned a_row_off = (unsigned)((wave_m * 128 + l31) * 128);
-    const unsigned a_swz = (unsigned)((l31 >> 1) & 7);
-    unsigned a_off[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a_off[ks] = a_row_off + ((((unsigned)(ks * 2 + half)) ^ a_swz) << 4);
-    const unsigned b_off = (unsigned)(GA_BYTES + (wave_n >> 1) * (GK * 128 * 2) + ((half * 128) + (wave_n & 1) * 64 + l31) * 16);
-
-    int m_tile0, n_tile0;
-    tile_of(blockIdx.x, m_tile0, n_tile0);
-    sources(m_tile0, n_tile0);
-    issue(0);
-    for (unsigned t = blockIdx.x; t < (unsigned)ntiles; t += gridDim.x) {
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int s = 0; s < nstages; ++s) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s + 1 < nstages) issue(s + 1);
-            const unsigned char* buf = smem_b + (s & 1) * GSTAGE;
-            bf16x8 a[2][4], b[2][2];
-            auto frags = [&](int ks, bf16x8 (&af)[4], bf16x8 (&bf)[2]) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (ks * 2 * 128 + j * 32) * 16);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks] + i * (32 * 128));
-            };
-            frags(0, a[0], b[0]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // the next tile's first stage goes out now (buffer 0: last read in stage nstages - 2, which every wave has left)
-        const int em = m_tile0, en = n_tile0;
-        const unsigned tn = t + gridDim.x;
-        if (tn < (unsigned)ntiles) {
-            tile_of(tn, m_tile0, n_tile0);
-            sources(m_tile0, n_tile0);
-            issue(0);
-        }
-        const bool full = em + GM <= p.M;
-        const bool gelu = p.epilogue == VF_EPI_GELU_ERF;
-        if (O16) {
-            const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
-            const bool dual16 = p.epilogue == VF_EPI_GELU_DUAL;
-            if (dual16) {
-                if (full) g256_store_bf16<3, true>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else g256_store_bf16<3, false>(p, acc, em, en, wave_m, wave_n, half, l31);
-            } else if (full) {
-                if (gbwd) g256_store_bf16<2, true>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else if (gelu) g256_store_bf16<1, true>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else g256_store_bf16<0, true>(p, acc, em, en, wave_m, wave_n, half, l31);
-            } else {
-                if (gbwd) g256_store_bf16<2, false>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else if (gelu) g256_store_bf16<1, false>(p, acc, em, en, wave_m, wave_n, half, l31);
-                else g256_store_bf16<0, false>(p, acc, em, en, wave_m, wave_n, half, l31);
-            }
-        } else {
-            g256_store_f32<false>(p, acc, em, en, wave_m, wave_n, half, l31, full, gelu);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int panel = (int)(lbid / (unsigned)per_panel);
+    const int in_panel = (int)(lbid - (unsigned)panel * per_panel);
+    nblk = panel * sn + in_panel % sn;
+    mtile = in_panel / sn;
 }
 
-#endif  // G256_PERSIST
+// TAIL tiles (round 6).  One workgroup per CU (128 KB of LDS): a launch of T tiles costs ceil(T / 256) tile times, and the
+// transformer's shapes sit just past a half round (training, M = 19 200: c_fc 900 tiles = 3.52 rounds, c_attn 675 = 2.64; inference,
+// M = 57 344: c_fc 2 688 = 10.5, c_proj 672 = 2.625).  With f_rows > 0 the launch is F = f_rows x nb FULL tiles — whole rounds of them —
+// followed by H = h_rows x nb tail tiles of 2 tail_ic x 32 rows that cover the remaining rows in ONE shorter round (a 192-row tile costs
+// ~3/4 of a full one: 3 of 4 row blocks per wave, 56 of 64 KB per stage).  Each XCD runs its full tiles first, then its tail tiles (ids are
+// XCD-contiguous within each kind: a kind's panel order and L2 reuse are those of a plain launch).  f_rows = 0: the plain grid.
+template <bool O16, bool DROP = false>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p, int f_rows, int h_rows, int tail_ic) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
+    const int tid = threadIdx.x;
+    const int nb = p.Cout / GN;
+    int mtile, nblk;
+    if (f_rows == 0) {
+        // XCD-contiguous logical workgroup id (vf_common.h), walked in column panels
+        g256_panel_order(vf_xcd_bid(), (p.M + GM - 1) / GM, nb, mtile, nblk);
+        g256_tile<O16, DROP, 4>(p, smem_b, mtile * GM, nblk, tid);
+        return;
+    }
+    const unsigned F = (unsigned)(f_rows * nb), tot = gridDim.x;
+    const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const unsigned nF = F / 8u + (x < (F & 7u) ? 1u : 0u);                          // this XCD's full tiles, then its tail tiles
+    const unsigned baseF = x * (F / 8u) + (x < (F & 7u) ? x : (F & 7u));
+    if (i < nF) {
+        g256_panel_order(baseF + i, f_rows, nb, mtile, nblk);
+        g256_tile<O16, DROP, 4>(p, smem_b, mtile * GM, nblk, tid);
+        return;
+    }
+    const unsigned baseT = x * (tot / 8u) + (x < (tot & 7u) ? x : (tot & 7u));
+    g256_panel_order(baseT - baseF + (i - nF), h_rows, nb, mtile, nblk);
+    const int m_tile0 = f_rows * GM + mtile * (tail_ic * 64);
+    if (tail_ic == 3) g256_tile<O16, DROP, 3>(p, smem_b, m_tile0, nblk, tid);
+    else g256_tile<O16, DROP, 2>(p, smem_b, m_tile0, nblk, tid);
+}
 
 }  // namespace
+
+// The tail policy of a launch (host; also what tests ask): full row tiles per column and tail tiles per column / their height.
+// Applied when the launch is more than one round of the 256 CUs, its last round is between a few tiles and 3/4 full, and the rows left over after
+// whole rounds of full tiles fit ONE round of 192-row (or 128-row) tail tiles.
+struct G256Tail { int f_rows, h_rows, ic; };
+static G256Tail g256_tail_policy(int M, int nb) {
+    const int mt = (M + GM - 1) / GM;
+    const long long ntiles = (long long)mt * nb;
+    constexpr int CUS = 256;
+    G256Tail none{0, 0, 0};
+    if (ntiles <= CUS || !vf_selected(VF_SEL_GEMM_TAIL)) return none;
+    const int last = (int)(ntiles % CUS);
+    if (last == 0 || last > (CUS * 3) / 4 - 8 || last < 16) return none;       // (nothing to gain past ~3/4 of a round; a handful of tiles: leave it)
+    const int f_rows = (int)((ntiles / CUS) * CUS / nb);                       // whole rounds of full tiles (F = f_rows x nb <= rounds x 256)
+    if (f_rows <= 0 || f_rows >= mt) return none;
+    const int rem_blocks = (M - f_rows * GM + 31) / 32;                        // 32-row blocks left per column
+    for (int ic = 2; ic <= 3; ++ic) {                                          // the shortest tail tile that fits one round
+        const int h_rows = (rem_blocks + 2 * ic - 1) / (2 * ic);
+        if ((long long)h_rows * nb <= CUS) return G256Tail{f_rows, h_rows, ic};
+    }
+    return none;
+}
 
 // Launcher used by vf_gemm_bf16 (gemm_bf16.hip).  Returns VF_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the
 // 128 x 128 kernel): bf16 A, Cout % 256 == 0, Cin % 64 == 0, no batch, at least one full row tile.
@@ -619,12 +461,12 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res)) return VF_ERR_UNSUPPORTED;
     if (a.epilogue == VF_EPI_GELU_DUAL && (a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (out fp32 or bf16)
     if ((a.reserved0 & 4) && a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;                             // (bit 2: a bf16 u for GELU_BWD)
-    if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;
+    if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;      // (no layer has both; the 128-tile kernel contracts gelu * + res)
     // fused output dropout (drop_rate > 0): the fp32-output path with no epilogue function; mask group indices are 32-bit here
     if (a.drop_rate != 0.f && (!(a.drop_rate > 0.f && a.drop_rate < 1.f) || o16 || a.epilogue != VF_EPI_NONE || a.drop_row0 < 0 || (a.drop_row0 & 3) ||
                                (((unsigned long long)a.M + (unsigned long long)a.drop_row0 + 3) / 4) * (unsigned long long)a.Cout >= (1ull << 32)))
         return VF_ERR_UNSUPPORTED;
-    if (G256_BUFFER && ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31))) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets     // (no layer has both; the 128-tile kernel contracts gelu * + res)
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
     if (vf_attr_needed(&attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
@@ -634,25 +476,10 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
         vf_attr_done(&attr_devs);
     }
     const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
-    const dim3 g((unsigned)(mt * nb));
-#if G256_PERSIST
-    // persistent form (developer build -DG256_PERSIST=256): that many workgroups (one per CU; a multiple of the 8 XCDs) walk the tiles
-    if (G256_BUFFER && (a.Cin / GK) % 2 == 0 && mt * nb > G256_PERSIST && a.drop_rate == 0.f) {
-        static unsigned long long attr_p_devs = 0;
-        if (vf_attr_needed(&attr_p_devs)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
-            if (e != hipSuccess) return (int)e;
-            vf_attr_done(&attr_p_devs);
-        }
-        const dim3 gp((unsigned)G256_PERSIST);
-        if (o16) hipLaunchKernelGGL((gemm_bf16_g256p_kernel<true>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);
-        else hipLaunchKernelGGL((gemm_bf16_g256p_kernel<false>), gp, dim3(512), (size_t)2 * GSTAGE, stream, a, mt * nb);
-        return vf_last_status();
-    }
-#endif
-    if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
-    else if (a.drop_rate > 0.f) hipLaunchKernelGGL((gemm_bf16_g256_kernel<false, true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
-    else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a);
+    const G256Tail t = g256_tail_policy(a.M, nb);
+    const dim3 g((unsigned)(t.f_rows ? (t.f_rows + t.h_rows) * nb : mt * nb));
+    if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
+    else if (a.drop_rate > 0.f) hipLaunchKernelGGL((gemm_bf16_g256_kernel<false, true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
+    else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
     return vf_last_status();
 }

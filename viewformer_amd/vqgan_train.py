@@ -62,6 +62,12 @@ class VQGANTrainer:
                                             ema_dw_hidden=torch.from_numpy(np.ascontiguousarray(host['quantize.ema_dw_hidden'])).to(self.dev),
                                             counter=int(np.asarray(host['quantize.counter']).reshape(-1)[0]))
         self._enc_plan, self._dec_plan = model._enc_plan, model._dec_plan
+        # debug switch (off in the product): issue every GroupNorm backward THREE times on the same live inputs and compare the results bit for
+        # bit on the spot.  The only transient this code base has shown — several PROCESSES time-sliced on one GPU, one of three identical
+        # launches returns lanes 48-63 of the sum(dt * xhat) accumulator wrong (profiles/r5_gpu_sharing_transient.txt) — is then caught where it
+        # happens; launch #0's result is what the step goes on with (as the product would), the event goes to `transient_events`
+        self.debug_triple_groupnorm_bwd = False
+        self.transient_events = []
         self.lpips = None
         if cfg.perceptual_weight > 0:
             from .lpips import LPIPS
@@ -215,9 +221,33 @@ class VQGANTrainer:
     def _gn_bw(self, ctx, da):
         name, x, mean_c, scale_c, n, HW, C, swish = ctx
         dx, dgamma, dbeta = T.groupnorm_bwd(x, da, mean_c, scale_c, self.p(name + '.weight'), self.p(name + '.bias'), n, HW, C, swish)
+        if self.debug_triple_groupnorm_bwd:
+            self._check_gn_bw_repeat(ctx, da, (dx, dgamma, dbeta))
         T.add_(self.g(name + '.weight'), dgamma)
         T.add_(self.g(name + '.bias'), dbeta)
         return dx
+
+    def _check_gn_bw_repeat(self, ctx, da, first):
+        name, x, mean_c, scale_c, n, HW, C, swish = ctx
+        outs = [tuple(t.clone() for t in first)]
+        for _ in range(2):
+            outs.append(T.groupnorm_bwd(x, da, mean_c, scale_c, self.p(name + '.weight'), self.p(name + '.bias'), n, HW, C, swish))
+        same = {(a, b): all(torch.equal(u, v) for u, v in zip(outs[a], outs[b])) for a, b in ((0, 1), (0, 2), (1, 2))}
+        if same[0, 1] and same[0, 2]:
+            return
+        odd = 0 if same[1, 2] else 1 if same[0, 2] else 2 if same[0, 1] else -1        # -1: all three differ
+        bad, good = outs[max(odd, 0)], outs[(max(odd, 0) + 1) % 3]
+        ev = dict(layer=name, step=self.step_count, outlier_launch=odd, C=C, HW=HW, n_img=n, swish=bool(swish), differing={})
+        for nm, a, b in zip(('dx', 'dgamma', 'dbeta'), bad, good):
+            if not torch.equal(a, b):
+                d = (a - b).abs()
+                if nm == 'dx':
+                    dd = d.view(n, HW, C)
+                    ev['differing'][nm] = dict(images=dd.amax((1, 2)).nonzero().flatten().tolist(),
+                                               channels=dd.amax((0, 1)).nonzero().flatten().tolist(), max_abs=float(d.max()))
+                else:
+                    ev['differing'][nm] = dict(channels=d.nonzero().flatten().tolist(), max_abs=float(d.max()))
+        self.transient_events.append(ev)
 
     # ------------------------------------------------------------------ blocks
     def _res_fw(self, name, x, n, H, W, cin, cout):
