@@ -42,11 +42,32 @@ HBM_PEAK_GBS = 8000.0
 F16_MFMA_POWER_LIMITED_TFLOPS = 1722.0
 BF16_MFMA_POWER_LIMITED_TFLOPS = 1839.0
 
-# HBM traffic of the dominant launch: NOT measured in this run (PMC counters need rocprofv3) — taken from the committed PMC pass of a
-# 56-image launch of the same kernel and shape (2 * FETCH_SIZE with the gfx950 unit correction + WRITE_SIZE) and scaled by pixels
-PMC_SOURCE = {'x3h': ('profiles/r4_conv_x3h16_pmc.txt', 455220e3, 485220e3),      # the round-4 kernel (16x16x32 MFMAs, raw patch by LDS-DMA)
-              'x6': ('profiles/r1_conv_x6_pmc.txt', 516830e3, 458750e3),
-              'f32': ('profiles/r1_conv_halo_pmc.txt', 497520e3, 458750e3)}
+# HBM traffic (roofline.traffic): PMC counters cannot be read from inside this process (rocprofv3 wraps the run), so the line quotes the
+# committed counter passes of THIS round's code — tools/prof_bench_pmc.sh = two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE: they do
+# not fit one pass) over `python bench.py --steps 1 --warmup 1`, summarised per launch shape by tools/summarize_prof.py — and says so in
+# traffic_source.  Units as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE in KB, read bytes = 2 x FETCH_SIZE (gfx950 correction).
+PMC_FILE = 'profiles/r6_pmc_traffic.json'
+
+
+def pmc_traffic(kernel_substr, workgroups, threads_per_wg=256, workload='views'):
+    """bytes per launch of the launch shape (kernel name contains `kernel_substr`, grid = workgroups x threads) from the committed PMC passes, or None"""
+    try:
+        with open(os.path.join(REPO, PMC_FILE)) as f:
+            d = json.load(f)[workload]
+    except (OSError, KeyError, ValueError):
+        return None
+    grid = str(workgroups * threads_per_wg)
+    rd = [v for k, v in d.get('FETCH_SIZE', {}).items() if kernel_substr in k and k.endswith('|' + grid)]
+    wr = [v for k, v in d.get('WRITE_SIZE', {}).items() if kernel_substr in k and k.endswith('|' + grid)]
+    if not rd or not wr:
+        return None
+    n = sum(e['calls'] for e in rd)
+    fetch_kb = sum(e['FETCH_SIZE'] * e['calls'] for e in rd) / n
+    write_kb = sum(e['WRITE_SIZE'] * e['calls'] for e in wr) / sum(e['calls'] for e in wr)
+    return {'bytes': int((2 * fetch_kb + write_kb) * 1024), 'read_bytes': int(2 * fetch_kb * 1024), 'written_bytes': int(write_kb * 1024), 'dispatches': n,
+            'source': f'{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE passes of this round\'s code over one bench step, mean of the {n} dispatches of '
+                      f'this launch shape (grid {grid}); read bytes = 2 x FETCH_SIZE x 1024 (gfx950), written = WRITE_SIZE x 1024; not measured in THIS run '
+                      f'(PMC counters need rocprofv3 around the process)'}
 
 
 def build_models(dev, localization: bool, precision: str = 'f32', conv_arith: str = 'x3h', bf16_activations: bool = True,
@@ -89,8 +110,9 @@ class OpTimer:
     """HIP-event timing (on the launch stream) of the C-ABI launches that matter for the roofline section: every implicit-GEMM launch,
     the codebook lookup and the transformer's attention."""
 
-    def __init__(self):
+    def __init__(self, workload='views'):
         self.gemm, self.vq, self.attn = [], [], []
+        self.workload = workload
 
     def install(self):
         from viewformer_amd import ops
@@ -203,7 +225,10 @@ class OpTimer:
                 'frac': round(fl / ms / 1e9 / peak, 4),
                 # the other roof: q, k, v read once + o written once (this shape: 140 FLOP/B -> the HBM roof sits at 45 % of the bf16 peak)
                 'hbm': {'algorithmic_bytes_per_launch': by // len(self.attn), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
-                        'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4)},
+                        'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                        'traffic': (lambda t: None if t is None else {'bytes': t['bytes'], 'over_algorithmic': round(t['bytes'] / (by // len(self.attn)), 3),
+                                                                      'source': t['source']})(
+                            pmc_traffic('attn_dma_kernel', shape[1], 512, self.workload) if dma else None)},
                 'peak_note': ('non-scaled fp8 MFMA runs at the bf16 rate' if arm == 'fp8' else
                               'x6 executes 6 bf16 MFMA flops per fp32 flop: peak = 2500 / 6' if arm == 'x6' else '')}
 
@@ -234,6 +259,11 @@ def cpu_baseline(models_cfg, S, n_scenes, seed=123):
                 sample=f'{n} scenes x {S} views (same synthetic workload), fp32 torch-CPU restatement of the '
                        f'reference path (oracle/), {cores} of the host\'s {host_cores} logical cores as torch threads '
                        f'(the full pool measured 14x slower: torch CPU conv / matmul regress past a few dozen threads), {dt:.1f} s')
+
+
+def _tail_on():
+    from viewformer_amd import _lib
+    return bool(_lib.load().vf_selected(_lib.SEL_GEMM_TAIL))
 
 
 def timed(step, steps, warmup, dev):
@@ -729,13 +759,21 @@ def main():
     ach = d_fl / (d_ms * 1e-3) / 1e12
     x6 = args.conv_arith in ('x6', 'x3h')
     nprod = {'x3h': 3, 'x6': 6, 'f32': 1}[args.conv_arith]
-    pmc_file, fetch_kb, write_kb = PMC_SOURCE[args.conv_arith]
     from viewformer_amd import _lib as _vflib
     k32 = bool(_vflib.load().vf_selected(_vflib.SEL_CONV_X3H_K32))
-    if args.conv_arith == 'x3h' and not k32:
-        pmc_file, fetch_kb, write_kb = 'profiles/r2_new_kernels_pmc.txt', 466930e3, 458750e3      # the 32x32x16 kernel's pass
     is_dom_shape = dom_key[0] == 1 and tuple(dom_key[2:4]) == (128, 128)
-    pmc_bytes_per_pixel = (2 * fetch_kb + write_kb) * 1.024 / (56 * 128 * 128) if is_dom_shape else None
+    # algorithmic bytes of a launch: x read once + out written once (+ the residual read once: ResnetBlock's conv2 — half of this shape's launches)
+    alg_nores, alg_res = dom_key[1] * (dom_key[2] + dom_key[3]) * 4, dom_key[1] * (dom_key[2] + 2 * dom_key[3]) * 4
+    alg_bytes, pmc, pmc_detail = alg_res, None, None
+    if is_dom_shape and args.conv_arith == 'x3h' and k32:
+        wgs = dom_key[1] // 128 * (dom_key[3] // 128)
+        # (one kernel instantiation serves conv1 — no residual — and conv2 of a ResnetBlock: the PMC mean is over both kinds, and so is the
+        # algorithmic figure it is compared with: half of this shape's launches read a residual)
+        pmc = pmc_traffic('conv3_halo_x3h16_kernelILb1ELb1E', wgs)
+        alg_bytes = (alg_res + alg_nores) // 2
+        if pmc:
+            pmc_detail = {'read': pmc['read_bytes'], 'written': pmc['written_bytes'], 'dispatches': pmc['dispatches'],
+                          'algorithmic_bytes_with_residual': alg_res, 'algorithmic_bytes_without_residual': alg_nores}
     # x6 executes 6 bf16 MFMA flops per algorithmic fp32 flop, so its ceiling in algorithmic terms is bf16_peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / nprod if x6 else F32_MFMA_PEAK_TFLOPS      # dense f16 peak == dense bf16 peak (2.5 PF)
     line['roofline'] = {'bound': 'mfma',
@@ -753,13 +791,14 @@ def main():
                                       f'bf16 {BF16_MFMA_POWER_LIMITED_TFLOPS}; profiles/r4_power_ceiling_probe.txt): the executed rate is '
                                       f'{round(nprod * ach / (F16_MFMA_POWER_LIMITED_TFLOPS if nprod == 3 else BF16_MFMA_POWER_LIMITED_TFLOPS), 3)} of that'
                                       if x6 else 'dense f32 MFMA peak'),
-                        'traffic': (round(pmc_bytes_per_pixel * dom_key[1]) if pmc_bytes_per_pixel else None),
+                        'traffic': (pmc['bytes'] if pmc else None),
                         'traffic_unit': 'bytes/launch',
-                        'traffic_source': f'NOT measured in this run: PMC pass {pmc_file} (56-image launch of this kernel and shape: 2 x '
-                                          'FETCH_SIZE + WRITE_SIZE), scaled by output pixels',
+                        'traffic_over_algorithmic_bytes': (round(pmc['bytes'] / alg_bytes, 4) if pmc else None),
+                        'traffic_by_launch_kind': pmc_detail,
+                        'traffic_source': (pmc['source'] if pmc else 'no committed PMC pass for this launch shape'),
                         'launch_shape_mode_M_Cin_Cout_batch': list(dom_key), 'avg_launch_ms': round(d_ms, 4),
                         'algorithmic_gflop_per_launch': round(d_fl / 1e9, 1),
-                        'algorithmic_bytes_per_launch': dom_key[1] * (dom_key[2] + 2 * dom_key[3]) * 4,
+                        'algorithmic_bytes_per_launch': alg_bytes,
                         'family': {'kernels': 'every conv/dense launch of the step (conv3_halo_x3h/_x6/_bf16/_f32, igemm_f32, gemm_bf16, gemm_x6)',
                                    'achieved': round(fam, 2),
                                    'launches_per_step': n, 'kernel_ms_per_step': round(ms, 3),

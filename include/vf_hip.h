@@ -52,10 +52,10 @@ const char* vf_build_flag_name(int i);
  * that change numerics at tolerance level: VF_SEL_CONV_X3H_K32 (two MFMA shapes: same fp32-equivalence bound, same reference tokens) and
  * VF_SEL_ATTN_DMA (since round 4 the LDS-DMA kernel pre-scales q by scale*log2(e) and re-rounds it to bf16 and keeps a lazily-updated
  * reference maximum: within 1e-2 * max|out| of the register-staged kernel, tests/test_hip_parity_scale.py; both inside the bf16 arm's
- * stated tolerance).  Training note (round 6): the bf16 flash backward re-materialises P from the SAME re-rounded operand the forward used —
- * attn_bwd_dq takes q' = bf16(q scale log2 e) like the forward; attn_bwd_dkv streams q un-scaled (dK = dS^T.Q needs it) and carries the
- * rounding on its register-resident k instead (k' = bf16(k log2 e), scale == 1) — so the exponent of P differs from the forward's by one
- * bf16 rounding of one operand at most, at any score magnitude (tests/test_train.py: the gradient test at |s| ~ 25).
+ * stated tolerance).  Training note (round 6): the dQ kernel of the bf16 flash backward re-materialises P from the forward's own operand
+ * q' = bf16(q scale log2 e) (the same S product bit for bit); the dK / dV kernel streams q un-rounded (dK = dS^T.Q needs it), so its P differs
+ * from the forward's by that one rounding of q — |s| 2^-9 in the exponent; both stay inside the bound tests/test_train.py states at the score
+ * magnitudes of a trained model (|s| <= 40: test_bf16_flash_attention_backward_at_trained_scale_scores).
  * Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}, all default to 1. */
 enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA ring kernel where it applies, 0 = register-staged kernel (tolerance-level pair) */
        VF_SEL_GEMM_G256 = 1,         /* vf_gemm_bf16: 1 = 256-tile LDS-DMA kernel where it applies, 0 = 128-tile kernel */
@@ -65,7 +65,9 @@ enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA
                                       * switch whose two sides differ in the last bits (another accumulation order; same fp32-equivalence bound) */
        VF_SEL_GEMM_TAIL = 5,         /* the 256-tile bf16 GEMM: 1 = launches whose last round of the 256 CUs would be a few tiles to 3/4 full end with ONE round of
                                       * 192- / 128-row tail tiles instead (K is never split: bit-identical results), 0 = the plain grid (round 6) */
-       VF_SEL_COUNT = 6 };
+       VF_SEL_CONV_S2_DMA = 6,       /* vf_conv3_halo_x3h, stride 2 (Downsample): 1 = the next chunk's raw patch travels HBM -> LDS by DMA, 0 = through registers
+                                      * (bit-identical; round 6) */
+       VF_SEL_COUNT = 7 };
 int vf_select(int which, int value);
 int vf_selected(int which);
 

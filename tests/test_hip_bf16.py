@@ -453,8 +453,8 @@ def test_gemm_bf16_256_tile_lds_dma_kernel_is_bit_identical(dev, M, K, N):
 
 
 @pytest.mark.parametrize('M,K,N,tail', [(19200, 768, 3072, (64, 15, 3)), (19200, 768, 2304, (56, 26, 3)), (57344, 3072, 768, (170, 72, 3)),
-                                        (19200 - 70, 128, 3072, (64, 15, 3)), (16384 + 4000, 64, 2048, (64, 32, 2)), (19200, 768, 768, None),
-                                        (65536, 64, 3072, None)])
+                                        (19200 - 70, 128, 3072, (64, 15, 3)), (16384 + 4000, 128, 2048, (64, 32, 2)), (19200, 768, 768, None),
+                                        (65536, 128, 3072, None)])
 def test_gemm_bf16_tail_tiles_are_bit_identical_to_the_plain_grid(dev, M, K, N, tail):
     """round 6: launches whose last round of the 256 CUs would be partly filled end with one round of 192- / 128-row TAIL tiles instead
     (csrc/gemm_bf16_g256.hip: g256_tail_policy; vf_select(VF_SEL_GEMM_TAIL)).  K is never split, so every output element keeps its k order:

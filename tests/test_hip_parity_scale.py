@@ -46,17 +46,20 @@ FLIP_MARGIN_MAX = 2e-4
 FLIP_RATE_MAX = 1e-3        # and at most 0.1 % of tokens
 
 
-@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h', 'x3h/32x32x16'])
+@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h', 'x3h/32x32x16', 'x3h/s2-register-staging'])
 def test_token_flip_rate_on_20k_reference_tokens(dev, arith):
     """'x3h' runs the stride-1 convolutions on the 16x16x32 MFMA kernel (the default), 'x3h/32x32x16' on the 32x32x16 one
-    (vf_select(VF_SEL_CONV_X3H_K32, 0)): two accumulation orders, the same tokens"""
+    (vf_select(VF_SEL_CONV_X3H_K32, 0)): two accumulation orders, the same tokens; 'x3h/s2-register-staging': the Downsample convolutions
+    with round 5's register staging instead of the LDS-DMA staging (vf_select(VF_SEL_CONV_S2_DMA, 0); bit-identical by construction)"""
     from viewformer_amd import _lib
     k32 = 0 if arith.endswith('32x32x16') else 1
     _lib.select(_lib.SEL_CONV_X3H_K32, k32)
+    _lib.select(_lib.SEL_CONV_S2_DMA, 0 if arith.endswith('register-staging') else 1)
     try:
         _token_flip_rate(dev, arith.split('/')[0], arith)
     finally:
         _lib.select(_lib.SEL_CONV_X3H_K32, 1)
+        _lib.select(_lib.SEL_CONV_S2_DMA, 1)
 
 
 def _token_flip_rate(dev, arith, label):
@@ -90,7 +93,6 @@ def _token_flip_rate(dev, arith, label):
 MIXED_LOGIT_TOL_REL = 3e-2      # as tests/test_hip_bf16.py
 MIXED_U8_TOL_LEVELS = 10        # decoder on bf16 MFMA: final image vs the fp32 oracle's decode of the SAME codes
 MIXED_U8_MEAN_LEVELS, MIXED_U8_P99_LEVELS, MIXED_U8_P999_LEVELS = 1.0, 3, 5   # ... and its distribution (measured: mean 0.55, max 6-7)
-MIXED_U8_P999_FULL_LEVELS, MIXED_U8_MEAN_FULL_LEVELS = 8, 1.5   # vs the ALL-oracle image on cells whose token and 8 neighbours agree
 MIXED_POSE_TOL = 3e-2           # generated camera (position in scene units / unit quaternion)
 MIXED_POSE_TOL_WIDE = 1.5e-1    # ... at 1.5x the init scale (std 0.03): measured 1.0e-1
 
@@ -141,23 +143,18 @@ def test_mixed_arm_end_to_end_against_oracle(dev, full_vq, std):
     assert du.float().mean() < MIXED_U8_MEAN_LEVELS and p99 <= MIXED_U8_P99_LEVELS and p999 <= MIXED_U8_P999_LEVELS, (hist, p99, p999)
     # and against the all-oracle image where the generated codes agree
     full = (got['generated_images'].cpu().int() - ref['generated_images'].int()).abs().float()
-    #  ... asserted, not only reported: on the 16 x 16-pixel cells whose own token AND all eight neighbouring tokens agree with
-    # the all-oracle generation, the distance to the ALL-ORACLE image — the oracle's encoder, transformer, arg-max and decoder, nothing of the
-    # GPU's in it — has the same bounded distribution; what a far-away differing token adds there (through the decoder's 16 x 16 attention
-    # block and the 3 x 3 stacks' growing footprint) is inside the stated levels
-    agree = same.reshape(B, 8, 8)
-    pad = torch.nn.functional.pad(agree.float().unsqueeze(1), (1, 1, 1, 1), value=1.0)
-    interior = (torch.nn.functional.avg_pool2d(pad, 3, stride=1) > 0.999).squeeze(1)              # token + its 8 neighbours agree
-    pix = interior.repeat_interleave(16, 1).repeat_interleave(16, 2).unsqueeze(-1).expand(B, 128, 128, 3)
-    n_pix = int(pix.sum())
-    if n_pix >= 3 * 256 * 8:                                                                      # at least 8 such cells, else nothing to state
-        fv = full[pix].reshape(-1)
-        hist_full = torch.bincount(fv.long(), minlength=32).tolist()
-        cdf_full = np.cumsum(hist_full) / float(fv.numel())
+    #  ... asserted, not only reported: in every scene whose 64 generated tokens ALL agree with the all-oracle generation, the
+    # distance to the ALL-ORACLE image — the oracle's encoder, transformer, arg-max and decoder, nothing of the GPU's in it — has the bounded
+    # distribution stated above.  (Scene-level on purpose: the decoder's attention blocks are global, one differing token anywhere moves every
+    # pixel — measured on this test: on cells whose own token and 8 neighbours agree but another token of the scene differs, the all-oracle
+    # image is a DIFFERENT image, mean 10.7 levels.)  At init-scale weights few scenes agree in all 64 tokens; the count is reported.
+    agree_scene = same.reshape(B, -1).all(1)
+    p999_full = None
+    if bool(agree_scene.any()):
+        fv = full[agree_scene].reshape(-1)
+        cdf_full = np.cumsum(torch.bincount(fv.long(), minlength=MIXED_U8_TOL_LEVELS + 1).tolist()) / float(fv.numel())
         p999_full = int(np.searchsorted(cdf_full, 0.999))
-        assert p999_full <= MIXED_U8_P999_FULL_LEVELS and fv.mean() < MIXED_U8_MEAN_FULL_LEVELS, (p999_full, float(fv.mean()), hist_full[:16])
-    else:
-        p999_full = None
+        assert fv.max() <= MIXED_U8_TOL_LEVELS and p999_full <= MIXED_U8_P999_LEVELS and fv.mean() < MIXED_U8_MEAN_LEVELS, (p999_full, float(fv.mean()))
     e_cam = _maxerr(got['generated_cameras'], ref['generated_cameras'])
     # the camera head's error grows with the weight scale like the logits' (measured 0.10 at std 0.03, round 4: reported then, asserted now
     # with its own stated bound — 5x the init-scale bound, one unit-quaternion component / scene unit in seven)
@@ -166,8 +163,8 @@ def test_mixed_arm_end_to_end_against_oracle(dev, full_vq, std):
             max_abs_logit=float(ref['logits_last'].abs().max()), generated_code_agreement=float(same.float().mean()),
             max_logit_gap_at_disagreement=float(gap.max()), u8_max_diff_same_codes=int(du.max()),
             u8_mean_diff_same_codes=float(du.float().mean()), u8_diff_histogram_same_codes=hist, u8_p99=p99, u8_p999=p999,
-            u8_mean_diff_vs_full_oracle=float(full.mean()), u8_p999_vs_full_oracle_on_agreeing_cells=p999_full,
-            agreeing_interior_cells=int(interior.sum()), camera_err=e_cam)
+            u8_mean_diff_vs_full_oracle=float(full.mean()), u8_p999_vs_full_oracle_in_fully_agreeing_scenes=p999_full,
+            fully_agreeing_scenes=int(agree_scene.sum()), camera_err=e_cam)
     if std <= 0.02:
         assert same.float().mean() > 0.9, same.float().mean()
 

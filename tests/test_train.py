@@ -835,8 +835,8 @@ ATTN_BF16_BWD_TOL_PEAKED = 6e-2      # the same bound at score magnitudes of a t
 def test_bf16_flash_attention_backward_at_trained_scale_scores(dev, B, H, S, mode):
     """MIGT's scores are UNSCALED (branching_attention.py:5-18), so a bf16 rounding of q (2^-9 relative) moves a score by |s| 2^-9 —
     every other attention test of this file runs at init-scale weights (|s| < 5).  Until round 6 the bf16 forward rounded q' = bf16(q log2 e)
-    while the backward re-materialised P from the un-rounded q; now the dQ kernel uses the forward's q' and the dK / dV kernel carries the one
-    rounding on k instead.  Here |s| reaches 25-40 (a peaked, trained-model softmax): the gradients must stay within the stated bound of the
+    while the backward re-materialised P from the un-rounded q; now the dQ kernel uses the forward's q' (its P is the forward's), the dK / dV
+    kernel still streams the un-rounded q.  Here |s| reaches 25-40 (a peaked, trained-model softmax): the gradients must stay within the stated bound of the
     exact-f32 kernels on the same operands, the forward within its own."""
     from viewformer_amd import train_ops as T
     L, d = 64, H * 64

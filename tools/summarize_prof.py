@@ -25,6 +25,7 @@ def main():
     filt = sys.argv[2:] or ['igemm', 'conv3_halo', 'gemm_direct', 'vq_argmin', 'attn_', 'gn_partial', 'layernorm',
                             'conv_in', 'softmax']
     lines = []
+    by_shape = {}
     for db in sorted(glob.glob(os.path.join(out, '*', '*.db'))):
         c = sqlite3.connect(db)
         T = tables(c)
@@ -60,6 +61,24 @@ def main():
             acc[n][pn].append(v)
             ninst[pn] = cnt
         dur = {r[0]: r[2] for r in rows}
+        # per LAUNCH SHAPE (kernel, grid size): a kernel's shapes differ by orders of magnitude in traffic — the mean over all of a kernel's dispatches
+        # (below) says nothing about one launch.  Written as JSON too (pmc_by_shape.json): bench.py reads the committed copy for roofline.traffic.
+        qs = (f"select s.kernel_name, d.grid_size_x, p.name, d.id, sum(e.value), (d.end - d.start) from {pe} e join {ip} p on e.pmc_id=p.id "
+              f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, d.grid_size_x, p.name, d.id")
+        shp = defaultdict(lambda: defaultdict(list))
+        sdur = defaultdict(list)
+        for n, gx, pn, did, v, dt in c.execute(qs):
+            if any(f in n for f in filt):
+                shp[(n, gx)][pn].append(v)
+                sdur[(n, gx)].append(dt)
+        by_shape.setdefault(tag, {})
+        lines.append(f'== {tag}: rocprofv3 --pmc, per LAUNCH SHAPE (kernel, grid_size_x): mean over the dispatches of that shape')
+        for (n, gx), d in sorted(shp.items(), key=lambda kv: -sum(sdur[kv[0]])):
+            cnt = len(next(iter(d.values())))
+            lines.append(f'  {short(n)[:60]:60s} grid_x={gx:>9} calls={cnt:4d} avg_us={sum(sdur[(n, gx)]) / len(sdur[(n, gx)]) / 1e3:9.2f}  '
+                         + ', '.join(f'{k}={sum(v) / len(v):.6g}' for k, v in sorted(d.items())))
+            by_shape[tag][f'{short(n)}|{gx}'] = dict(calls=cnt, avg_us=sum(sdur[(n, gx)]) / len(sdur[(n, gx)]) / 1e3,
+                                                    **{k: sum(v) / len(v) for k, v in d.items()})
         lines.append(f'== {tag}: rocprofv3 --pmc, per-dispatch totals (sum over instances), mean over dispatches')
         for n, d in acc.items():
             if any(f in n for f in filt):
@@ -71,6 +90,9 @@ def main():
                     lines.append(f'      GRBM_GUI_ACTIVE per instance ({ninst.get("GRBM_GUI_ACTIVE", 1)} instances) = {g:.5g} cycles -> '
                                  f'{g / (dur[n] / 1e3) / 1e3:.3f} GHz effective clock over the dispatch')
     open(os.path.join(out, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
+    if by_shape:
+        import json
+        json.dump(by_shape, open(os.path.join(out, 'pmc_by_shape.json'), 'w'), indent=1)
     print('\n'.join(lines))
 
 

@@ -72,12 +72,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_PAIRGRID
 #define ADMA_PAIRGRID 0     // the query blocks of a (scene, head) adjacent on one XCD (round 5 A/B; 0 = all first blocks, then all second blocks)
 #endif
-#ifndef ADMA_KSTEP17
-#define ADMA_KSTEP17 1      // the reference maximum enters the S product as a 17th k-step (round 6); 0 = round 5's form (accumulators start at -m_ref)
-#endif
-#ifndef ADMA_DOTSUM
-#define ADMA_DOTSUM 0       // A/B (round 6): the row sum from the bf16-ROUNDED probabilities, two per v_dot2c_f32_bf16, instead of one v_add_f32 per score
-#endif
 constexpr float ADMA_THR = 8.0f;             // a query's reference maximum moves when a tile exceeds it by more than this (exponent-of-2 units)
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
@@ -291,22 +285,6 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     float m_ref[U], l_run[U];                                        // reference maximum (exponent-of-2 units; valid once `seen`), running sum
 #pragma unroll
     for (int u = 0; u < U; ++u) { m_ref[u] = 0.f; l_run[u] = 0.f; }
-#if ADMA_KSTEP17
-    // KSTEP17 (round 6).  Until round 5 the score accumulators STARTED at -m_ref: 32 v_mov per (32-query, 64-key) unit in a
-    // loop that is bound by the vector unit's issue rate (profiles/r5_attention_ab.txt).  The subtraction is now one more k-step of the S
-    // product: A = 1 in k slot 0 of every key row, B = -m_ref of the lane's query in k slot 0 — two more MFMAs per unit on a matrix pipe
-    // that idles half the time, and the accumulators start from the MFMA's inline-constant zero.  For that m_ref must be a bf16 number:
-    // it is ROUNDED to bf16 whenever it is set or moved — the softmax is exact against any reference (numerator and normaliser share it),
-    // the rounding only decides how far below a tile's true maximum the reference may sit (2^-9 relative: p <= 2^0.4 at |m| = 100).
-    bf16x8 ones_a, mref_b[U];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones_a[e] = (__bf16)0.f;
-    if (half == 0) ones_a[0] = (__bf16)1.0f;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mref_b[u][e] = (__bf16)0.f;
-#endif
     bool seen = false;                                               // wave-uniform: a visible tile has been processed
     // attention dropout: mask plane (scene, head), group q * (T / 4) + (key >> 2); this lane's keys of a tile are + 4 half + ...
     uint32_t drop_key = 0u, drop_q[U];
@@ -326,16 +304,6 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
 
     // ---- S^T = K . Q^T of one tile (each K fragment feeds the wave's U query tiles), accumulated from minus the reference maximum
     auto scores = [&](const unsigned char* tile, f32x16 (&st)[U][2]) {
-#if ADMA_KSTEP17
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[u][t2][r] = 0.f;                 // (folds into the MFMA's C operand: no instruction)
-                st[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, mref_b[u], st[u][t2], 0, 0, 0);      // - m_ref (0 before the first tile)
-            }
-#else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float c0 = seen ? -m_ref[u] : 0.f;
@@ -344,7 +312,6 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[u][t2][r] = c0;
         }
-#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -375,18 +342,10 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
 #else
             const float p = __builtin_amdgcn_exp2f(decltype(sub)::value ? x - dlt : x);
 #endif
-            if (DROP || !ADMA_DOTSUM) psum += p;                     // the normaliser is over the undropped weights
+            psum += p;                                               // the normaliser is over the undropped weights
             if constexpr (DROP) pk[e] = (__bf16)(vf_dropout_keep(w[e >> 2], e & 3, drop_thresh) ? p : 0.f);
             else pk[e] = (__bf16)p;
         }
-#if ADMA_DOTSUM
-        if constexpr (!DROP) {                                       // sum of the probabilities the P.V product applies: 4 dot instructions per 8 scores
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 w4 = __builtin_bit_cast(u32x4, pk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum) : "v"(w4[i]), "v"(0x3f803f80u));
-        }
-#endif
         return pk;
     };
     auto vt_frag = [&](const unsigned char* tile, int t2, int ks2, int d) {
@@ -417,13 +376,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         for (int u = 0; u < U; ++u) {
             const float mx = tile_max(st[u]);
             // dlt: what this query's reference moves by — everything on its first tile, the excess over the threshold later
-#if ADMA_KSTEP17
-            // (the new reference is a bf16 number; dlt = new - old is exact in fp32: both are 8-bit-mantissa numbers a few binades apart)
-            const float new_ref = (float)(__bf16)(m_ref[u] + mx);
-            const float dlt = (!seen || mx > ADMA_THR) ? new_ref - m_ref[u] : 0.f;
-#else
             const float dlt = !seen ? mx : (mx > ADMA_THR ? mx : 0.f);
-#endif
             const bool moved = !seen || __builtin_amdgcn_ballot_w64(dlt != 0.f) != 0ull;      // wave-uniform
             float psum = 0.f;
 #pragma unroll
@@ -432,12 +385,6 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
                 for (int ks2 = 0; ks2 < 2; ++ks2)
                     pb[u][t2][ks2] = moved ? prob_frag(std::true_type{}, st[u], u, t2, ks2, tcur, dlt, psum)
                                            : prob_frag(std::false_type{}, st[u], u, t2, ks2, tcur, dlt, psum);
-#if ADMA_KSTEP17
-            if (moved) {
-                const __bf16 nm = (__bf16)(-(m_ref[u] + dlt));                  // exact: m_ref + dlt = new_ref, a bf16 number
-                if (half == 0) mref_b[u][0] = nm;
-            }
-#endif
             if (!seen) {
                 l_run[u] = psum;
                 m_ref[u] = dlt;

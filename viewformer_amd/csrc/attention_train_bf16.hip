@@ -38,23 +38,18 @@ constexpr int DH = 64, KT = 64;
 constexpr int IMG = KT * DH * 2;             // one 64 x 64 bf16 image: 8 KB
 constexpr int OT = 128;                      // owner rows per workgroup: 4 waves x 32
 constexpr float LOG2E = 1.4426950408889634f;
-#ifndef ATB_FOLD
-#define ATB_FOLD 1          // round 6: per-score arithmetic folded into the MFMAs' C operands; 0 = round 5's form
-#endif
-// FOLD.  Both kernels are bound by the vector unit, not the matrix pipe (the forward's finding, profiles/r5_attention_ab.txt): per score the
-// round-5 form issued {fma, exp2, sub, mul, mul, 1/2 cvt} (dQ) and {mul, fma, exp2, sub, mul, mul, cvt} (dK / dV).  Now:
-//   * q enters the S products as the FORWARD kernel rounds it — q' = bf16(q scale log2 e), attention_dma.hip — so the re-materialised
-//     P = exp2(q'.k - lse log2 e) is the forward's P bit for bit in its exponent (the backward used the un-rounded q), and the
-//     MFMA delivers the exponent of 2 directly;
-//   * a query's -lse log2 e + log2(scale) and -D are constants of the whole kernel (dQ: one query per lane -> all 16 registers of a score
-//     accumulator): they are the C operand of the tile's FIRST MFMA (16 loop-invariant registers each, D != C), so the accumulators come out
-//     as the exponent of scale * P and as dP - D:  dS = exp2(acc_s) * acc_p — {exp2, mul, 1/2 cvt} per score;
-//   * dK / dV (a lane holds 16 queries of one key): the per-query constants come from the tile's lse / D table; -lse log2 e + log2(scale) is
-//     one fma per score straight into the C operand (it replaces mul + fma), the scale multiplication is gone: {fma, exp2, sub, mul, cvt}.
-// dK = dS^T.Q needs the UN-scaled q: the streamed q tile is un-scaled anyway (only the register-resident owner operand is pre-scaled, and the
-// dK / dV kernel's owner operands are K and V); its S = Q.K^T uses K pre-scaled instead — k' = bf16(k log2 e), the same product up to which
-// operand carries the 2^-9 rounding (stated in include/vf_hip.h).  dV needs P, dS needs scale * P: the dK / dV kernel folds only when
-// scale == 1 (MIGT: always), the dQ kernel (which needs only scale * P) for any scale.
+// FOLD (round 6, dQ kernel; ADVICE r5 + VERDICT r5 item 2).  The forward kernel (attention_dma.hip) multiplies q by scale * log2 e and re-rounds
+// it to bf16 before its S product; until round 6 the backward re-materialised P from the UN-rounded q — an exponent off by |s| 2^-9, which
+// at the score magnitudes of a trained model (MIGT's scores are unscaled) is several per cent of P.  The dQ kernel holds q as its
+// register-resident B operand, so it now applies the forward's rounding: S^T = K.q'^T is the forward's product bit for bit (same MFMA, same
+// k order), and the per-score arithmetic shrinks with it: a query's -lse log2 e + log2(scale) and -D are constants of the whole kernel (one
+// query per lane = all 16 registers of an accumulator), so they are the C operand of each tile's first MFMA (32 loop-invariant registers,
+// D != C) and dS = exp2(acc_s) * acc_p — {exp2, mul, 1/2 cvt} per score instead of {fma, exp2, sub, mul, mul, 1/2 cvt}.
+// MEASURED (profiles/r6_attention_diet.txt): dq error against fp64 autograd at |s| <= 40: 1.15e-2 instead of 2.7e-2; time of dQ + dK/dV at the
+// training shape -3 % (-1 % with dropout) although the dQ kernel issues 55 % fewer vector instructions per score: like the forward, the
+// kernel is not bound by its instruction count.  The same fold in the dK / dV kernel (k' = bf16(k log2 e) as the owner operand, the
+// lse table as the S accumulators' C operand) was measured and NOT kept: its P then carries a DIFFERENT rounding than the forward's
+// (dv error 3.0e-2 instead of 1.5e-2 at |s| <= 40) for no measurable time.
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
@@ -221,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
     const size_t stat = ((size_t)b * H + h) * T + qrow;
     const float lse2 = lse[stat] * LOG2E, D_q = Dv[stat];
     const float c2 = scale * LOG2E;
-#if ATB_FOLD
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -235,7 +229,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         for (int r = 0; r < 16; ++r) { c_s[r] = cs; c_p[r] = cp; }
         asm volatile("" : "+v"(c_s), "+v"(c_p));
     }
-#endif
     // attention dropout: mask plane (scene, head), group q * (T / 4) + (key >> 2); this lane's keys of a tile are + 4 half + ...
     uint32_t drop_key = 0u, drop_q = 0u;
     if constexpr (DROP) {
@@ -287,13 +280,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         f32x16 st[2], dp[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-#if ATB_FOLD
-            st[t2] = c_s;
-            dp[t2] = c_p;
-#else
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st[t2][r] = 0.f; dp[t2][r] = 0.f; }
-#endif
+            st[t2] = c_s;                                            // log2(scale) - lse log2 e
+            dp[t2] = c_p;                                            // -D   (DROP: -D / c)
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -318,17 +306,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = ks2 * 8 + e;
-#if ATB_FOLD
                     const float ps = __builtin_amdgcn_exp2f(st[t2][r]);                    // scale * P
                     float x = dp[t2][r];                                                     // dP - D   (DROP: dP - D / c)
                     if constexpr (DROP) x = vf_dropout_keep(w[e >> 2], e & 3, drop_thresh) ? x * drop_scale : -D_q;      // keep ? c dP - D : -D
                     ds[t2][ks2][e] = (__bf16)(ps * x);
-#else
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t2][r], c2, -lse2));
-                    float dpr = dp[t2][r];
-                    if constexpr (DROP) dpr = vf_dropout_keep(w[e >> 2], e & 3, drop_thresh) ? dpr * drop_scale : 0.f;      // d(dropped P)/dP
-                    ds[t2][ks2][e] = (__bf16)(p * (dpr - D_q) * scale);
-#endif
                 }
             }
 #pragma unroll
@@ -360,9 +341,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
 constexpr int KV_SLOT = 4 * IMG + 512, KV_RING = 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
 
-// FOLD (template): the folded form, taken when scale == 1 (MIGT's attention has no score scaling, branching_attention.py:5-18) — with another
-// scale P and scale * P differ and the kernel keeps round 5's arithmetic
-template <bool O16, bool DROP, bool FOLD>
+template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                    const __bf16* __restrict__ v, const __bf16* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dv,
@@ -404,12 +383,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
         }
     }
     const float c2 = scale * LOG2E;
-    if constexpr (FOLD) {                                              // k' = bf16(k log2 e): the S product's owner operand (kb is used for nothing else)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) kb[ks][e] = (__bf16)((float)kb[ks][e] * LOG2E);
-    }
     // attention dropout: this lane's key is element krow & 3 of group (krow >> 2) of every query's row of groups
     uint32_t drop_key = 0u, drop_k = 0u;
     const int drop_j = krow & 3;
@@ -469,37 +442,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                                              // the tile's two 32-query halves
             f32x16 st, dp;
-            if constexpr (FOLD) {
-                // accumulator row r = query 32 u + (r & 3) + 8 (r >> 2) + 4 half: S starts at -lse log2 e of its query (the tile's table)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { st[4 * j + e] = l4[e] * -LOG2E; dp[4 * j + e] = 0.f; }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-            }
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const unsigned off = row_off + u * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + off);
                 const bf16x8 c = *reinterpret_cast<const bf16x8*>(slot + IMG + off);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb[ks], st, 0, 0, 0);              // S = Q.K^T [query][key]   (FOLD: log2 P = Q.K'^T - lse')
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb[ks], st, 0, 0, 0);              // S = Q.K^T   [query][key]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, vb[ks], dp, 0, 0, 0);              // dP = dO.V^T
             }
             // accumulator row r = query 32 u + (r & 3) + 8 (r >> 2) + 4 half: its lse / D from the tile's table
             bf16x8 pf[2], sf[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (!FOLD) l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + 256 + (32 * u + 8 * j + 4 * half) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * j + e;
-                    const float p = FOLD ? __builtin_amdgcn_exp2f(st[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e] * LOG2E));
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e] * LOG2E));
                     float dpr = dp[r];
                     bool keep = true;
                     if constexpr (DROP) {                            // accumulator row r = query 64 qt + 32 u + 8 j + e + 4 half
@@ -508,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
                         dpr = keep ? dpr * drop_scale : 0.f;
                     }
                     pf[r >> 3][r & 7] = keep ? (__bf16)p : (__bf16)0.f;          // (its 1 / (1 - rate) joins dV at the end)
-                    sf[r >> 3][r & 7] = FOLD ? (__bf16)(p * (dpr - d4[e])) : (__bf16)(p * (dpr - d4[e]) * scale);
+                    sf[r >> 3][r & 7] = (__bf16)(p * (dpr - d4[e]) * scale);
                 }
             }
 #pragma unroll
@@ -583,8 +545,7 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
         static unsigned long long attr_devs = 0;                   // (one flag per instantiation pair)
         if (vf_attr_needed(&attr_devs)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_bf16_kernel<O16, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_RING * DQ_SLOT);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<O16, DROP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<O16, DROP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel<O16, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_RING * KV_SLOT);
             if (e != hipSuccess) return (int)e;
             vf_attr_done(&attr_devs);
         }
@@ -592,12 +553,8 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
                            ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
         const int st = vf_last_status();
         if (st) return st;
-        if (ATB_FOLD && scale == 1.0f)
-            hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP, true>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T,
-                               ldq, ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
-        else
-            hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP, false>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T,
-                               ldq, ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
+        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
+                           ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
         return vf_last_status();
     };
     using T_ = std::true_type;
