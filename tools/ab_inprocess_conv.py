@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """In-process A/B of the encoder's x3h convolutions across builds of libvf_hip.so: every library is loaded with its own handle and the SAME launch
 is timed in alternation (box / minute clock drift cancels); outputs are compared bit for bit with the first library's.
-  python tools/ab_inprocess_conv.py [--cases s1res,s1,s2,...] lib1.so lib2.so ..."""
+  python tools/ab_inprocess_conv.py [--cases s1res,s1,s2,...] lib1.so lib2.so[:SEL=VAL] ...
+A library given as path:SEL=VAL is loaded from a private COPY (its own vf_select state) with vf_select(SEL, VAL) applied: one build, two switch settings."""
 import json
 import os
 import statistics
@@ -16,7 +17,24 @@ args = sys.argv[1:]
 cases = 's1res,s1,s2,s2_64,s2_32'
 if args and args[0] == '--cases':
     cases, args = args[1], args[2:]
-libs = [(os.path.basename(p), _lib.load_variant(p)) for p in args]
+torch.zeros(1, device=dev)                                # (the HIP runtime is up before any library copy is loaded)
+
+
+def _load(spec):
+    if ':' not in spec:
+        return os.path.basename(spec), _lib.load_variant(spec)
+    import shutil
+    import tempfile
+    path, sel = spec.split(':')
+    which, val = (int(x) for x in sel.split('='))
+    tmp = os.path.join(tempfile.mkdtemp(prefix='vf_ab_'), f'libvf_sel{which}_{val}.so')
+    shutil.copy(path, tmp)
+    h = _lib.load_variant(tmp)
+    assert h.vf_select(which, val) >= 0
+    return f'{os.path.basename(path)}[vf_select({which},{val})]', h
+
+
+libs = [_load(p) for p in args]
 
 
 def bench(name, make):
