@@ -601,7 +601,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if args.preflight or world > 1:
-        pf = preflight(args, rank, local, world, dev)
+        try:
+            pf = preflight(args, rank, local, world, dev)
+        except Exception as e:      # noqa: BLE001  (inside a timed run the pre-flight is a courtesy: it must never cost the line; --preflight alone fails loudly)
+            if args.preflight:
+                raise
+            pf = {'preflight': 'ERROR', 'error': repr(e)[:400]}
         if rank == 0:
             (sys.stdout if args.preflight else sys.stderr).write(json.dumps(pf) + '\n')
             (sys.stdout if args.preflight else sys.stderr).flush()

@@ -65,9 +65,7 @@ enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA
                                       * switch whose two sides differ in the last bits (another accumulation order; same fp32-equivalence bound) */
        VF_SEL_GEMM_TAIL = 5,         /* the 256-tile bf16 GEMM: 1 = launches whose last round of the 256 CUs would be a few tiles to 3/4 full end with ONE round of
                                       * 192- / 128-row tail tiles instead (K is never split: bit-identical results), 0 = the plain grid (round 6) */
-       VF_SEL_CONV_S2_DMA = 6,       /* vf_conv3_halo_x3h, stride 2 (Downsample): 1 = the next chunk's raw patch travels HBM -> LDS by DMA, 0 = through registers
-                                      * (bit-identical; round 6) */
-       VF_SEL_COUNT = 7 };
+       VF_SEL_COUNT = 6 };
 int vf_select(int which, int value);
 int vf_selected(int which);
 

@@ -79,7 +79,7 @@ def test_library_reads_no_environment_and_its_switches_are_explicit(lib):
     csrc = os.path.join(REPO, 'viewformer_amd', 'csrc')
     for f in os.listdir(csrc):
         assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
-    n = 7                                                                    # VF_SEL_COUNT (round 6: + VF_SEL_GEMM_TAIL, VF_SEL_CONV_S2_DMA: bit-identical pairs)
+    n = 6                                                                    # VF_SEL_COUNT (round 6: + VF_SEL_GEMM_TAIL, a bit-identical pair)
     for which in range(n):
         assert lib.vf_selected(which) == 1                                   # defaults: the faster kernel of each pair
         assert lib.vf_select(which, 0) == 1 and lib.vf_selected(which) == 0

@@ -46,20 +46,17 @@ FLIP_MARGIN_MAX = 2e-4
 FLIP_RATE_MAX = 1e-3        # and at most 0.1 % of tokens
 
 
-@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h', 'x3h/32x32x16', 'x3h/s2-register-staging'])
+@pytest.mark.parametrize('arith', ['f32', 'x6', 'x3h', 'x3h/32x32x16'])
 def test_token_flip_rate_on_20k_reference_tokens(dev, arith):
     """'x3h' runs the stride-1 convolutions on the 16x16x32 MFMA kernel (the default), 'x3h/32x32x16' on the 32x32x16 one
-    (vf_select(VF_SEL_CONV_X3H_K32, 0)): two accumulation orders, the same tokens; 'x3h/s2-register-staging': the Downsample convolutions
-    with round 5's register staging instead of the LDS-DMA staging (vf_select(VF_SEL_CONV_S2_DMA, 0); bit-identical by construction)"""
+    (vf_select(VF_SEL_CONV_X3H_K32, 0)): two accumulation orders, the same tokens"""
     from viewformer_amd import _lib
     k32 = 0 if arith.endswith('32x32x16') else 1
     _lib.select(_lib.SEL_CONV_X3H_K32, k32)
-    _lib.select(_lib.SEL_CONV_S2_DMA, 0 if arith.endswith('register-staging') else 1)
     try:
         _token_flip_rate(dev, arith.split('/')[0], arith)
     finally:
         _lib.select(_lib.SEL_CONV_X3H_K32, 1)
-        _lib.select(_lib.SEL_CONV_S2_DMA, 1)
 
 
 def _token_flip_rate(dev, arith, label):

@@ -81,37 +81,6 @@ def test_conv3_halo_x3h_is_fp32_equivalent(dev, mode, cin, cout, H, pro):
     assert mx3 < 6e-7 and rms3 < 1.25 * rms32 + 1e-9
 
 
-@pytest.mark.parametrize('cin,cout,H,n', [(128, 128, 32, 3), (64, 256, 64, 2), (32, 128, 32, 5), (128, 128, 128, 2), (256, 256, 32, 4), (32, 128, 64, 1)])
-def test_conv3_s2_x3h_dma_staging_is_bit_identical_to_register_staging(dev, cin, cout, H, n):
-    """round 6: the Downsample convolution with the next chunk's raw patch travelling HBM -> LDS by DMA (the default) against
-    the register-staged form (vf_select(VF_SEL_CONV_S2_DMA, 0)): same split, same MFMA order -> the same bits, incl. the fused GroupNorm
-    partials; tiles on the right / bottom border (zero padding), one 16-channel chunk (no next chunk to stage), several images, repeated
-    launches (the landing area is reused)."""
-    from viewformer_amd import ops, _lib
-    Ho = H // 2
-    x = (_rand((n * H * H, cin), 31) * 1.7).to(dev)
-    w = (_rand((cout, cin, 3, 3), 32) * 0.05).to(dev)
-    b, r = _rand((cout,), 33).to(dev), _rand((n * Ho * Ho, cout), 34).to(dev)
-    wp = ops.pack_conv3_x3h(w)
-    M = n * Ho * Ho
-
-    def run():
-        out = torch.full((M, cout), float('nan'), device=dev)
-        part = ops.new_gn_part(n, Ho, Ho, dev) if cout // 32 <= 16 else None
-        for _ in range(3):
-            ops.igemm(x, wp, M, cin, cout, out, bias=b, res=r, mode=ops.MODE_CONV3_S2PAD, Hin=H, Win=H, Hout=Ho, Wout=Ho, x3h=True, gn_part=part)
-        return out, part
-    new, new_part = run()
-    prev = _lib.select(_lib.SEL_CONV_S2_DMA, 0)
-    try:
-        old, old_part = run()
-    finally:
-        _lib.select(_lib.SEL_CONV_S2_DMA, prev)
-    assert not torch.isnan(new).any() and torch.equal(new, old), (new - old).abs().max().item()
-    if new_part is not None:
-        assert torch.equal(new_part, old_part)
-
-
 @pytest.mark.parametrize('cin,cout,H,pro', [(128, 128, 16, True), (64, 256, 32, False), (128, 128, 64, True), (256, 256, 16, True), (512, 512, 16, False),
                                             (512, 128, 16, True)])
 def test_conv3_halo_x3h_both_mfma_shapes_meet_the_same_bound(dev, cin, cout, H, pro):

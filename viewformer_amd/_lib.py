@@ -34,11 +34,10 @@ class VfIgemmArgs(ctypes.Structure):
 SEL_ATTN_DMA, SEL_GEMM_G256, SEL_LN_BWD_TWO_ROWS, SEL_ATTN_Q32 = 0, 1, 2, 3
 SEL_CONV_X3H_K32 = 4          # (the one pair that differs in the last bits: 16x16x32 vs 32x32x16 MFMAs in the x3h convolution)
 SEL_GEMM_TAIL = 5             # 256-tile bf16 GEMM: tail tiles in the last round (bit-identical)
-SEL_CONV_S2_DMA = 6           # stride-2 x3h convolution: raw patch by LDS-DMA (bit-identical)
 # developer convenience: these environment variables are translated into vf_select calls ONCE, when the library is loaded (the library
 # itself reads no environment variable)
 _ENV_SELECT = {'VF_ATTN_DMA': SEL_ATTN_DMA, 'VF_GEMM_G256': SEL_GEMM_G256, 'VF_LN_BWD_TWO_ROWS': SEL_LN_BWD_TWO_ROWS, 'VF_ATTN_Q32': SEL_ATTN_Q32,
-               'VF_CONV_X3H_K32': SEL_CONV_X3H_K32, 'VF_GEMM_TAIL': SEL_GEMM_TAIL, 'VF_CONV_S2_DMA': SEL_CONV_S2_DMA}
+               'VF_CONV_X3H_K32': SEL_CONV_X3H_K32, 'VF_GEMM_TAIL': SEL_GEMM_TAIL}
 
 PACK_DESC_BYTES = 40          # vf_pack_desc (ops.pack_bf16_multi builds the table as a numpy record array of this item size)
 P = c_void_p

@@ -367,26 +367,17 @@ constexpr int S2_NPIX = S2_PH * S2_PW;                       // 561
 constexpr int S2_LDB = 80;                                   // 2 planes x 32 B + 16 B pad = 5 x 16 B
 constexpr int S2_SLOTS = (S2_NPIX * 4 + 255) / 256;          // float4 staging slots per thread (9)
 constexpr int S2_BUF = (S2_NPIX + 1) * S2_LDB;
-constexpr int S2_RAW = (S2_SLOTS - 1) * 4096 + ((S2_NPIX - 64 * (S2_SLOTS - 1) + 15) / 16) * 1024;      // landing area of the DMA form: [slot][wave][1 KB], last slot short
-#ifndef S2_DMA_TAP
-#define S2_DMA_TAP 4          // the tap behind whose weight loads the next chunk's raw patch is issued
-#endif
 
+// (Round 6, VERDICT r5 item 4, measured and removed — profiles/r6_conv_ab.txt: the stride-1 kernel's raw-patch staging ported here — the next chunk's raw
+// fp32 patch HBM -> LDS by DMA into a landing area behind the patch buffer (80.8 KB, two workgroups per CU still fit), issued at tap 4 behind that tap's
+// weight loads, each thread reading its own 16 bytes back when it parks the chunk; 36 VGPRs freed (220 instead of 256).  Bit-identical and 0.1 - 0.9 %
+// SLOWER at all three Downsample shapes (taps 2 / 4 / 6 alike): since round 2's "240 TF, waits on its patch loads" the weights-first issue order and the
+// skipped last staging had already brought the kernel to 299 - 341 TF.)
 // P8: the 16x16 -> 8x8 Downsample (the encoder's last): the 8x16 output tile is TWO images side by side (img, img1), each with its own
 // 17x17 input patch; a patch row is [even cols of A (9) | even cols of B (9) | odd cols of A (8) | odd cols of B (8)] = 34 pixels.
-//
-// DMA (round 6): the stride-1 kernel's raw-patch staging, ported.  The register form holds the NEXT chunk's raw patch in 36
-// VGPRs for a whole chunk and issues its loads at the chunk's start: every weight fragment issued behind them waits for HBM in the in-order
-// vmcnt queue (without the patch loads the kernel ran 354 instead of 240 TF: that wait was its bound).  Here the raw fp32 patch of the next
-// chunk travels HBM -> LDS by DMA (buffer_load ... lds, 16 B per lane: lane = (pixel, channel quad), the source address is per lane, the
-// landing area [slot][wave][lane] lane-linear behind the patch buffer: 561 x 64 B + 561 x 80 B = 80 784 B, two workgroups per CU still fit),
-// issued at tap 4 — behind the weights of taps 5 and 6, three taps before anything queued behind it is needed — and each thread reads its own
-// 16 bytes back when it parks the chunk.  Same split, same MFMA order: bit-identical to the register form (vf_select(VF_SEL_CONV_S2_DMA)).
-// The pair form (P8, 17 x 34 pixels: 83 KB with a landing area) keeps the register staging.
-template <bool P8, bool DMA>
+template <bool P8>
 __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
-    static_assert(!(P8 && DMA), "the pair form has no room for a landing area");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [S2_BUF] (+ [SLOTS][4 waves][1 KB] raw landing area)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [S2_BUF]
     constexpr int PW = P8 ? 34 : S2_PW;
     constexpr int NPIX = S2_PH * PW;
     constexpr int SLOTS = (NPIX * 4 + 255) / 256;
@@ -435,36 +426,19 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
         else slot = pr * PW + (pc & 1) * (TW + 1) + (pc >> 1);                // parity-major row
         s_lds[q] = (pix < NPIX ? slot : NPIX) * S2_LDB + c4 * 8;
     }
-    f32x4 preg[DMA ? 1 : SLOTS];
-    unsigned char* __restrict__ raw_l = smem_h + (size_t)(NPIX + 1) * S2_LDB;       // DMA: slot q of wave w at raw_l + q * 4096 + w * 1024 (last slot: waves 0 .. only)
-    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+    f32x4 preg[SLOTS];
     auto patch_load = [&](int chunk) {
-        if constexpr (DMA) {
 #pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                if (q == SLOTS - 1 && wave * 16 + 64 * q >= NPIX) continue;      // (a wave whose 16 pixels of the last slot are all past the patch: no landing KB)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (__attribute__((address_space(3))) void*)(raw_l + q * 4096 + wave * 1024), 16,
-                                                         (unsigned)s_off[q] * 4u, (unsigned)(chunk * 16 * 4), 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + chunk * 16 + s_off[q]);
-        }
+        for (int q = 0; q < SLOTS; ++q) preg[q] = *reinterpret_cast<const f32x4*>(X + chunk * 16 + s_off[q]);
     };
     auto patch_park = [&]() {
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            f32x4 raw = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (DMA) {
-                if (!(q == SLOTS - 1 && wave * 16 + 64 * q >= NPIX)) raw = *reinterpret_cast<const f32x4*>(raw_l + q * 4096 + tid * 16);
-            } else {
-                raw = preg[q];
-            }
             f16x4 oh, ol;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 _Float16 h, l;
-                split2(s_ok[q] ? raw[e] : 0.f, h, l);
+                split2(s_ok[q] ? preg[q][e] : 0.f, h, l);
                 oh[e] = h; ol[e] = l;
             }
             unsigned char* dst = smem_h + s_lds[q];
@@ -536,11 +510,8 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
     patch_load(0);
     b_load(bring[0], 0);
     if (S2_BR > 2) b_load(bring[1], 1);
-    auto chunk_body = [&](int chunk, auto last_chunk) {
-        constexpr bool LAST = decltype(last_chunk)::value;      // (DMA: the issue of the next chunk's pieces sits in straight-line code — a wave-uniform
-                                                                // branch around it would make hipcc's waitcnt pass too strict at the merge, see x3h16)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();                                        // every wave is done reading the previous chunk
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's raw pieces have landed (each thread reads back its own lane's bytes)
         patch_park();
         // vmcnt retires loads in issue order: a weight fragment issued AFTER the next chunk's patch loads (HBM latency) cannot be consumed
         // before they have landed.  So tap 2's fragments go out first — the patch then has until tap 3 instead of tap 2 (without the
@@ -551,17 +522,12 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
 #ifdef VF_X3H_X_NOPATCH
         if (chunk == 0)
 #endif
-        if constexpr (!DMA) {
-            if (!VF_X3H_SKIP_LAST || chunk + 1 < nchunks) patch_load(min(chunk + 1, nchunks - 1));
-        }
+        if (!VF_X3H_SKIP_LAST || chunk + 1 < nchunks) patch_load(min(chunk + 1, nchunks - 1));
         __syncthreads();
         a_load(aring[0], 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (!VF_X3H_S2_WFIRST || t > 0) b_load(bring[(t + S2_BR - 1) % S2_BR], chunk * 9 + t + S2_BR - 1);
-            if constexpr (DMA && !LAST) {
-                if (t == S2_DMA_TAP) patch_load(chunk + 1);     // (the landing area was last read by this chunk's park, two barriers ago)
-            }
             if (t + 1 < 9) a_load(aring[(t + 1) & 1], t + 1);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -577,12 +543,6 @@ __global__ __launch_bounds__(256, 2) void conv3_s2_x3h_kernel(vf_igemm_args p) {
                 for (int j = 0; j < NJ; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[t & 1][mi][0], bring[t % S2_BR][0][j], acc[mi][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    if constexpr (DMA) {
-        for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
-        chunk_body(nchunks - 1, std::true_type{});
-    } else {
-        for (int chunk = 0; chunk < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
     }
     const float inv_s = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.w_packed) + (size_t)(p.Cin / CK) * 9 * nb * TAP_BYTES);
 #pragma unroll
@@ -771,10 +731,10 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
     for (int q = 0; q < G::SLOTS; ++q) patch_store_slot(0, q);
     __syncthreads();
 
-    // one 32-channel chunk; P0 = chunk & 1 (nine taps: the weight ring's parity flips per chunk, so the chunk loop is unrolled by two)
     // (Round 6, VERDICT r5 item 5b, measured and removed — profiles/r6_conv_ab.txt: the residual tile of a ResnetBlock's conv2 pulled towards the CU by
     // LDS-DMA during the tile's LAST chunk, whose landing area is idle, so that the epilogue's 64 cold loads per lane hit L2: 0.5 - 0.8 % SLOWER
     // at every residual shape, bit-identical.  The tile's time is its energy: hiding a latency moves nothing, 64 KB more LDS writes cost.)
+    // one 32-channel chunk; P0 = chunk & 1 (nine taps: the weight ring's parity flips per chunk, so the chunk loop is unrolled by two)
     auto chunk_body = [&](int chunk, auto parity) {
         constexpr int P0 = decltype(parity)::value;
         const unsigned char* patch = smem_h + P0 * G::BUF;
@@ -977,6 +937,7 @@ int launch_halo16(const vf_igemm_args& a, hipStream_t stream) {
     hipLaunchKernelGGL((conv3_halo_x3h16_kernel<PRO, SWISH>), dim3((unsigned)blocks), dim3(256), smem, stream, a);
     return vf_last_status();
 }
+
 template <bool UP2, bool PAIR>
 int dispatch_pro(const vf_igemm_args& a, hipStream_t s) {
     // stride 1, whole 8 x 16 tiles, an even number of 32-channel chunks, GroupNorm groups of <= 16 channels: the 16x16x32 kernel
@@ -1028,22 +989,11 @@ int vf_conv3_halo_x3h(const vf_igemm_args* args, void* stream) {
         if (int st = vf_halo_gn_check(a)) return st;
         if (p8) {
             const long long blocks = (long long)((a.M / 64 + 1) / 2) * (a.Cout / BN);
-            hipLaunchKernelGGL((conv3_s2_x3h_kernel<true, false>), dim3((unsigned)blocks), dim3(256), (size_t)(S2_PH * 34 + 1) * S2_LDB, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(conv3_s2_x3h_kernel<true>, dim3((unsigned)blocks), dim3(256), (size_t)(S2_PH * 34 + 1) * S2_LDB, (hipStream_t)stream, a);
             return vf_last_status();
         }
         const long long blocks = (long long)(a.M / (a.Hout * a.Wout)) * (a.Hout / TH) * (a.Wout / TW) * (a.Cout / BN);
-        if (vf_selected(VF_SEL_CONV_S2_DMA) && (long long)a.Hin * a.Win * a.Cin < (1ll << 29)) {      // raw patch by LDS-DMA (bit-identical; 0: the register-staged form); 32-bit BYTE offsets per image
-            static_assert(S2_BUF + S2_RAW <= 80 * 1024, "two workgroups per CU");
-            static unsigned long long attr_devs = 0;
-            if (vf_attr_needed(&attr_devs)) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_s2_x3h_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2_BUF + S2_RAW);
-                if (e != hipSuccess) return (int)e;
-                vf_attr_done(&attr_devs);
-            }
-            hipLaunchKernelGGL((conv3_s2_x3h_kernel<false, true>), dim3((unsigned)blocks), dim3(256), (size_t)(S2_BUF + S2_RAW), (hipStream_t)stream, a);
-            return vf_last_status();
-        }
-        hipLaunchKernelGGL((conv3_s2_x3h_kernel<false, false>), dim3((unsigned)blocks), dim3(256), (size_t)S2_BUF, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv3_s2_x3h_kernel<false>, dim3((unsigned)blocks), dim3(256), (size_t)S2_BUF, (hipStream_t)stream, a);
         return vf_last_status();
     }
     if (a.mode != VF_MODE_CONV3_S1 && a.mode != VF_MODE_CONV3_UP2) return VF_ERR_UNSUPPORTED;
