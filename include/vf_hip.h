@@ -56,7 +56,7 @@ const char* vf_build_flag_name(int i);
  * q' = bf16(q scale log2 e) (the same S product bit for bit); the dK / dV kernel streams q un-rounded (dK = dS^T.Q needs it), so its P differs
  * from the forward's by that one rounding of q — |s| 2^-9 in the exponent; both stay inside the bound tests/test_train.py states at the score
  * magnitudes of a trained model (|s| <= 40: test_bf16_flash_attention_backward_at_trained_scale_scores).
- * Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}, all default to 1. */
+ * Process-wide, atomic; vf_select returns the previous value (or VF_ERR_BAD_ARG), value in {0, 1}; all default to 1 except VF_SEL_GEMM_TAIL (0). */
 enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA ring kernel where it applies, 0 = register-staged kernel (tolerance-level pair) */
        VF_SEL_GEMM_G256 = 1,         /* vf_gemm_bf16: 1 = 256-tile LDS-DMA kernel where it applies, 0 = 128-tile kernel */
        VF_SEL_LN_BWD_TWO_ROWS = 2,   /* vf_layernorm_bwd_f32: 1 = two rows of a wave in flight, 0 = one */
@@ -64,7 +64,8 @@ enum { VF_SEL_ATTN_DMA = 0,          /* vf_attn_blockcausal_bf16_v2: 1 = LDS-DMA
        VF_SEL_CONV_X3H_K32 = 4,      /* vf_conv3_halo_x3h, stride 1: 1 = the v_mfma_f32_16x16x32_f16 kernel where it applies, 0 = the 32x32x16 kernel.  The ONE
                                       * switch whose two sides differ in the last bits (another accumulation order; same fp32-equivalence bound) */
        VF_SEL_GEMM_TAIL = 5,         /* the 256-tile bf16 GEMM: 1 = launches whose last round of the 256 CUs would be a few tiles to 3/4 full end with ONE round of
-                                      * 192- / 128-row tail tiles instead (K is never split: bit-identical results), 0 = the plain grid (round 6) */
+                                      * 192- / 128-row tail tiles instead (K is never split: bit-identical results), 0 = the plain grid (the DEFAULT: the policy is
+                                      * 2-5 % faster on an isolated launch and nothing in the timed steps, round 6) */
        VF_SEL_COUNT = 6 };
 int vf_select(int which, int value);
 int vf_selected(int which);

@@ -81,9 +81,10 @@ def test_library_reads_no_environment_and_its_switches_are_explicit(lib):
         assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
     n = 6                                                                    # VF_SEL_COUNT (round 6: + VF_SEL_GEMM_TAIL, a bit-identical pair)
     for which in range(n):
-        assert lib.vf_selected(which) == 1                                   # defaults: the faster kernel of each pair
-        assert lib.vf_select(which, 0) == 1 and lib.vf_selected(which) == 0
-        assert lib.vf_select(which, 1) == 0 and lib.vf_selected(which) == 1
+        default = 0 if which == 5 else 1                                     # defaults: the faster kernel of each pair IN THE TIMED STEPS (the tail
+        assert lib.vf_selected(which) == default                             # policy wins only on isolated launches: off)
+        assert lib.vf_select(which, 1 - default) == default and lib.vf_selected(which) == 1 - default
+        assert lib.vf_select(which, default) == 1 - default and lib.vf_selected(which) == default
     assert lib.vf_select(n, 1) == -1 and lib.vf_select(-1, 1) == -1 and lib.vf_select(0, 2) == -1 and lib.vf_selected(n) == -1
 
 

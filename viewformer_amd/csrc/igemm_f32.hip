@@ -316,7 +316,7 @@ int vf_abi_version(void) { return 19; }
 // ---- kernel selection (include/vf_hip.h): process-wide switches between kernels whose results the tests assert BIT-IDENTICAL.  The library
 // reads no environment variable (tests/test_abi.py checks that it does not even import the libc call); a host that wants an environment override
 // translates it into vf_select calls (viewformer_amd/_lib.py does, once, at load).
-static int g_vf_select[VF_SEL_COUNT] = {1, 1, 1, 1, 1, 1};
+static int g_vf_select[VF_SEL_COUNT] = {1, 1, 1, 1, 1, 0};      // (VF_SEL_GEMM_TAIL: off — faster alone, not in the step: profiles/r6_gemm_tail_ab.txt)
 int vf_select(int which, int value) {
     if (which < 0 || which >= VF_SEL_COUNT || (value != 0 && value != 1)) return VF_ERR_BAD_ARG;
     return __atomic_exchange_n(&g_vf_select[which], value, __ATOMIC_RELAXED);
