@@ -400,32 +400,34 @@ __device__ __forceinline__ void g256_panel_order(unsigned lbid, int mt, int nb, 
 // followed by H = h_rows x nb tail tiles of 2 tail_ic x 32 rows that cover the remaining rows in ONE shorter round (a 192-row tile costs
 // ~3/4 of a full one: 3 of 4 row blocks per wave, 56 of 64 KB per stage).  Each XCD runs its full tiles first, then its tail tiles (ids are
 // XCD-contiguous within each kind: a kind's panel order and L2 reuse are those of a plain launch).  f_rows = 0: the plain grid.
-template <bool O16, bool DROP = false>
+// TAIL = false: the plain grid and nothing else in the kernel (the tail form's three tile bodies in ONE kernel cost the plain path 66 spilled
+// SGPRs and ~1 % — measured against round 5's kernel, profiles/r6_gemm_tail_ab.txt — so the two grids are two instantiations)
+template <bool O16, bool DROP = false, bool TAIL = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_g256_kernel(vf_igemm_args p, int f_rows, int h_rows, int tail_ic) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][GSTAGE]: A image, then W image
     const int tid = threadIdx.x;
     const int nb = p.Cout / GN;
     int mtile, nblk;
-    if (f_rows == 0) {
+    if constexpr (!TAIL) {
         // XCD-contiguous logical workgroup id (vf_common.h), walked in column panels
         g256_panel_order(vf_xcd_bid(), (p.M + GM - 1) / GM, nb, mtile, nblk);
         g256_tile<O16, DROP, 4>(p, smem_b, mtile * GM, nblk, tid);
-        return;
+    } else {
+        const unsigned F = (unsigned)(f_rows * nb), tot = gridDim.x;
+        const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        const unsigned nF = F / 8u + (x < (F & 7u) ? 1u : 0u);                          // this XCD's full tiles, then its tail tiles
+        const unsigned baseF = x * (F / 8u) + (x < (F & 7u) ? x : (F & 7u));
+        if (i < nF) {
+            g256_panel_order(baseF + i, f_rows, nb, mtile, nblk);
+            g256_tile<O16, DROP, 4>(p, smem_b, mtile * GM, nblk, tid);
+            return;
+        }
+        const unsigned baseT = x * (tot / 8u) + (x < (tot & 7u) ? x : (tot & 7u));
+        g256_panel_order(baseT - baseF + (i - nF), h_rows, nb, mtile, nblk);
+        const int m_tile0 = f_rows * GM + mtile * (tail_ic * 64);
+        if (tail_ic == 3) g256_tile<O16, DROP, 3>(p, smem_b, m_tile0, nblk, tid);
+        else g256_tile<O16, DROP, 2>(p, smem_b, m_tile0, nblk, tid);
     }
-    const unsigned F = (unsigned)(f_rows * nb), tot = gridDim.x;
-    const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-    const unsigned nF = F / 8u + (x < (F & 7u) ? 1u : 0u);                          // this XCD's full tiles, then its tail tiles
-    const unsigned baseF = x * (F / 8u) + (x < (F & 7u) ? x : (F & 7u));
-    if (i < nF) {
-        g256_panel_order(baseF + i, f_rows, nb, mtile, nblk);
-        g256_tile<O16, DROP, 4>(p, smem_b, mtile * GM, nblk, tid);
-        return;
-    }
-    const unsigned baseT = x * (tot / 8u) + (x < (tot & 7u) ? x : (tot & 7u));
-    g256_panel_order(baseT - baseF + (i - nF), h_rows, nb, mtile, nblk);
-    const int m_tile0 = f_rows * GM + mtile * (tail_ic * 64);
-    if (tail_ic == 3) g256_tile<O16, DROP, 3>(p, smem_b, m_tile0, nblk, tid);
-    else g256_tile<O16, DROP, 2>(p, smem_b, m_tile0, nblk, tid);
 }
 
 }  // namespace
@@ -467,19 +469,24 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
                                (((unsigned long long)a.M + (unsigned long long)a.drop_row0 + 3) / 4) * (unsigned long long)a.Cout >= (1ull << 32)))
         return VF_ERR_UNSUPPORTED;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.Cin * a.Cout * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-    static unsigned long long attr_devs = 0;      // bit d: raised on device d (the attribute is per device)
-    if (vf_attr_needed(&attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_g256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
-        if (e != hipSuccess) return (int)e;
-        vf_attr_done(&attr_devs);
-    }
     const int mt = (a.M + GM - 1) / GM, nb = a.Cout / GN;
     const G256Tail t = g256_tail_policy(a.M, nb);
     const dim3 g((unsigned)(t.f_rows ? (t.f_rows + t.h_rows) * nb : mt * nb));
-    if (o16) hipLaunchKernelGGL((gemm_bf16_g256_kernel<true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
-    else if (a.drop_rate > 0.f) hipLaunchKernelGGL((gemm_bf16_g256_kernel<false, true>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
-    else hipLaunchKernelGGL((gemm_bf16_g256_kernel<false>), g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
-    return vf_last_status();
+    auto launch = [&](auto kernel, unsigned long long* devs) -> int {
+        if (vf_attr_needed(devs)) {                // (per instantiation and device: > 64 KB of dynamic LDS)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GSTAGE);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(devs);
+        }
+        hipLaunchKernelGGL(kernel, g, dim3(512), (size_t)2 * GSTAGE, stream, a, t.f_rows, t.h_rows, t.ic);
+        return vf_last_status();
+    };
+    static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;      // bit d: raised on device d
+    const bool drop = a.drop_rate > 0.f;
+    if (t.f_rows) {
+        if (o16) return launch(gemm_bf16_g256_kernel<true, false, true>, &d3);
+        return drop ? launch(gemm_bf16_g256_kernel<false, true, true>, &d5) : launch(gemm_bf16_g256_kernel<false, false, true>, &d4);
+    }
+    if (o16) return launch(gemm_bf16_g256_kernel<true, false, false>, &d0);
+    return drop ? launch(gemm_bf16_g256_kernel<false, true, false>, &d2) : launch(gemm_bf16_g256_kernel<false, false, false>, &d1);
 }
