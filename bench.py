@@ -229,6 +229,9 @@ class OpTimer:
                         'traffic': (lambda t: None if t is None else {'bytes': t['bytes'], 'over_algorithmic': round(t['bytes'] / (by // len(self.attn)), 3),
                                                                       'source': t['source']})(
                             pmc_traffic('attn_dma_kernel', shape[1], 512, self.workload) if dma else None)},
+                'binding_roof_note': 'the north star prices this kernel against the MFMA peak; at 64 features per head and 64-token views its arithmetic intensity '
+                                     '(useful FLOP per byte of q, k, v, o) puts the HBM roof BELOW the matrix roof — see hbm.frac (algorithmic bytes) and '
+                                     'hbm.traffic (counter bytes incl. the re-read of key tiles by the second query block)',
                 'peak_note': ('non-scaled fp8 MFMA runs at the bf16 rate' if arm == 'fp8' else
                               'x6 executes 6 bf16 MFMA flops per fp32 flop: peak = 2500 / 6' if arm == 'x6' else '')}
 
