@@ -374,7 +374,15 @@ def run_train(args, rank, local, world, dev):
                        'weights': 'random-init MIGT 88.4M', 'loss': float(met['loss']), 'collective': comm},
             'roofline': {'bound': 'mfma', 'kernel': 'dense GEMM family of the step (gemm_bf16 / gemm_bf16_g256 / gemm_tn_bf16 or gemm_x3h / gemm_x6 launches: forward, dX, dW incl. its slab sums)',
                          'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                         'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': n,
+                         'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                         # HBM bytes of the family's largest launch shape (c_fc forward and its dX twin, 900 tiles: the same algorithmic bytes) from
+                         # this round's committed counter passes
+                         'traffic': (lambda t, alg: None if t is None else {
+                             'launch': '19 200 x 768 x 3072 with bf16 in / out (c_fc forward with its GELU-dual epilogue; mlp.c_proj dX with its GELU-backward epilogue)',
+                             'bytes': t['bytes'], 'algorithmic_bytes': alg, 'over_algorithmic': round(t['bytes'] / alg, 3), 'source': t['source']})(
+                             pmc_traffic('gemm_bf16_g256_kernelILb1ELb0E', (64 + 15) * 12 if _tail_on() else 900, 512, 'train')
+                             if (arm == 'bf16' and (B, S) == (10, 10)) else None, 19200 * 768 * 2 + 768 * 3072 * 2 + 2 * 19200 * 3072 * 2),
+                         'launches_per_step': n,
                          'kernel_ms_per_step': round(ms, 3), 'algorithmic_gflop_per_step': round(fl / 1e9, 1),
                          'timing': 'HIP events on the launch stream around every GEMM-family launch of ONE step run with the weight-gradient '
                                    'GEMMs serialised on the main stream (no concurrent kernel stretches a duration); the timed steps overlap '
