@@ -67,6 +67,8 @@ VARIANTS = {
     # hipcc then orders them behind the ring with its own `s_waitcnt vmcnt(0)` — the slow but compiler-ordered reference of
     # tests/test_hip_ring_stress.py, which compares the two builds' results bit for bit
     'trintrin': (['-DVF_X_TRINTRIN'], ['attention_dma', 'attention_train_bf16', 'gemm_tn_bf16']),
+    # A/B only (tools/ab_inprocess_*attn.py): the attention launches' owner blocks in index order instead of heaviest first
+    'attn_index_order': (['-DADMA_HEAVY_FIRST=0', '-DATB_HEAVY_FIRST=0'], ['attention_dma', 'attention_train_bf16']),
 }
 
 

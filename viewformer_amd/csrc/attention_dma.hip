@@ -69,6 +69,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_PSWAP
 #define ADMA_PSWAP 1
 #endif
+#ifndef ADMA_HEAVY_FIRST
+#define ADMA_HEAVY_FIRST 1  // query blocks dispatched heaviest first (round 6); 0 = in index order (round 5)
+#endif
 #ifndef ADMA_PAIRGRID
 #define ADMA_PAIRGRID 0     // the query blocks of a (scene, head) adjacent on one XCD (round 5 A/B; 0 = all first blocks, then all second blocks)
 #endif
@@ -129,7 +132,7 @@ template <bool DROP, int U>
 __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq,
     int ldk, int ldv, int ldo, float scale, int twin, float* __restrict__ lse_out, uint32_t drop_thresh, float drop_scale, uint32_t drop_seed,
-    uint32_t drop_site, uint32_t drop_plane0) {
+    uint32_t drop_site, uint32_t drop_plane0, vf_attn_order order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING x (K image | V image)
     constexpr int NW = 8 / U;                  // waves per workgroup
     constexpr int PW = 8 / NW;                 // 1 KB pieces of K (and of V) a wave moves per tile
@@ -140,8 +143,9 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    // grid (H, B, query blocks): all first blocks (4 key tiles), then all second blocks (8) — measured faster than interleaving the two
-    // kinds on a CU (145 us) although the second kind re-reads tiles 0-3 from HBM
+    // grid (H, B, query blocks): all blocks of one kind back to back — measured faster than interleaving two kinds on a CU (145 us) although the
+    // later kind re-reads key tiles from HBM — and, since round 6, the HEAVIEST kind first (order.blk: the launch no longer ends with a partly
+    // filled round of its longest workgroups)
 #if ADMA_PAIRGRID
     // the query blocks of one (scene, head) on ONE XCD, dispatched back to back (heavy block first): the light block's key tiles are then L2 hits
     int qblk = (int)blockIdx.z, h = (int)blockIdx.x;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         }
     }
 #else
-    const int qblk = (int)blockIdx.z;
+    const int qblk = (int)order.blk[blockIdx.z];           // heaviest query block first (vf_common.h: vf_attn_block_order)
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
 #endif
@@ -554,6 +558,9 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
     const uint32_t thr = vf_dropout_thresh(drop_rate);
     const float dsc = 1.0f / (1.0f - drop_rate);
+    const int nq = (T + QT - 1) / QT;
+    if (nq > 64) return VF_ERR_UNSUPPORTED;
+    const vf_attn_order order = vf_attn_block_order(T / KT, QT / KT, nq, twin_view, false, ADMA_HEAVY_FIRST != 0);
     auto launch = [&](auto drop, auto u) -> int {
         constexpr bool DROP = decltype(drop)::value;
         constexpr int U = decltype(u)::value;
@@ -564,7 +571,7 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
             vf_attr_done(&attr_devs);
         }
         hipLaunchKernelGGL((attn_dma_kernel<DROP, U>), grid, dim3(U == 2 ? 256 : 512), (size_t)RING * TILE_BYTES, stream, q_, k_, v_, o_, H, T, ldq, ldk, ldv, ldo,
-                           scale, twin_view, lse_out, thr, dsc, drop_seed, drop_site, drop_plane0);
+                           scale, twin_view, lse_out, thr, dsc, drop_seed, drop_site, drop_plane0, order);
         return vf_last_status();
     };
     using D1 = std::true_type;

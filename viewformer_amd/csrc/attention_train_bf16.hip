@@ -38,6 +38,9 @@ constexpr int DH = 64, KT = 64;
 constexpr int IMG = KT * DH * 2;             // one 64 x 64 bf16 image: 8 KB
 constexpr int OT = 128;                      // owner rows per workgroup: 4 waves x 32
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ATB_HEAVY_FIRST
+#define ATB_HEAVY_FIRST 1   // owner blocks dispatched heaviest first (round 6, vf_common.h: vf_attn_block_order); 0 = in index order
+#endif
 // FOLD (round 6, dQ kernel; ADVICE r5 + VERDICT r5 item 2).  The forward kernel (attention_dma.hip) multiplies q by scale * log2 e and re-rounds
 // it to bf16 before its S product; until round 6 the backward re-materialised P from the UN-rounded q — an exponent off by |s| 2^-9, which
 // at the score magnitudes of a trained model (MIGT's scores are unscaled) is several per cent of P.  The dQ kernel holds q as its
@@ -183,13 +186,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
                                                                   const float* __restrict__ lse, const float* __restrict__ Dv,
                                                                   void* __restrict__ dq, int H, int T, int ldq, int ldk, int ldv, int lddo,
                                                                   int lddq, float scale, int twin, uint32_t drop_thresh, float drop_scale,
-                                                                  uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0) {
+                                                                  uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, vf_attn_order order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
-    const int q0 = blockIdx.z * OT;
+    const int q0 = (int)order.blk[blockIdx.z] * OT;                  // heaviest owner block first (vf_common.h: vf_attn_block_order)
     const int qw0 = q0 + wave * 32;
     const int nviews = T / KT;
     const int qview = qw0 / KT;
@@ -348,13 +351,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
                                                                    void* __restrict__ dk, void* __restrict__ dv, int H, int T, int ldq, int ldk,
                                                                    int ldv, int lddo, int lddk, int lddv, float scale, int twin,
                                                                    uint32_t drop_thresh, float drop_scale, uint32_t drop_seed, uint32_t drop_site,
-                                                                   uint32_t drop_plane0) {
+                                                                   uint32_t drop_plane0, vf_attn_order order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
-    const int k0 = blockIdx.z * OT;
+    const int k0 = (int)order.blk[blockIdx.z] * OT;
     const int kw0 = k0 + wave * 32;
     const int nviews = T / KT;
     const int kview = kw0 / KT;
@@ -535,7 +538,11 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
     const size_t ldmax = (size_t)(ldq > ldk ? ldq : ldk) > (size_t)(ldv > lddo ? ldv : lddo) ? (size_t)(ldq > ldk ? ldq : ldk) : (size_t)(ldv > lddo ? ldv : lddo);
     if ((size_t)T * ldmax * 2 >= (1ull << 31)) return VF_ERR_UNSUPPORTED;                     // 32-bit buffer offsets per (scene, head)
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + OT - 1) / OT));
+    const int nblk = (T + OT - 1) / OT;
+    if (nblk > 64) return VF_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)H, (unsigned)B, (unsigned)nblk);
+    const vf_attn_order ord_q = vf_attn_block_order(T / KT, OT / KT, nblk, twin_view, false, ATB_HEAVY_FIRST != 0);
+    const vf_attn_order ord_k = vf_attn_block_order(T / KT, OT / KT, nblk, twin_view, true, ATB_HEAVY_FIRST != 0);
     const __bf16 *q_ = reinterpret_cast<const __bf16*>(q), *k_ = reinterpret_cast<const __bf16*>(k), *v_ = reinterpret_cast<const __bf16*>(v),
                  *do_ = reinterpret_cast<const __bf16*>(dout);
     const uint32_t thr = vf_dropout_thresh(drop_rate);
@@ -550,11 +557,11 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
             vf_attr_done(&attr_devs);
         }
         hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
-                           ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
+                           ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_q);
         const int st = vf_last_status();
         if (st) return st;
         hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
-                           ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0);
+                           ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_k);
         return vf_last_status();
     };
     using T_ = std::true_type;

@@ -287,6 +287,48 @@ VF_REG_FLAG(VF_X_TRINTRIN)
 int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long long sk, long long sn, long long st,
                    int BN, int batch, long long src_bstride, hipStream_t stream);
 
+// ---- heaviest-first order of an attention launch's owner blocks (round 6) -------------------------------------------------------------------
+// Under the block-causal / twin / streams masks the owner blocks of a (scene, head) differ in work by up to 10 x (a query block walks 4 .. 21 key
+// tiles at configs[2], a key block of the training step's stream 0 is seen by 28 query tiles, most others by 2), and the grid's last dimension is
+// dispatched in index order: with the light blocks first the launch ends with a partly filled round of its HEAVIEST workgroups (configs[2]: 100
+// step-units on 512 workgroup slots against 88 heaviest-first, 84 ideal; the training forward 23 vs 20, its dQ 29 vs 25).  The launchers
+// therefore hand the kernels a permutation: blockIdx.z = r runs the block with the r-th largest number of visible tiles (ties: lower index first).
+// Every workgroup computes what it computed before — results are bit-identical; only the dispatch order changes.
+struct vf_attn_order { unsigned char blk[64]; };
+static inline bool vf_attn_visible(int qv, int kv, int twin) {           // the kernels' visible(): plain / twin (Vc = twin >= 0) / streams (Sv = -twin >= 2)
+    if (twin <= -2) {
+        const int Sv = -twin, qs = qv / Sv, qi = qv - qs * Sv, ks = kv / Sv, ki = kv - ks * Sv;
+        return qs == 0 ? (ks == 0 && ki <= qi) : ((ks == 0 && ki < qi) || kv == qv);
+    }
+    const int Vc = twin >= 0 ? twin : 0x3fffffff;
+    return kv == qv || (kv < Vc ? kv : Vc) < (qv < Vc ? qv : Vc);
+}
+// nblocks owner blocks of `vpb` views each over nviews views; by_key: the owners are KEY views (weight = query tiles that see one of them),
+// otherwise QUERY views (weight = key tiles one of them sees).  heaviest_first = false: the identity
+static inline vf_attn_order vf_attn_block_order(int nviews, int vpb, int nblocks, int twin, bool by_key, bool heaviest_first) {
+    vf_attn_order o;
+    int w[64];
+    if (nblocks > 64) nblocks = 64;
+    for (int b = 0; b < 64; ++b) o.blk[b] = (unsigned char)b;
+    if (!heaviest_first) return o;
+    for (int b = 0; b < nblocks; ++b) {
+        int cnt = 0;
+        for (int t = 0; t < nviews; ++t) {
+            bool any = false;
+            for (int v = b * vpb; v < (b + 1) * vpb && v < nviews && !any; ++v) any = by_key ? vf_attn_visible(t, v, twin) : vf_attn_visible(v, t, twin);
+            cnt += any;
+        }
+        w[b] = cnt;
+    }
+    for (int i = 1; i < nblocks; ++i) {                                  // stable insertion sort, descending weight
+        const unsigned char bi = o.blk[i];
+        int j = i - 1;
+        while (j >= 0 && w[o.blk[j]] < w[bi]) { o.blk[j + 1] = o.blk[j]; --j; }
+        o.blk[j + 1] = bi;
+    }
+    return o;
+}
+
 // ---- ds_read_b64_tr_b16 behind inline asm (round 5) ---------------------------------------------------------------------------------
 // hipcc's waitcnt pass cannot prove that an LDS read issued through the transposing-read INTRINSIC (__builtin_amdgcn_ds_read_tr16_b64)
 // is independent of a pending LDS-DMA (buffer_load ... lds): in front of the first such read after a DMA issue it inserts
@@ -297,6 +339,14 @@ int vf_pack_b_impl(const float* src, float* dst, int K, int N, int taps, long lo
 // reads are issued as inline asm, which the pass does not look into: the asm block carries its own `s_waitcnt lgkmcnt(0)`, i.e. its
 // outputs are valid when it ends (it also waits for any LDS read the compiler still has in flight: harmless).  Same instructions, same
 // data, same arithmetic: bit-identical results.  `off*` must fold to immediates (unrolled loop indices do under -O3).
+// INVARIANTS the callers keep, because the compiler no longer orders these reads against the ring:
+//   * a ring slot is read only behind the issuing waves' COUNTED `s_waitcnt vmcnt(N)` for it plus the `s_barrier` at the top of the ring step; N counts
+//     LDS-DMA pieces only — no other vector-memory operation may be added inside a ring loop without re-deriving every N of that loop
+//     (tools/isa_vmcnt_audit.py lists the loop's VMEM instructions and waits; tests/test_isa_audit.py runs it);
+//   * offsets are DS immediates: offA / offB (+ gap) must stay below 65 536 — the assembler REJECTS a larger `offset:` (hipcc fails the build, probed in
+//     round 6), so the bound needs no static_assert of its own; today's maximum is ~32 KB;
+//   * results are compared with a build that issues the same reads through the intrinsic (-DVF_X_TRINTRIN: compiler-ordered, slower), output for output,
+//     under memory noise: tests/test_hip_ring_stress.py (viewformer_amd.build.build_variant('trintrin')).
 typedef __bf16 vf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short vf_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned vf_lds_addr(const void* p) {          // byte address inside the workgroup's LDS allocation
