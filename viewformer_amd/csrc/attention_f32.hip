@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256, 2) void attn_blockcausal_kernel(const float* _
     // whenever H * B % 8 == 0, and share its L2 copy of that head's K / V (consecutive ids go round-robin over the 8 XCDs)
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
-    const int q0 = blockIdx.z * QT;
+    // query blocks heaviest first (round 6): under the plain / twin masks a later block sees more key tiles, and a launch that dispatches the light
+    // blocks first ends on a partly filled round of its longest workgroups (attention_dma.hip; the streams mask is not monotone: index order there)
+    const int q0 = (int)(twin > -2 ? gridDim.z - 1 - blockIdx.z : blockIdx.z) * QT;
 
     const float* qb = q + b * (size_t)T * ldq + h * DH;
     const float* kb = k + b * (size_t)T * ldk + h * DH;

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256, 2) void attn_lp_kernel(const float* __restrict
     // grid (H, B, query tiles): the query tiles of one (scene, head) sit H*B ids apart = on one XCD whenever H*B % 8 == 0
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
-    const int q0 = blockIdx.z * QT;
+    // query blocks heaviest first (round 6): under the plain / twin masks a later block sees more key tiles, and a launch that dispatches the light
+    // blocks first ends on a partly filled round of its longest workgroups (attention_dma.hip; the streams mask is not monotone: index order there)
+    const int q0 = (int)(twin > -2 ? gridDim.z - 1 - blockIdx.z : blockIdx.z) * QT;
     const int qw0 = q0 + wave * QW;                      // this wave's first query
 
     const float* qf = q + b * (size_t)T * ldq + h * DH;
