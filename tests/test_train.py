@@ -827,6 +827,27 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
     assert torch.equal(got, got2)
 
 
+@pytest.mark.gpu
+def test_one_launch_repack_equals_the_per_tensor_packings(dev):
+    """vf_gemm_bf16_pack_multi (the training step's one-launch refresh of every layer's W and W^T packing; round 6: one thread per packed 16-byte
+    group, coalesced loads — 211 instead of 321 us for the step's table) against vf_gemm_bf16_pack, bit for bit: the transformer's four layer
+    shapes, both orientations, and shapes that end inside a 64-deep chunk / a 128-wide block (zero padding)."""
+    from viewformer_amd import ops
+    g = np.random.Generator(np.random.PCG64(5))
+    items, refs = [], []
+    for r, c in ((768, 2304), (768, 768), (768, 3072), (3072, 768), (1026, 768), (200, 136), (64, 128)):
+        w = torch.from_numpy(g.standard_normal((r, c)).astype(np.float32)).to(dev)
+        for tr in (False, True):
+            ref = ops.pack_dense_nk_bf16(w) if tr else ops.pack_dense_kn_bf16(w)
+            items.append((w, tr, torch.full_like(ref, float('nan'))))
+            refs.append(ref)
+    run = ops.pack_bf16_multi(items)
+    run()                                                        # (the closure re-runs the same launch: the step's refresh)
+    torch.cuda.synchronize()
+    for (w, tr, out), ref in zip(items, refs):
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (tuple(w.shape), tr)
+
+
 ATTN_BF16_BWD_TOL_PEAKED = 6e-2      # the same bound at score magnitudes of a trained model (measured: see profiles/r6_attention_diet.txt)
 
 

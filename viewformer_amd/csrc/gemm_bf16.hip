@@ -529,22 +529,41 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 __global__ void pack_bf16_multi_kernel(const vf_pack_desc* __restrict__ descs) {
     const vf_pack_desc d = descs[blockIdx.y];
     const int nb = (d.N + BN - 1) / BN, nchunks = (d.K + CK - 1) / CK;
-    const long long total = (long long)nchunks * nb * CK * BN;
+    // one thread = the 8 consecutive k of one packed 16-byte group (round 6: the element-per-thread form read 8 different k rows from 8 neighbouring
+    // threads — 32-byte segments, 1.6 TB/s for the step's 88 M weights): neighbouring threads are neighbouring n, so for the [K][N] source (sn == 1)
+    // each of the 8 loads is one contiguous 256-byte run per wave; for the [N][K] source (sk == 1) a thread's 8 values are two 16-byte loads
+    const long long groups = (long long)nchunks * nb * (CK * BN / 8);
     __bf16* __restrict__ dst = reinterpret_cast<__bf16*>(d.dst);
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 7);
-        long long t = idx >> 3;
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    for (long long gi = blockIdx.x * (long long)blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+        long long t = gi;
         const int nl = (int)(t % BN); t /= BN;
         const int half = (int)(t & 1);
         const int ks = (int)((t >> 1) & 3);
         t >>= 3;
         const int nblk = (int)(t % nb);
         const int chunk = (int)(t / nb);
-        const int k = chunk * CK + ks * 16 + half * 8 + e;
+        const int k0 = chunk * CK + ks * 16 + half * 8;
         const int n = nblk * BN + nl;
-        float v = 0.f;
-        if (k < d.K && n < d.N) v = d.src[k * d.sk + n * d.sn];
-        dst[idx] = (__bf16)v;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (n < d.N) {
+            const float* sp = d.src + (long long)k0 * d.sk + (long long)n * d.sn;
+            if (d.sk == 1 && k0 + 8 <= d.K && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0)) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e < d.K) v[e] = sp[(long long)e * d.sk];
+            }
+        }
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x8_t*>(dst + gi * 8) = o;
     }
 }
 
