@@ -529,6 +529,15 @@ int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dw
                      int vocab, void* workspace, void* stream);
 /* weight/bias gradient of vf_dense_small_k_gelu_f32's linear part: dW[k][n] += sum_r x[r][k]*dy[r][n], db[n] += sum_r dy */
 int vf_dense_small_k_bwd_f32(const float* x, const float* dy, float* dW, float* db, int64_t rows, int K, int N, void* stream);
+/* The other tiny dimension (round 6): a dense layer with N <= 8 OUTPUTS — the pose head's c_proj, 1536 -> 7 (viewformer/models/migt.py:291-292,354:
+ * MLP(n_state, n_embd = 7) inside QuaternionPoseRepresentation) — as one pass over x at HBM rate, and its weight gradient dW = x^T dy
+ * (autograd of Conv1D.call, migt.py:89-96, under train_step :464-505).  out[r][n] = sum_k x[r][k] W[k][n] + b[n] (b may be NULL); K % 4 == 0,
+ * K <= 4096, ldx % 4 == 0, x 16-byte aligned.  The gradient writes vf_dense_small_n_wgrad_slabs(rows) slab partial sums of K x N floats into `ws`
+ * and folds them in slab order (deterministic); K <= 2048; accumulate != 0: dW += . */
+int vf_dense_small_n_f32(const float* x, const float* W, const float* b, float* out, int64_t rows, int K, int N, int64_t ldx, void* stream);
+int vf_dense_small_n_wgrad_slabs(int64_t rows);
+int vf_dense_small_n_wgrad_f32(const float* x, const float* dy, float* dW, float* ws, int64_t rows, int K, int N, int64_t ldx, int accumulate,
+                               void* stream);
 /* AdamWeightDecay step (viewformer/models/utils.py:507-537 on Keras Adam): p -= lr_decay*p; m,v update;
  * p -= lr_adam * m / (sqrt(v) + eps)   with lr_adam = lr*sqrt(1-b2^t)/(1-b1^t), lr_decay = lr*weight_decay or 0 */
 int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_decay, float lr_adam, float beta1,

@@ -828,6 +828,75 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('rows,K,N', [(6400, 1536, 7), (130, 1536, 7), (64, 256, 8), (1000, 768, 3), (1, 4, 1)])
+def test_small_n_dense_layer_and_its_weight_gradient(dev, rows, K, N):
+    """round 6: the pose head's 1536 -> 7 layer (migt.py:291-292,354) and its dW on one-pass kernels (csrc/train_ops.hip: dense_small_n*) against
+    fp64; deterministic (slab partials folded in slab order); accumulate adds; the trainer's two paths (small_n_pose_head on / off) give the same
+    step within fp32 rounding (test_small_n_pose_head_matches_the_implicit_gemm_path below)."""
+    from viewformer_amd import train_ops as T
+    g = np.random.Generator(np.random.PCG64(61))
+    x = torch.from_numpy(g.standard_normal((rows, K)).astype(np.float32)).to(dev)
+    W = torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(g.standard_normal(N).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(g.standard_normal((rows, N)).astype(np.float32)).to(dev)
+    assert T.dense_small_n_supported(K, N)
+    out = T.dense_small_n(x, W, b, rows, K, N)
+    ref = x.double() @ W.double() + b.double()
+    mag = x.double().abs() @ W.double().abs() + b.double().abs()
+    assert float(((out.double() - ref).abs() / mag).max()) < 2e-6
+    assert torch.equal(out, T.dense_small_n(x, W, b, rows, K, N))
+    assert torch.equal(T.dense_small_n(x, W, None, rows, K, N), T.dense_small_n(x, W, torch.zeros_like(b), rows, K, N))
+    dW = torch.full((K, N), float('nan'), device=dev)
+    T.dense_small_n_wgrad(x, dy, dW, rows, K, N, accumulate=False)
+    refw = x.double().T @ dy.double()
+    magw = x.double().abs().T @ dy.double().abs()
+    assert float(((dW.double() - refw).abs() / magw.clamp_min(1e-30)).max()) < 4e-6
+    dW2 = dW.clone()
+    T.dense_small_n_wgrad(x, dy, dW2, rows, K, N, accumulate=True)
+    assert torch.allclose(dW2, 2 * dW, rtol=1e-5, atol=1e-5 * float(dW.abs().max()))      # (dst + fold(slabs): one more rounding per element)
+    dW3 = torch.empty_like(dW)
+    T.dense_small_n_wgrad(x, dy, dW3, rows, K, N, accumulate=False)
+    assert torch.equal(dW3, dW)                                     # deterministic
+    # a strided x (a column slice of a wider activation): ldx > K
+    if K >= 256:
+        wide = torch.cat([x, x.flip(1)], 1)
+        assert torch.equal(T.dense_small_n(wide[:, :K], W, b, rows, K, N), out)
+
+
+@pytest.mark.gpu
+def test_small_n_pose_head_matches_the_implicit_gemm_path(dev):
+    """the training step with the pose head's 1536 -> 7 layer on the small-N kernels (default) and on the implicit-GEMM kernel (round 5): same loss,
+    same gradients within fp32 summation-order noise — incl. the pose head's own weight and bias gradients"""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch
+    from oracle import migt_oracle as mg
+    cfg = MIGTConfig(n_layer=2, d_model=256, n_head=4, sequence_size=4, n_loss_skip=1, localization_weight='2', pose_multiplier=0.2, dropout=0.0,
+                     learning_rate=1e-3, weight_decay=0.05, total_steps=50)
+    sd = make_migt_weights(cfg, seed=4)
+    g = np.random.Generator(np.random.PCG64(12))
+    B, S = 2, 4
+    tokens = torch.from_numpy(g.integers(0, cfg.n_embeddings, size=(B, S, 8, 8)))
+    _, cams = synthetic_scene_batch(B, S, 8, 6)
+    poses = mg.normalize_cameras(mg.to_relative_cameras(torch.from_numpy(cams))[0])
+    res = {}
+    for small in (True, False):
+        tr = MIGTTrainer(MIGT(cfg).load_state_dict(sd).to(dev), warmup_steps=4)
+        tr.small_n_pose_head = small
+        m = tr.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+        res[small] = (float(m['loss']), tr.flat_g.clone(), tr)
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1.0, abs(res[False][0]))
+    tr = res[True][2]
+    for n in tr.names:
+        a, b, _ = tr.slices[n]
+        ref = res[False][1][a:b]
+        if float(ref.abs().max()) > 0:
+            e = ((res[True][1][a:b] - ref).abs().max() / ref.abs().max()).item()
+            assert e < 2e-5, (n, e)
+
+
+@pytest.mark.gpu
 def test_one_launch_repack_equals_the_per_tensor_packings(dev):
     """vf_gemm_bf16_pack_multi (the training step's one-launch refresh of every layer's W and W^T packing; round 6: one thread per packed 16-byte
     group, coalesced loads — 211 instead of 321 us for the step's table) against vf_gemm_bf16_pack, bit for bit: the transformer's four layer

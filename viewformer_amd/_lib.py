@@ -161,6 +161,9 @@ EXPORTS = {
     'vf_embed_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vf_embed_bwd_f32': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, P, P]),
     'vf_dense_small_k_bwd_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    'vf_dense_small_n_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int64, P]),
+    'vf_dense_small_n_wgrad_slabs': (c_int, [c_int64]),
+    'vf_dense_small_n_wgrad_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int64, c_int, P]),
     'vf_adamw_f32': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     'vf_adamw_flat_f32': (c_int, [P, P, P, P, c_int64, P, c_int, c_float, c_float, c_float, c_float, c_float, P]),
     'vf_axpby_f32': (c_int, [c_float, P, c_float, P, P, c_int64, P]),

@@ -615,6 +615,87 @@ __global__ void scale_gradnorm_kernel(float* __restrict__ x, const float* __rest
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
 }
 
+
+// ---- tiny-N dense layer and its weight gradient (round 6): the pose head's c_proj is 1536 -> 7 (migt.py:291-292,354; QuaternionPoseRepresentation).  On the
+// implicit-GEMM kernel (N padded to a 32-column tile, 50 workgroups for 6 400 rows) the forward and the dW = X^T dY each took 176 us of a 20 ms training
+// step — for 0.14 GFLOP and 39 MB.  Both are one pass over X at HBM rate:
+//   forward: one wave per row, lanes stride the K axis in float4 steps, W^T staged in LDS [n][K], N <= 8 accumulators per lane, DPP wave sums;
+//   dW: a workgroup owns a slab of rows and every k (threads stride K), dY's row is a broadcast, N <= 8 accumulators per owned k; slab partials
+//       are folded by vf_sum_slabs_f32 in slab order (deterministic).
+constexpr int SN_MAX = 8;
+__global__ __launch_bounds__(256) void dense_small_n_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                            float* __restrict__ out, long long rows, int K, int N, long long ldx) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];          // [SN_MAX][K]: W transposed (zero rows beyond N)
+    for (int i = threadIdx.x; i < SN_MAX * K; i += 256) {
+        const int n = i / K, k = i - n * K;
+        wt[i] = n < N ? W[(size_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k4 = K >> 2;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const f32x4* __restrict__ xr = reinterpret_cast<const f32x4*>(x + r * ldx);
+        float acc[SN_MAX];
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
+        for (int c = lane; c < k4; c += 64) {
+            const f32x4 xv = xr[c];
+#pragma unroll
+            for (int n = 0; n < SN_MAX; ++n) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + n * K + 4 * c);
+                acc[n] = __builtin_fmaf(xv[0], wv[0], __builtin_fmaf(xv[1], wv[1], __builtin_fmaf(xv[2], wv[2], __builtin_fmaf(xv[3], wv[3], acc[n]))));
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n) acc[n] = vf_wave_sum_dpp(acc[n]);
+        if (lane == 0) {
+            for (int n = 0; n < N; ++n) out[r * N + n] = acc[n] + (b ? b[n] : 0.f);
+        }
+    }
+}
+
+// slab[blockIdx.x][k][n] = sum over the slab's rows of x[m][k] * dy[m][n]; thread t owns k = t, t + 256, ...
+template <int KPT>
+__global__ __launch_bounds__(256) void dense_small_n_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+                                                                  long long rows, int K, int N, long long ldx, int rows_per_slab) {
+    __shared__ float dys[64][SN_MAX];
+    const long long m0 = (long long)blockIdx.x * rows_per_slab;
+    const long long m1 = m0 + rows_per_slab < rows ? m0 + rows_per_slab : rows;
+    float acc[KPT][SN_MAX];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n) acc[i][n] = 0.f;
+    for (long long mb = m0; mb < m1; mb += 64) {
+        const int nr = (int)(m1 - mb < 64 ? m1 - mb : 64);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * SN_MAX; i += 256) {
+            const int r = i / SN_MAX, n = i - r * SN_MAX;
+            dys[r][n] = (r < nr && n < N) ? dy[(mb + r) * N + n] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const float* __restrict__ xr = x + (mb + r) * ldx;
+            float xv[KPT];
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) { const int k = threadIdx.x + 256 * i; xv[i] = k < K ? xr[k] : 0.f; }
+#pragma unroll
+            for (int n = 0; n < SN_MAX; ++n) {
+                const float d = dys[r][n];
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) acc[i][n] = __builtin_fmaf(xv[i], d, acc[i][n]);
+            }
+        }
+    }
+    float* __restrict__ o = slabs + (size_t)blockIdx.x * K * N;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int k = threadIdx.x + 256 * i;
+        if (k < K)
+            for (int n = 0; n < N; ++n) o[(size_t)k * N + n] = acc[i][n];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -867,6 +948,49 @@ int vf_clip_grad_norm_f32(float* x, int64_t n, float max_norm, float* scratch1, 
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid1(n, 256, 1024)), dim3(256), 0, s, x, scratch1, (long long)n);
     hipLaunchKernelGGL(scale_gradnorm_kernel, dim3(grid1(n, 256, 8192)), dim3(256), 0, s, x, scratch1, max_norm, (long long)n);
     return vf_last_status();
+}
+
+
+/* out[r][n] = sum_k x[r][k] W[k][n] + b[n] for a tiny N (<= 8; the pose head's 1536 -> 7): one pass over x at HBM rate.  K % 4 == 0, K <= 4096,
+ * ldx % 4 == 0, 16-byte aligned x */
+int vf_dense_small_n_f32(const float* x, const float* W, const float* b, float* out, int64_t rows, int K, int N, int64_t ldx, void* stream) {
+    if (!x || !W || !out || rows < 0 || K <= 0 || N <= 0 || ldx < K) return VF_ERR_BAD_ARG;
+    if (N > SN_MAX || (K & 3) || K > 4096 || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return VF_ERR_UNSUPPORTED;
+    if (rows == 0) return VF_OK;
+    const size_t smem = (size_t)SN_MAX * K * sizeof(float);
+    static unsigned long long attr_devs = 0;
+    if (smem > 64 * 1024 && vf_attr_needed(&attr_devs)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_small_n_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return (int)e;
+        vf_attr_done(&attr_devs);
+    }
+    const long long wgs = (rows + 3) / 4;
+    hipLaunchKernelGGL(dense_small_n_kernel, dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(256), smem, (hipStream_t)stream, x, W, b, out, (long long)rows, K,
+                       N, (long long)ldx);
+    return vf_last_status();
+}
+
+/* number of slabs (and the rows per slab) vf_dense_small_n_wgrad_f32 writes for `rows` rows: the caller provides slabs * K * N floats of workspace */
+int vf_dense_small_n_wgrad_slabs(int64_t rows) {
+    if (rows <= 0) return 0;
+    const long long per = rows >= 256 * 32 ? 32 : 16;                 /* >= 200 workgroups at the step's 6 400 rows */
+    return (int)((rows + per - 1) / per);
+}
+
+/* dW[k][n] (+)= sum_r x[r][k] dy[r][n] for a tiny N (<= 8), K <= 2048: slab partial sums (workspace), folded in slab order */
+int vf_dense_small_n_wgrad_f32(const float* x, const float* dy, float* dW, float* ws, int64_t rows, int K, int N, int64_t ldx, int accumulate,
+                               void* stream) {
+    if (!x || !dy || !dW || !ws || rows <= 0 || K <= 0 || N <= 0 || ldx < K) return VF_ERR_BAD_ARG;
+    if (N > SN_MAX || K > 2048) return VF_ERR_UNSUPPORTED;
+    const int slabs = vf_dense_small_n_wgrad_slabs(rows);
+    const int per = (int)((rows + slabs - 1) / slabs);
+    hipStream_t s = (hipStream_t)stream;
+    const int kpt = (K + 255) / 256;
+    if (kpt <= 2) hipLaunchKernelGGL(dense_small_n_wgrad_kernel<2>, dim3(slabs), dim3(256), 0, s, x, dy, ws, (long long)rows, K, N, (long long)ldx, per);
+    else if (kpt <= 4) hipLaunchKernelGGL(dense_small_n_wgrad_kernel<4>, dim3(slabs), dim3(256), 0, s, x, dy, ws, (long long)rows, K, N, (long long)ldx, per);
+    else hipLaunchKernelGGL(dense_small_n_wgrad_kernel<8>, dim3(slabs), dim3(256), 0, s, x, dy, ws, (long long)rows, K, N, (long long)ldx, per);
+    if (int st = vf_last_status()) return st;
+    return vf_sum_slabs_f32(ws, slabs, (int64_t)K * N, (int64_t)K * N, dW, accumulate, stream);
 }
 
 }  // extern "C"

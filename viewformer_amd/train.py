@@ -416,6 +416,7 @@ class MIGTTrainer:
                                       # layers' backward GEMMs, which then run on the 256-tile kernel (the rounding is the one the GEMM's operand
                                       # load applied anyway; only the two bias gradients see it)
 
+    small_n_pose_head = True          # the pose head's 1536 -> 7 layer and its dW on the one-pass small-N kernels (False: the implicit-GEMM kernel, round 5)
     bf16_lm_head = True               # bf16 arm: the tied LM head (logits, dH, dwte) on the bf16 pipe like every other wide layer (the native-f32
                                       # GEMMs it replaces were 0.8 ms of a 21 ms step); False: native f32 MFMA
     _lm16 = None
@@ -634,7 +635,12 @@ class MIGTTrainer:
             hloc = hf[:, 2].contiguous().view(M1, d)
             up = self._linear(hloc, 'pose_criterion.pose_classifier.c_fc', M1)
             p1 = T.gelu(up)
-            raw = self._linear(p1, 'pose_criterion.pose_classifier.c_proj', M1)
+            dn_p = m._dense['pose_criterion.pose_classifier.c_proj']
+            small_n = self.small_n_pose_head and T.dense_small_n_supported(dn_p.k, dn_p.n) and p1.dtype == torch.float32 and p1.is_contiguous()
+            if small_n:          # 1536 -> 7: one pass over p1 instead of an implicit GEMM on a 32-column tile (176 -> ~15 us, round 6)
+                raw = T.dense_small_n(p1, dn_p.w_raw, dn_p.bias, M1, dn_p.k, dn_p.n)
+            else:
+                raw = self._linear(p1, 'pose_criterion.pose_classifier.c_proj', M1)
             dyn = c.use_dynamic_pose_loss
             if dyn:                                                                  # DynamicLossWeightingCriterion, migt.py:107-120
                 sw = self.p(DYN_KEY)
@@ -688,9 +694,12 @@ class MIGTTrainer:
             name = 'pose_criterion.pose_classifier.c_proj'
             dn = m._dense[name]
             T.colsum(draw, self.g(name + '.bias'), M1, 7, accumulate=True)
-            p1t = T.transpose(p1, M1, dn.k)
-            drp = ops.pack(draw, M1, 7, 1, sk=7, sn=1, st=0)
-            ops.igemm(p1t, drp, dn.k, M1, 7, self.g(name + '.weight'))
+            if small_n:          # dW = p1^T @ draw straight from the row-major operands (no transpose, no packing)
+                T.dense_small_n_wgrad(p1, draw, self.g(name + '.weight'), M1, dn.k, 7, accumulate=True)
+            else:
+                p1t = T.transpose(p1, M1, dn.k)
+                drp = ops.pack(draw, M1, 7, 1, sk=7, sn=1, st=0)
+                ops.igemm(p1t, drp, dn.k, M1, 7, self.g(name + '.weight'))
             w2t = T.transpose(dn.w_raw, dn.k, 7).view(7, dn.k)
             dp1 = ops.dense_small_k(draw, w2t, None, M1, 7, dn.k, gelu=False)
             dup = T.gelu_bwd(up, dp1)

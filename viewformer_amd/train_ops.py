@@ -135,6 +135,28 @@ def dense_small_k_bwd(x, dy, dW, db, rows, K, N):
           'vf_dense_small_k_bwd_f32')
 
 
+def dense_small_n_supported(K, N):
+    """shapes vf_dense_small_n_f32 / _wgrad_f32 take: a dense layer with at most 8 outputs (the pose head's 1536 -> 7)"""
+    return N <= 8 and K % 4 == 0 and K <= 2048
+
+
+def dense_small_n(x, W, b, rows, K, N):
+    """out[rows][N] = x[rows][K] @ W[K][N] + b for N <= 8: one pass over x (csrc/train_ops.hip)"""
+    out = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_dense_small_n_f32(_p(_f32(x)), _p(_f32(W)), _p(_f32(b)) if b is not None else None, _p(out), rows, K, N, x.stride(0), _stream()),
+          'vf_dense_small_n_f32')
+    return out
+
+
+def dense_small_n_wgrad(x, dy, dW, rows, K, N, accumulate=True):
+    """dW[K][N] (+)= x^T @ dy for N <= 8 (slab partial sums folded in slab order: deterministic)"""
+    lib = _lib.load()
+    ws = torch.empty((int(lib.vf_dense_small_n_wgrad_slabs(rows)), K * N), dtype=torch.float32, device=x.device)
+    check(lib.vf_dense_small_n_wgrad_f32(_p(_f32(x)), _p(_f32(dy)), _p(_f32(dW)), _p(ws), rows, K, N, x.stride(0), 1 if accumulate else 0, _stream()),
+          'vf_dense_small_n_wgrad_f32')
+    return dW
+
+
 def adamw_(param, grad, m, v, lr_decay, lr_adam, beta1, beta2, eps):
     check(_lib.load().vf_adamw_f32(_p(_f32(param)), _p(_f32(grad)), _p(_f32(m)), _p(_f32(v)), param.numel(), lr_decay, lr_adam,
                                    beta1, beta2, eps, _stream()), 'vf_adamw_f32')
