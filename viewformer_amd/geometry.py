@@ -9,13 +9,30 @@ viewformer/evaluate/evaluate_transformer.py:70-94 and viewformer/models/migt.py:
 import torch
 
 
+# Hamilton product, term table of geometry_tf.py:6-13: output component o = sum over t of  sign[o][t] * q1[(t+1)%4] * q2[_Q2_IDX[o][t]],
+# summed left to right.  One gather + one multiply per operand and three adds (7 element-wise launches) instead of one launch per scalar
+# operation of the literal formula (32): the evaluator's frame changes were ~180 launches of 4-5 us per inference step.  The results are the
+# literal formula's bit for bit — a sign flip is exact, and a - b == a + (-b) in IEEE arithmetic (tests/test_geometry.py).
+_Q1_IDX = (1, 2, 3, 0)
+_Q2_IDX = ((1, 2, 3, 0), (0, 3, 2, 1), (3, 0, 1, 2), (2, 1, 0, 3))
+_Q_SIGN = ((-1., -1., -1., 1.), (1., 1., -1., 1.), (-1., 1., 1., 1.), (1., -1., 1., 1.))
+_q_tables = {}
+
+
+def _quaternion_tables(device, dtype):
+    key = (str(device), dtype)
+    if key not in _q_tables:
+        _q_tables[key] = (torch.tensor(_Q1_IDX, device=device), torch.tensor(_Q2_IDX, device=device).reshape(-1),
+                          torch.tensor(_Q_SIGN, device=device, dtype=dtype))
+    return _q_tables[key]
+
+
 def quaternion_multiply(q1, q2):
-    w1, x1, y1, z1 = q1.unbind(-1)
-    w2, x2, y2, z2 = q2.unbind(-1)
-    return torch.stack((-x1 * x2 - y1 * y2 - z1 * z2 + w1 * w2,
-                        x1 * w2 + y1 * z2 - z1 * y2 + w1 * x2,
-                        -x1 * z2 + y1 * w2 + z1 * x2 + w1 * y2,
-                        x1 * y2 - y1 * x2 + z1 * w2 + w1 * z2), -1)
+    q1, q2 = torch.broadcast_tensors(q1, q2)
+    i1, i2, sign = _quaternion_tables(q1.device, q1.dtype)
+    a = q1.index_select(-1, i1).unsqueeze(-2) * sign                               # [...,4 out,4 terms]
+    p = a * q2.index_select(-1, i2).unflatten(-1, (4, 4))
+    return ((p[..., 0] + p[..., 1]) + p[..., 2]) + p[..., 3]
 
 
 def quaternion_normalize(x, epsilon: float = 1e-12):
