@@ -523,7 +523,8 @@ int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const
                     float* ori_loss, float* draw, int64_t rows, int L, float position_multiplier, void* stream);
 /* backward of vf_embed_sum_f32 (the tf.gather / wpe slice of migt.py:358-368 under autograd): dwte[id] += sum of dh over the tokens
  * with that id, dwpe[l] += sum_bs dh, dadd[bs][:] = sum_l dh.  Deterministic (fixed-order partial sums, no float atomics);
- * workspace = vf_embed_bwd_workspace_bytes(d, vocab) bytes. */
+ * workspace = vf_embed_bwd_workspace_bytes(d, vocab) bytes.  d % 4 == 0, d <= 2048, dh 16-byte aligned (rows are read as float4), else
+ * VF_ERR_UNSUPPORTED. */
 size_t vf_embed_bwd_workspace_bytes(int d, int vocab);
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
                      int vocab, void* workspace, void* stream);

@@ -828,6 +828,33 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('BS,L,d,vocab', [(300, 64, 768, 1026), (7, 16, 128, 66), (3, 50, 2048, 10)])
+def test_embedding_backward_with_a_heavy_mask_id(dev, BS, L, d, vocab):
+    """vf_embed_bwd_f32 at the training step's shape: a third of the tokens are whole views of the MASK id (the blocks that own it were the
+    kernel's whole duration until round 6), ragged token counts, ids outside the table clamped like tf.gather on GPU; fixed-order sums —
+    two runs agree bit for bit."""
+    from viewformer_amd import train_ops as T
+    g = torch.Generator().manual_seed(BS + d)
+    ids = torch.randint(0, vocab - 2, (BS, L), generator=g, dtype=torch.int32)
+    ids[::3] = vocab - 2                                                # the MASK stream's views
+    ids[1, :3] = torch.tensor([-5, vocab + 7, vocab - 1], dtype=torch.int32)
+    dh = torch.randn(BS * L, d, generator=g)
+    ref_ids = ids.long().clamp(0, vocab - 1).view(-1)
+    wte0, wpe0 = torch.randn(vocab, d, generator=g), torch.randn(L, d, generator=g)
+    ref_wte = wte0.double().index_add(0, ref_ids, dh.double())
+    ref_wpe = wpe0.double() + dh.double().view(BS, L, d).sum(0)
+    ref_add = dh.double().view(BS, L, d).sum(1)
+    outs = []
+    for _ in range(2):
+        dwte, dwpe = wte0.clone().to(dev), wpe0.clone().to(dev)
+        dadd = T.embed_bwd(dh.to(dev), ids.view(-1).to(dev), dwte, dwpe, BS, L, d, vocab)
+        outs.append((dwte, dwpe, dadd))
+    assert _err(outs[0][0], ref_wte) < 2e-6 and _err(outs[0][1], ref_wpe) < 2e-6 and _err(outs[0][2].view(BS, d), ref_add) < 2e-6
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rows,K,N', [(6400, 1536, 7), (130, 1536, 7), (64, 256, 8), (1000, 768, 3), (1, 4, 1)])
 def test_small_n_dense_layer_and_its_weight_gradient(dev, rows, K, N):
     """round 6: the pose head's 1536 -> 7 layer (migt.py:291-292,354) and its dW on one-pass kernels (csrc/train_ops.hip: dense_small_n*) against

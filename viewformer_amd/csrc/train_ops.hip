@@ -412,49 +412,59 @@ __global__ void pose_loss_kernel(const float* __restrict__ raw, const float* __r
 //   embed_bwd_wte_sum:     dwte[id] += partial[0][id] + partial[1][id] + ... in that order
 //   embed_bwd_pos:         thread (l, c) walks bs ascending; thread (bs, c) walks l ascending
 constexpr int EMB_SPLITS = 16;
+constexpr int EMB_U = 8;                                                  // rows in flight per wave
+// Round 6: a third of the training tokens carry the MASK id (whole views of the MASK stream), so 16 of the 16 400 blocks did a third of the
+// work at four rows per load latency: 256 us for 59 MB.  Now every wave owns a quarter of each 64-token window (its 16 lanes' matches,
+// ascending), reads whole rows as float4 (a lane holds columns 4 (lane + 64 j)) with eight rows in flight, and the four wave sums are added
+// in wave order — another fixed order than before (results differ in the last bits from round 5's, and are as deterministic).
 __global__ __launch_bounds__(256) void embed_bwd_wte_partial_kernel(const float* __restrict__ dh, const int* __restrict__ ids,
                                                                     float* __restrict__ partial, long long ntok, int d, int vocab) {
+    extern __shared__ float emb_s[];                                  // [4 waves][d]
     const int id = blockIdx.x, sp = blockIdx.y;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
     const long long t0 = sp * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-    float acc[8];                                                     // d <= 2048
+    const int d4 = d >> 2;                                            // (launcher: d % 4 == 0, d <= 2048)
+    float4 acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    // 64 tokens per round: every wave ballots the same 64 ids (lane = token), then walks the matches in ascending order, four rows
-    // in flight (a third of the training tokens carry the MASK id: one row per load latency made this kernel 1.6 ms)
+    for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long base = t0; base < t1; base += 64) {
         int v = -1;
         if (base + lane < t1) {
             v = ids[base + lane];
             v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
         }
-        unsigned long long m = __ballot(v == id);
-        while (m) {
-            long long tk[4];
+        const unsigned long long m = __ballot(v == id);
+        unsigned mw = (unsigned)(m >> (16 * wave)) & 0xffffu;           // this wave's quarter of the window
+        while (mw) {
+            long long tk[EMB_U];
             int n = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (m) { tk[u] = base + __builtin_ctzll(m); m &= m - 1; n = u + 1; } else tk[u] = base;
+            for (int u = 0; u < EMB_U; ++u) {
+                if (mw) { tk[u] = base + 16 * wave + __builtin_ctz(mw); mw &= mw - 1; n = u + 1; } else tk[u] = base;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int c = threadIdx.x + q * 256;
-                if (c < d) {
-                    float x[4];
+                const int c4 = lane + q * 64;
+                if (c4 < d4) {
+                    float4 x[EMB_U];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) x[u] = dh[tk[u] * d + c];
+                    for (int u = 0; u < EMB_U; ++u) x[u] = reinterpret_cast<const float4*>(dh + tk[u] * d)[c4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[q] += (u < n) ? x[u] : 0.f;     // ascending token order: deterministic
+                    for (int u = 0; u < EMB_U; ++u)
+                        if (u < n) { acc[q].x += x[u].x; acc[q].y += x[u].y; acc[q].z += x[u].z; acc[q].w += x[u].w; }   // ascending tokens
                 }
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int c = threadIdx.x + q * 256;
-        if (c < d) partial[((long long)sp * vocab + id) * d + c] = acc[q];
+        const int c4 = lane + q * 64;
+        if (c4 < d4) reinterpret_cast<float4*>(emb_s + wave * d)[c4] = acc[q];
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256)
+        partial[((long long)sp * vocab + id) * d + c] = ((emb_s[c] + emb_s[d + c]) + emb_s[2 * d + c]) + emb_s[3 * d + c];
 }
 __global__ void embed_bwd_wte_sum_kernel(const float* __restrict__ partial, float* __restrict__ dwte, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -861,10 +871,10 @@ size_t vf_embed_bwd_workspace_bytes(int d, int vocab) {
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
                      int vocab, void* workspace, void* stream) {
     if (!dh || !ids || !dwte || !dwpe || !dadd || !workspace || BS <= 0 || L <= 0 || d <= 0 || vocab <= 0) return VF_ERR_BAD_ARG;
-    if (d > 2048) return VF_ERR_UNSUPPORTED;
+    if (d > 2048 || d % 4 != 0 || (reinterpret_cast<uintptr_t>(dh) & 15) != 0) return VF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(embed_bwd_wte_partial_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), 0, s, dh, ids, partial,
+    hipLaunchKernelGGL(embed_bwd_wte_partial_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), (size_t)4 * d * sizeof(float), s, dh, ids, partial,
                        (long long)BS * L, d, vocab);
     const long long n = (long long)vocab * d;
     hipLaunchKernelGGL(embed_bwd_wte_sum_kernel, dim3(grid1(n, 256, 4096)), dim3(256), 0, s, partial, dwte, n);
