@@ -62,3 +62,29 @@ def test_streamed_host_round_trip_returns_the_plain_results_in_order(dev, models
             n += 1
         assert n == len(batches)
     assert list(stream_batch_predictions(tr, vq, iter([]))) == []
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_camera_bookkeeping_beside_the_model_kernels_changes_nothing(dev, models, fused, monkeypatch):
+    """evaluate.CAMERA_SIDE_STREAM: the frame changes (geometry.py) run on a second HIP stream beside the encoder / decoder kernels.  Same
+    values on or off, call after call (a missing stream dependency would show up as stale or torn cameras in some repetition), also when the
+    caller's own stream is not the default one."""
+    from viewformer_amd import evaluate
+    from viewformer_amd.weights import synthetic_scene_batch
+    tr, vq = models
+    batches = [synthetic_scene_batch(2 + 3 * (i % 3), 3, 32, seed=40 + i) for i in range(9)]
+    monkeypatch.setattr(evaluate, 'CAMERA_SIDE_STREAM', False)
+    plain = [evaluate.generate_batch_predictions(tr, vq, f, c, return_codes=True, fused_passes=fused) for f, c in batches]
+    monkeypatch.setattr(evaluate, 'CAMERA_SIDE_STREAM', True)
+    other = torch.cuda.Stream(dev)
+    for rep in range(3):
+        for i, (f, c) in enumerate(batches):
+            if rep == 2:
+                other.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(other):
+                    out = evaluate.generate_batch_predictions(tr, vq, f, c, return_codes=True, fused_passes=fused)
+                torch.cuda.current_stream(dev).wait_stream(other)
+            else:
+                out = evaluate.generate_batch_predictions(tr, vq, f, c, return_codes=True, fused_passes=fused)
+            for k in KEYS + ('codes', 'generated_codes', 'logits_last', 'pose_last'):
+                assert torch.equal(out[k], plain[i][k]), (rep, i, k)

@@ -51,6 +51,16 @@ def main():
                     lines.append(f'       grid_x={g:>9} (workgroups={g // 256:>6})  calls={cnt:4d} avg_us={avg / 1e3:10.2f} total_ms={ssum / 1e6:9.3f}')
             except Exception as e:           # column names differ between rocprofv3 versions: the per-kernel table above stands
                 lines.append(f'  -- (per-shape breakdown unavailable: {e})')
+            if os.environ.get('PROF_ALL'):   # every kernel of the run, each by launch shape -> summary_full.txt (the hunt for small kernels)
+                full = []
+                for n, cnt, avg, s, vg, lds in rows:
+                    full.append(f'{short(n):78s} calls={cnt:5d} avg_us={avg / 1e3:10.2f} total_ms={s / 1e6:9.3f} pct={100 * s / tot:5.2f} vgpr={vg} lds={lds}')
+                    per = c.execute(f"select d.grid_size_x, count(*), avg(d.end-d.start), sum(d.end-d.start) from {kd} d join {ks} s on "
+                                    f"d.kernel_id=s.id where s.kernel_name=? group by d.grid_size_x order by 4 desc", (n,)).fetchall()
+                    if len(per) > 1:
+                        for g, pc, pa, ps in per[:10]:
+                            full.append(f'       grid_x={g:>10}  calls={pc:5d} avg_us={pa / 1e3:10.2f} total_ms={ps / 1e6:9.3f}')
+                open(os.path.join(out, 'summary_full.txt'), 'w').write('\n'.join(full) + '\n')
             continue
         pe, ip = T('rocpd_pmc_event'), T('rocpd_info_pmc')
         q = (f"select s.kernel_name, p.name, d.id, sum(e.value), count(*) from {pe} e join {ip} p on e.pmc_id=p.id "

@@ -178,7 +178,12 @@ __device__ __forceinline__ void store_transposed_bf16(const f32x16 (&acc)[2], un
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dQ
-constexpr int DQ_SLOT = 3 * IMG, DQ_RING = 3, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
+#ifndef ATB_DQ_RING
+#define ATB_DQ_RING 3              // 3 slots = 72 KB: two workgroups per CU, two tiles ahead.  2 slots (48 KB: three per CU, one tile ahead; build.py
+                                  // 'dq_ring2') measured the same within the order effect of an alternation (round 6: 162.3 vs 165.6 us for dQ + dK/dV
+                                  // as second library, 160.5 vs 160.3 as first; bit-identical): occupancy is not what holds this kernel back
+#endif
+constexpr int DQ_SLOT = 3 * IMG, DQ_RING = ATB_DQ_RING, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
 
 template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,

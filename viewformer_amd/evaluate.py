@@ -25,6 +25,53 @@ def _frames_for_encode(images, image_size):
     return flat
 
 
+CAMERA_SIDE_STREAM = True       # the O(B*S) camera bookkeeping (geometry.py: ~100 element-wise launches of 4-5 us per batch, 0.5 ms of a 113 ms
+                                # step when they queue between the model kernels) runs on a second HIP stream beside the encoder / decoder
+                                # kernels; same torch operations on the same values — results bit-identical (tests/test_hip_evaluate_loop.py)
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(dev)
+    return _side_streams[key]
+
+
+class _beside:
+    """``with _beside(dev, *inputs) as b: ...`` runs the block's launches on the side stream after everything queued on the current stream
+    so far (the inputs are ready); ``b.join(*outputs)`` makes the current stream wait for them.  Tensors that cross streams are recorded on
+    the stream that did not allocate them (caching-allocator rule)."""
+
+    def __init__(self, dev, *inputs):
+        self.on = CAMERA_SIDE_STREAM and torch.device(dev).type == 'cuda'
+        if self.on:
+            self.cur, self.side = torch.cuda.current_stream(dev), _side_stream(dev)
+            self.ctx = torch.cuda.stream(self.side)
+            self.inputs = inputs
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.cur)
+            for t in self.inputs:
+                if t is not None:
+                    t.record_stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        if self.on:
+            self.cur.wait_stream(self.side)
+            for t in outputs:
+                if t is not None:
+                    t.record_stream(self.cur)
+
+
 MAX_SCENES_PER_CALL = 256      # scenes per transformer / decoder pass: the reference's loop batches arbitrary sizes
                                # (evaluate_transformer.py:219); scenes are independent, so a larger batch is walked in chunks with
                                # identical results (1024 scenes = 7168 frames would otherwise need 32-bit-offset-breaking activations)
@@ -47,9 +94,10 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
         return {k: (None if parts[0][k] is None else torch.cat([p[k] for p in parts])) for k in parts[0]}
     ground_truth_cameras = cameras[:, -1]
     transform = None
-    if transformer_model.config.augment_poses == 'relative':            # :99-101
-        cameras, transform = geometry.to_relative_cameras(cameras)
-    cameras = geometry.normalize_cameras(cameras)                       # :102
+    with _beside(dev, cameras) as frames_change:                        # (beside the encoder: CAMERA_SIDE_STREAM)
+        if transformer_model.config.augment_poses == 'relative':        # :99-101
+            cameras, transform = geometry.to_relative_cameras(cameras)
+        cameras = geometry.normalize_cameras(cameras)                   # :102
 
     B, S = images.shape[:2]
     t = transformer_model.config.token_image_size
@@ -61,6 +109,7 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
     # ``return_codes`` also hands back the last view's logits; without it the arg-max is fused into the LM head's epilogue where the
     # arm supports it (the [B*64, 1024] logits never reach HBM)
     pose_last, lg = None, None
+    frames_change.join(cameras, transform)
     if transformer_model.use_localization and fused_passes:
         first, pose_last = transformer_model.generate_and_localize(codes, cameras, codes_only=not return_codes)   # :119-123 + :134-136
         if return_codes:
@@ -80,21 +129,28 @@ def generate_batch_predictions(transformer_model, codebook_model, images, camera
         generated_codes = ops.argmax_rows(lg.view(-1, nE), B * t * t, nE).view(B, t, t)   # :123 (ties -> lowest index)
     generated_codes = generated_codes.view(B, t, t)
 
+    def camera_tail(pose_last):
+        with _beside(dev, pose_last, cameras, transform) as tail:       # (beside the decoder when the fused pass already has the pose)
+            if transformer_model.use_localization:                      # :134-136
+                generated_cameras = transformer_model.reduce_cameras(pose_last, -2)
+            else:
+                generated_cameras = cameras[:, :1]                      # :138
+            if transformer_model.config.augment_poses == 'relative':    # :139-140
+                generated_cameras = geometry.from_relative_cameras(generated_cameras, transform)
+        return tail, generated_cameras
+
+    tail = None
+    if pose_last is not None or not transformer_model.use_localization:
+        tail, generated_cameras = camera_tail(pose_last)
     dec = codebook_model.decode_code(generated_codes)                   # :127
     if codebook_model.data_format == 'NCHW':
         dec = dec.permute(0, 2, 3, 1)
     generated_images = ops.postprocess_u8(dec.contiguous())             # :128-129
-
-    if transformer_model.use_localization:                              # :134-136
-        if pose_last is None:
-            out2 = transformer_model(dict(input_ids=codes, poses=cameras[:, :-1]), training=False,
-                                     last_view_logits_only=True)
-            pose_last = out2['pose_prediction'][:, -1:]
-        generated_cameras = transformer_model.reduce_cameras(pose_last, -2)
-    else:
-        generated_cameras = cameras[:, :1]                              # :138
-    if transformer_model.config.augment_poses == 'relative':            # :139-140
-        generated_cameras = geometry.from_relative_cameras(generated_cameras, transform)
+    if tail is None:                                                    # the reference's separate localization call, :134-136
+        out2 = transformer_model(dict(input_ids=codes, poses=cameras[:, :-1]), training=False, last_view_logits_only=True)
+        pose_last = out2['pose_prediction'][:, -1:]
+        tail, generated_cameras = camera_tail(pose_last)
+    tail.join(generated_cameras)
     res = dict(ground_truth_images=images[:, -1], generated_images=generated_images,
                ground_truth_cameras=ground_truth_cameras, generated_cameras=generated_cameras[:, -1])
     if return_codes:
