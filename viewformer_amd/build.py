@@ -69,6 +69,8 @@ VARIANTS = {
     'trintrin': (['-DVF_X_TRINTRIN'], ['attention_dma', 'attention_train_bf16', 'gemm_tn_bf16']),
     # A/B only (tools/ab_inprocess_*attn.py): the attention launches' owner blocks in index order instead of heaviest first
     'attn_index_order': (['-DADMA_HEAVY_FIRST=0', '-DATB_HEAVY_FIRST=0'], ['attention_dma', 'attention_train_bf16']),
+    # A/B only: the x3h16 convolution's staging transform (GroupNorm-apply + swish + fp16 split) on packed fp32 instructions (bit-identical, slower)
+    'x3h16_pk_xform': (['-DX3H16_PKXFORM=1'], ['conv3_halo_x3h']),
     # A/B only: the dQ kernel with a two-slot ring (48 KB: three workgroups per CU instead of two, one tile ahead instead of two)
     'dq_ring2': (['-DATB_DQ_RING=2'], ['attention_train_bf16']),
 }

@@ -573,6 +573,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef X3H16_LB
 #define X3H16_LB 2
 #endif
+#ifndef X3H16_PKXFORM
+#define X3H16_PKXFORM 0         // 1 = the staging transform on packed fp32 instructions (build.py variant 'x3h16_pk_xform'): same bits, a third fewer vector
+                                // instructions per staged value — and 2.5-4 % SLOWER (profiles/r6_conv_ab.txt): measured in round 6, not shipped
+#endif
 #ifndef VF_X3H16_ABL
 #define VF_X3H16_ABL 0          // ablation bits (WRONG results; tools/variants.sh builds only): 1 weight fragments pinned to tap 0, 2 patch fragments read once per
 #endif                          // chunk, 4 no epilogue, 8 no MFMAs, 16 no next-chunk staging (DMA + transform), 32 staging without the transform
@@ -672,6 +676,26 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
         f32x4 raw = {0.f, 0.f, 0.f, 0.f};                        // (slot 5 of wave 3 has no landing area: pixels 184 .. 191 do not exist)
         if (!(q == G::SLOTS - 1 && wave == 3)) raw = *reinterpret_cast<const f32x4*>(raw_l + q * 4096 + tid * 16);
         f16x4 oh, ol;
+#if X3H16_PKXFORM && !VF_X3H_PRECISE_SWISH
+        // the GroupNorm-apply + swish + split of two values at a time on packed fp32 instructions (vf_common.h: vf_swish_1ulp_pk): the same
+        // operations in the same order as the scalar form below — same bits, a third fewer vector instructions per staged value (A/B only: slower)
+        const bool okq = ((ok_mask >> q) & 1u) != 0u;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            vf_f32x2 t = {raw[2 * e2], raw[2 * e2 + 1]};
+            if (PRO && !(VF_X3H16_ABL & 32)) {
+                const vf_f32x2 m2 = {pmean[2 * e2], pmean[2 * e2 + 1]}, s2 = {pscale[2 * e2], pscale[2 * e2 + 1]}, b2 = {pbeta[2 * e2], pbeta[2 * e2 + 1]};
+                t = (t - m2) * s2 + b2;
+                if (SWISH) t = vf_swish_1ulp_pk(t);
+            }
+            if (!okq) t = (vf_f32x2){0.f, 0.f};
+            const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y;
+            const vf_f32x2 hb = {(float)h0, (float)h1}, k2048 = {2048.f, 2048.f};
+            const vf_f32x2 lo = (t - hb) * k2048;
+            oh[2 * e2] = h0; oh[2 * e2 + 1] = h1;
+            ol[2 * e2] = (_Float16)lo.x; ol[2 * e2 + 1] = (_Float16)lo.y;
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = raw[e];
@@ -683,6 +707,7 @@ __global__ __launch_bounds__(256, X3H16_LB) void conv3_halo_x3h16_kernel(vf_igem
             split2(((ok_mask >> q) & 1u) ? t : 0.f, h, l);
             oh[e] = h; ol[e] = l;
         }
+#endif
         *reinterpret_cast<f16x4*>(dst) = oh;
         *reinterpret_cast<f16x4*>(dst + 64) = ol;
     };

@@ -50,6 +50,23 @@ __device__ __forceinline__ float vf_swish_1ulp(float v) {
     return v * r;
 }
 
+// the same function on two values with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two lanes of work per issue slot;
+// v_exp_f32 / v_rcp_f32 / v_min_f32 stay scalar).  Operation for operation the scalar sequence, so the results are its results bit for bit.
+typedef float vf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vf_f32x2 vf_swish_1ulp_pk(vf_f32x2 v) {
+    const vf_f32x2 LH = {-1.4426950408889634f, -1.4426950408889634f}, LL = {-1.9259629911266175e-8f, -1.9259629911266175e-8f};
+    const vf_f32x2 LN2 = {0.6931471805599453f, 0.6931471805599453f}, ONE = {1.0f, 1.0f};
+    vf_f32x2 th = v * LH;
+    const vf_f32x2 tl = __builtin_elementwise_fma(v, LH, -th) + v * LL;
+    th.x = fminf(th.x, 126.0f);
+    th.y = fminf(th.y, 126.0f);
+    const vf_f32x2 e0 = {__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
+    const vf_f32x2 d = ONE + __builtin_elementwise_fma(e0 * tl, LN2, e0);
+    vf_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-d, r, ONE), r, r);
+    return v * r;
+}
+
 __device__ __forceinline__ float vf_gelu_erf(float v) {
     // tf.nn.gelu(approximate=False): 0.5 x (1 + erf(x / sqrt 2))
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
