@@ -239,6 +239,12 @@ def gemm_bf16_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulat
     return dst
 
 
+TN_TARGET_WORKGROUPS = 192      # row-range splits of the weight-gradient GEMM: tiles x splits ~ three quarters of the CUs (each split writes a slab that
+                                # vf_sum_slabs_f32 folds).  Round 6, in-process alternation of the training step: 256 (7 splits of the 36-tile layers) 19.72 ms,
+                                # 224 (6) 19.71, 208 / 192 (5) 19.47-19.49, 176 (4) 19.65, 128 19.85: the weight gradients run beside the dX GEMM of the main
+                                # stream, and five slabs instead of seven are 29 % less slab traffic (profiles/r6_small_kernels.txt)
+
+
 def gemm_tn_bf16_supported(x, M, K, N):
     return x.dtype == torch.bfloat16 and gemm_tn_bf16_shape_ok(M, K, N)
 
@@ -265,7 +271,7 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
     lib = _lib.load()
     _chk(x16, torch.bfloat16, 'x16')
     tiles = (K // 256) * (N // 256)
-    splits = max(1, min(M // 64, 256 // tiles if tiles <= 256 else 1))
+    splits = max(1, min(M // 64, TN_TARGET_WORKGROUPS // tiles if tiles <= TN_TARGET_WORKGROUPS else 1))
     # one array of `splits` records (weight slab | bias slab): where the gradient buffer holds the bias right behind the weight (the trainer's
     # flat buffer does), ONE slab sum folds both
     rec = K * N + (N if db is not None else 0)
