@@ -476,6 +476,8 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
                      void* dv, int out_bf16 /* gradients written as bf16 (ldd* in elements) instead of fp32 */, int B, int H, int T, int L,
                      int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale, int twin_view, float drop_rate,
                      uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, void* stream);
+/* (round 6) vf_attn_bwd_bf16 with dq == NULL issues only the dK / dV launch, with dk == dv == NULL only the dQ launch: the two are independent, a caller
+ * may put them on two streams (viewformer_amd/train_ops.py: attn_bwd_bf16(kv_stream=...)). */
 /* elementwise dropout of the training graph (tf.keras.layers.Dropout at migt.py:72,216,403) on x [rows][cols] row-major:
  * out = keep ? x/(1-rate) : 0 [+ res], keep(m, n) = vf_dropout_keep(word of mask group (m' >> 2) * cols + n, m' & 3, floor(rate * 2^32)),
  * m' = m + row0 (row0: the first row's index in the global batch of a data-parallel step, 0 otherwise) (csrc/vf_common.h: four

@@ -1308,3 +1308,31 @@ def test_gelu_dual_epilogue_of_the_256_tile_kernel(dev, M):
         ops.igemm(x16, wp, M, K, N, u, bias=b, bf16=True, a16=True, out_aux=f)
     with pytest.raises(_lib.VfError):
         ops.igemm(x16, wp, M, K, N, u, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('drop', [(0.0, 0, 0), (0.1, 9, 3)])
+def test_attention_backward_launches_on_two_streams_give_the_one_stream_results(dev, drop):
+    """vf_attn_bwd_bf16 with dq == NULL / dk == dv == NULL issues one of its two launches; train_ops.attn_bwd_bf16(kv_stream=...) puts dK / dV on a
+    second stream beside dQ: same bits as the single call, call after call"""
+    from viewformer_amd import train_ops as T
+    B, H, S = 3, 4, 9
+    d, Tn = H * 64, S * 64
+    g = torch.Generator().manual_seed(21)
+    kv = torch.cuda.Stream(dev)
+    for it in range(4):
+        qkv = (torch.randn(B * Tn, 3 * d, generator=g) * 0.4).to(dev).to(torch.bfloat16)
+        dout = (torch.randn(B * Tn, d, generator=g) * 0.1).to(dev).to(torch.bfloat16)
+        q, k, v = qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d]
+        o = torch.empty(B * Tn, d, device=dev, dtype=torch.bfloat16)
+        lse = T.attn_fwd_lse_bf16(q, k, v, o, B, H, Tn, 64, 3 * d, 3 * d, 3 * d, d, 1.0, -3, drop)
+        res = []
+        for stream in (None, kv, kv):
+            dqkv = torch.full((B * Tn, 3 * d), float('nan'), device=dev, dtype=torch.bfloat16)
+            T.attn_bwd_bf16(q, k, v, o, dout, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d], B, H, Tn, 64, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d,
+                            3 * d, 1.0, -3, drop, kv_stream=stream)
+            res.append(dqkv)
+        torch.cuda.synchronize()
+        assert not torch.isnan(res[0].float()).any()
+        for r in res[1:]:
+            assert torch.equal(r.view(torch.int16), res[0].view(torch.int16)), it

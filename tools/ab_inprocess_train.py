@@ -19,6 +19,9 @@ from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch  # n
 
 modname, attr = sys.argv[1].split(':')
 mod = importlib.import_module(modname)
+while '.' in attr:                                    # module:Class.attr
+    head, attr = attr.split('.', 1)
+    mod = getattr(mod, head)
 vals = [ast.literal_eval(v) for v in sys.argv[2:] if not v.startswith('--')]
 rounds = int(os.environ.get('AB_ROUNDS', 6))
 steps = int(os.environ.get('AB_STEPS', 10))

@@ -16,6 +16,9 @@ from viewformer_amd.weights import synthetic_scene_batch  # noqa: E402
 
 modname, attr = sys.argv[1].split(':')
 mod = importlib.import_module(modname)
+while '.' in attr:                                    # module:Class.attr
+    head, attr = attr.split('.', 1)
+    mod = getattr(mod, head)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 8

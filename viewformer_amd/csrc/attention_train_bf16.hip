@@ -534,8 +534,12 @@ int vf_attn_bwd_prep_bf16(const void* dout, const void* out, float* D, int B, in
 int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* D, void* dq, void* dk,
                      void* dv, int out_bf16, int B, int H, int T, int L, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv,
                      float scale, int twin_view, float drop_rate, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_plane0, void* stream) {
-    if (!q || !k || !v || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
+    // dq == NULL: only the dK / dV launch; dk == dv == NULL: only the dQ launch (the two are independent: a caller may issue them on two streams)
+    const bool do_q = dq != nullptr, do_kv = dk != nullptr || dv != nullptr;
+    if (!q || !k || !v || !dout || !lse || !D || (!do_q && !do_kv) || (do_kv && (!dk || !dv)) || B <= 0 || H <= 0 || T <= 0 || !(scale > 0.f)) return VF_ERR_BAD_ARG;
     if (!(drop_rate >= 0.f && drop_rate < 1.f)) return VF_ERR_BAD_ARG;
+    if (!do_q) { dq = dk; lddq = lddk; }                      // (placeholders for the argument checks below; never written)
+    if (!do_kv) { dk = dv = dq; lddk = lddv = lddq; }
     if (L != KT || T % KT != 0 || T / KT > 64) return VF_ERR_UNSUPPORTED;                     // 64-token views, at most 64 of them (tile bit masks)
     if (ldq < H * DH || ldk < H * DH || ldv < H * DH || lddo < H * DH || lddq < H * DH || lddk < H * DH || lddv < H * DH) return VF_ERR_BAD_ARG;
     if (((ldq | ldk | ldv | lddo) & 7) || ((lddq | lddk | lddv) & (out_bf16 ? 7 : 3))) return VF_ERR_BAD_ARG;
@@ -561,12 +565,15 @@ int vf_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
             if (e != hipSuccess) return (int)e;
             vf_attr_done(&attr_devs);
         }
-        hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
-                           ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_q);
-        const int st = vf_last_status();
-        if (st) return st;
-        hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
-                           ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_k);
+        if (do_q) {
+            hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)DQ_RING * DQ_SLOT, s, q_, k_, v_, do_, lse, D, dq, H, T, ldq, ldk,
+                               ldv, lddo, lddq, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_q);
+            const int st = vf_last_status();
+            if (st) return st;
+        }
+        if (do_kv)
+            hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<O16, DROP>), grid, dim3(256), (size_t)KV_RING * KV_SLOT, s, q_, k_, v_, do_, lse, D, dk, dv, H, T, ldq,
+                               ldk, ldv, lddo, lddk, lddv, scale, twin_view, thr, dsc, drop_seed, drop_site, drop_plane0, ord_k);
         return vf_last_status();
     };
     using T_ = std::true_type;

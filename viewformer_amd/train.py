@@ -357,6 +357,16 @@ class MIGTTrainer:
         return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u)
 
     overlap_weight_gradients = True   # bf16 arm: the TN weight-gradient GEMM of a layer on a second stream beside that layer's dX GEMM
+    overlap_attention_backward = False  # bf16 arm: the attention backward's dK / dV launch on a third stream beside its dQ launch — same bits, measured
+                                        # 19.75 vs 19.65 ms per step (6 alternating rounds, round 6): the two kernels' workgroups sharing CUs cost more
+                                        # than their tails; off
+    _kv_stream_obj = None
+
+    def _kv_stream(self):
+        if self._kv_stream_obj is None:
+            self._kv_stream_obj = torch.cuda.Stream(self.dev)
+        return self._kv_stream_obj
+
     _side_stream = None
     _side_busy = False
 
@@ -730,7 +740,8 @@ class MIGTTrainer:
             if attn16:
                 dqkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if grad16 else torch.float32, device=dev)
                 T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
-                                B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S, drop=drop_attn(i))
+                                B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, 1.0, -S, drop=drop_attn(i),
+                                kv_stream=self._kv_stream() if self.overlap_attention_backward else None)
             else:
                 dqkv = self._attn_bwd(qkv, datt, B, Tn, L, -S, att=att, lse=lse, drop=drop_attn(i))
             dn1 = self._linear_bwd(p + '.attn.c_attn', n1, dqkv, M)

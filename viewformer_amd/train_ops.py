@@ -234,9 +234,11 @@ def attn_fwd_lse_bf16(q, k, v, out, B, H, T, L, ldq, ldk, ldv, ldo, scale=1.0, m
 
 
 def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale=1.0, mask_spec=-1,
-                  drop=(0.0, 0, 0)):
+                  drop=(0.0, 0, 0), kv_stream=None):
     """dQ, dK, dV (fp32, or bf16 when the output tensors are bf16; written in place; column views allowed) from bf16 q / k / v / out / dout
-    on the bf16 matrix pipe; ``drop`` as in the forward (the masks are recomputed)"""
+    on the bf16 matrix pipe; ``drop`` as in the forward (the masks are recomputed).  ``kv_stream``: the dK / dV launch goes to that stream
+    (after the row sums D on the current one) and the current stream waits for it at the end — the two launches are independent and each ends
+    on a partly filled round of its heaviest workgroups; same results."""
     lib = _lib.load()
     for t in (q, k, v, out, dout):
         _chk(t, torch.bfloat16)
@@ -245,8 +247,21 @@ def attn_bwd_bf16(q, k, v, out, dout, lse, dq, dk, dv, B, H, T, L, ldq, ldk, ldv
     o16 = dq.dtype == torch.bfloat16
     for t in (dq, dk, dv):
         _chk(t, torch.bfloat16 if o16 else torch.float32)
-    check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq), _p(dk), _p(dv), 1 if o16 else 0, B, H, T, L, ldq, ldk,
-                               ldv, lddo, lddq, lddk, lddv, scale, mask_spec, *_drop4(drop), _stream()), 'vf_attn_bwd_bf16')
+
+    def launch(dq_, dk_, dv_):
+        check(lib.vf_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(D), _p(dq_) if dq_ is not None else None,
+                                   _p(dk_) if dk_ is not None else None, _p(dv_) if dv_ is not None else None, 1 if o16 else 0, B, H, T, L, ldq, ldk,
+                                   ldv, lddo, lddq, lddk, lddv, scale, mask_spec, *_drop4(drop), _stream()), 'vf_attn_bwd_bf16')
+    if kv_stream is None:
+        return launch(dq, dk, dv)
+    main = torch.cuda.current_stream(q.device)
+    kv_stream.wait_stream(main)                               # q, k, v, dout, lse, D are complete
+    with torch.cuda.stream(kv_stream):
+        launch(None, dk, dv)
+    launch(dq, None, None)
+    for t in (q, k, v, dout, lse, D, dk, dv):
+        t.record_stream(kv_stream)
+    main.wait_stream(kv_stream)
 
 
 def dropout_add(x, rate, seed, site, res=None, out=None, cols=None, row0=0):
