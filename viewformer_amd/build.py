@@ -71,6 +71,9 @@ VARIANTS = {
     'attn_index_order': (['-DADMA_HEAVY_FIRST=0', '-DATB_HEAVY_FIRST=0'], ['attention_dma', 'attention_train_bf16']),
     # A/B only: the x3h16 convolution's staging transform (GroupNorm-apply + swish + fp16 split) on packed fp32 instructions (bit-identical, slower)
     'x3h16_pk_xform': (['-DX3H16_PKXFORM=1'], ['conv3_halo_x3h']),
+    # A/B only: rows per block of the LayerNorm backward (16 shipped)
+    'ln_bwd_rpb8': (['-DVF_LN_BWD_RPB=8'], ['train_ops']),
+    'ln_bwd_rpb32': (['-DVF_LN_BWD_RPB=32'], ['train_ops']),
     # A/B only: the dQ kernel with a two-slot ring (48 KB: three workgroups per CU instead of two, one tile ahead instead of two)
     'dq_ring2': (['-DATB_DQ_RING=2'], ['attention_train_bf16']),
 }

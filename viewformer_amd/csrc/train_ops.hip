@@ -760,7 +760,10 @@ int vf_colsum_f32(const float* x, float* out, int64_t M, int N, int64_t ld, int 
 // 19 200 x 768 with the residual and the bf16 copy (265 MB), kernel + finalize: 16 rows, one row at a time, four float4 slots per lane 89 us;
 // three slots (d = 768 exactly) 69-70 us; two rows in flight 62-64 us (4.2-4.3 TB/s; the shipped form, see the launcher for its history);
 // 8 rows per block 64-65, 4 rows 70-80; wave sums by DPP adds instead of ds_bpermute: 67.5 / 61.2 us (tools/bench_ln_bwd.py)
-constexpr int LN_BWD_RPB = 16;
+#ifndef VF_LN_BWD_RPB
+#define VF_LN_BWD_RPB 16            // rows per block of the LayerNorm backward (A/B: build.py variants 'ln_bwd_rpb8' / 'ln_bwd_rpb32')
+#endif
+constexpr int LN_BWD_RPB = VF_LN_BWD_RPB;
 size_t vf_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
     if (rows <= 0 || d <= 0) return 0;
     const int64_t blocks = (rows + LN_BWD_RPB - 1) / LN_BWD_RPB;
