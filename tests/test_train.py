@@ -1336,3 +1336,30 @@ def test_attention_backward_launches_on_two_streams_give_the_one_stream_results(
         assert not torch.isnan(res[0].float()).any()
         for r in res[1:]:
             assert torch.equal(r.view(torch.int16), res[0].view(torch.int16)), it
+
+
+@pytest.mark.gpu
+def test_early_per_layer_optimizer_leaves_the_same_parameters_bit_for_bit(dev):
+    """MIGTTrainer.early_optimizer: each layer's AdamWeightDecay update and re-pack on a third stream as soon as its gradients are final.  Three
+    steps with it and without it: parameters, both Adam moments and the losses are identical bit for bit (full width, bf16 arm, dropout on)."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(sequence_size=4, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.1, learning_rate=1e-3, weight_decay=0.05,
+                     total_steps=1000, batch_size=2, n_layer=3)
+    sd = make_migt_weights(cfg, seed=3)
+    g = np.random.Generator(np.random.PCG64(5))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(2, 4, 8, 8)))
+    poses = torch.from_numpy(g.standard_normal((2, 4, 7)).astype(np.float32))
+    res = []
+    for early in (False, True, True):
+        tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev))
+        tr.early_optimizer = early
+        losses = [tr.train_step(poses, tokens)['loss'].clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert (tr._layer_pack_ranges is not None) and tr._pack16 is not None
+        res.append((tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone(), torch.stack(losses)))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))

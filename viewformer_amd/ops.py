@@ -107,8 +107,13 @@ def pack_bf16_multi(items):
     descs = torch.from_numpy(a.view(np.uint8).copy()).to(items[0][0].device)
     n = len(items)
 
-    def run():
-        check(lib.vf_gemm_bf16_pack_multi(_p(descs), n, _stream()), 'vf_gemm_bf16_pack_multi')
+    def run(first=0, count=None):
+        """re-pack items [first, first + count) (default: all of them)"""
+        count = n - first if count is None else count
+        if count <= 0:
+            return
+        assert 0 <= first and first + count <= n
+        check(lib.vf_gemm_bf16_pack_multi(descs.data_ptr() + first * _lib.PACK_DESC_BYTES, count, _stream()), 'vf_gemm_bf16_pack_multi')
     run()
     return run
 

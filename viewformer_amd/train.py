@@ -233,9 +233,17 @@ class MIGTTrainer:
             # buffers): never run it against them — rebuild from scratch below
             self._pack16 = None
             self._pack16_keep = None
+            self._layer_pack_ranges = None
         if self._pack16 is not None:
-            self._pack16()
-        pack_items = []
+            if self._early_layers_done and self._layer_pack_ranges is not None:
+                # the layers' packings were refreshed right after their early update (train_step): only the rest of the table here
+                lo = min(a for a, n_ in self._layer_pack_ranges)
+                hi = max(a + n_ for a, n_ in self._layer_pack_ranges)
+                self._pack16(0, lo)
+                self._pack16(hi, None)
+            else:
+                self._pack16()
+        pack_items, pack_names = [], []
         for name, dn in m._dense.items():
             k32 = dn.k % 32 == 0
             to16 = bf16 and k32 and dn.k % 128 == 0 and dn.n % 128 == 0
@@ -257,6 +265,7 @@ class MIGTTrainer:
                     dn.wp16 = ops.pack_dense_kn_bf16(dn.w_raw)
                     self.wpT16[name] = ops.pack_dense_nk_bf16(dn.w_raw)
                     pack_items += [(dn.w_raw, False, dn.wp16), (dn.w_raw, True, self.wpT16[name])]
+                    pack_names += [name, name]
             if to6:
                 dn.wp6 = ops.pack_dense_kn_x3h(dn.w_raw) if x3h else ops.pack_dense_kn_x6(dn.w_raw)
                 self.wpT6[name] = ops.pack_dense_nk_x6(dn.w_raw)          # [K][N] read as the transposed [N][K] operand
@@ -264,12 +273,21 @@ class MIGTTrainer:
             head = m._wte[:nE]
             self._lm16 = (ops.pack_dense_nk_bf16(head), ops.pack_dense_kn_bf16(head))
             pack_items += [(head, True, self._lm16[0]), (head, False, self._lm16[1])]
+            pack_names += ['wte', 'wte']
         elif lm16 and self._pack16 is None:                          # (per-tensor refresh: one_launch_repack off)
             head = m._wte[:nE]
             self._lm16 = (ops.pack_dense_nk_bf16(head), ops.pack_dense_kn_bf16(head))
         if bf16 and self._pack16 is None and pack_items and self.one_launch_repack:
             self._pack16 = ops.pack_bf16_multi(pack_items)          # (re-packs once more; from now on the closure is the refresh)
             self._pack16_keep = pack_items                          # (the closure holds raw pointers: keep the tensors alive with it)
+            # descriptor ranges per transformer layer (early_optimizer: a layer's weights are re-packed as soon as they are updated); valid only
+            # when every layer's descriptors are contiguous and every wide layer weight is in the table
+            rng, ok = [], True
+            for i in range(c.n_layer):
+                idx = [j for j, nm in enumerate(pack_names) if nm.startswith(f'h.{i}.')]
+                ok = ok and len(idx) == 8 and idx == list(range(idx[0], idx[0] + 8))
+                rng.append((idx[0], len(idx)) if idx else (0, 0))
+            self._layer_pack_ranges = rng if ok else None
         m._lm_head = ops.pack(m._wte, d, nE, 1, sk=1, sn=d, st=0, out=m._lm_head)                          # logits = h @ wte^T (kept fresh for
         if not lm16:                                                                                      # whoever reads the model afterwards)
             self.lm_T = ops.pack(m._wte, nE, d, 1, sk=d, sn=1, st=0, out=getattr(self, 'lm_T', None))       # dH = dlogits @ wte
@@ -357,6 +375,50 @@ class MIGTTrainer:
         return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u)
 
     overlap_weight_gradients = True   # bf16 arm: the TN weight-gradient GEMM of a layer on a second stream beside that layer's dX GEMM
+    early_optimizer = False           # (measured in round 6: 19.660 vs 19.665 ms per step — the update hides, and the backward beside it slows by as much: off)
+                                      # bf16 arm: a layer's AdamWeightDecay update and the re-packing of its weights are issued on a third stream as soon as
+                                      # that layer's gradients are final (its backward and weight-gradient GEMMs done, its all-reduce complete) — HBM-bound
+                                      # work beside the matrix-bound backward of the layers below instead of 0.65 ms at the end of the step.  Same kernels on
+                                      # the same values: the parameters after a step are bit-identical (tests/test_train.py)
+    _opt_stream_obj = None
+    _layer_pack_ranges = None
+    _early_layers_done = False
+    _layer_nodecay = None
+    _head_nodecay = None
+
+    def _opt_stream(self):
+        if self._opt_stream_obj is None:
+            self._opt_stream_obj = torch.cuda.Stream(self.dev)
+        return self._opt_stream_obj
+
+    def _adam_scalars(self):
+        c, step = self.cfg, self.step_count
+        lr = learning_rate(step, self.lr_init, self.lr_total_steps, self.warmup_steps, self.lr_offset)
+        t = step + 1
+        return lr, lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
+    def _early_update_layer(self, i, handle=None):
+        """AdamWeightDecay over layer i's range of the flat buffer + its eight bf16 packings, on the optimizer stream"""
+        c = self.cfg
+        if self._layer_nodecay is None:                                      # (built on the main stream, before the optimizer stream's wait below)
+            self._layer_nodecay = []
+            for a, b in self.layer_ranges:
+                r = [[self.slices[n][0] - a, self.slices[n][1] - a] for n in self.names if 'bias' in n and a <= self.slices[n][0] < b]
+                self._layer_nodecay.append(torch.tensor(sorted(r), dtype=torch.int64, device=self.dev).reshape(-1, 2))
+        main, opt = torch.cuda.current_stream(self.dev), self._opt_stream()
+        opt.wait_stream(main)                                                # the layer's backward (LayerNorm / bias gradients) is queued on main
+        if self._side_busy:
+            opt.wait_stream(self._side_stream)                               # ... and its weight-gradient GEMMs + slab sums on the side stream
+        a, b = self.layer_ranges[i]
+        lr, lr_adam = self._adam_scalars()
+        with torch.cuda.stream(opt):
+            if handle is not None:
+                handle.wait()                                                # the layer's gradient all-reduce (this stream waits, not main)
+            T.adamw_flat_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
+                          self._layer_nodecay[i] if c.weight_decay > 0 else None, lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam,
+                          self.b1, self.b2, self.eps)
+            self._pack16(*self._layer_pack_ranges[i])
+
     overlap_attention_backward = False  # bf16 arm: the attention backward's dK / dV launch on a third stream beside its dQ launch — same bits, measured
                                         # 19.75 vs 19.65 ms per step (6 alternating rounds, round 6): the two kernels' workgroups sharing CUs cost more
                                         # than their tails; off
@@ -722,6 +784,11 @@ class MIGTTrainer:
         dh, dh16 = dh if (res16 and nl > 0) else (dh, None)
         handles = []
         overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
+        # early per-layer optimizer (see early_optimizer): needs the one-launch optimizer and re-pack tables, no clipping pass over the finished
+        # gradients, and — with more than one rank — the per-layer fp32 all-reduce whose handle the optimizer stream can wait for
+        early = (self.early_optimizer and apply_update and self.fused_optimizer and self._pack16 is not None and self._layer_pack_ranges is not None
+                 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
+                 and (self._world() == 1 or not reduce_gradients or (overlap and self.grad_allreduce_dtype == 'f32')))
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
             h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
@@ -748,9 +815,13 @@ class MIGTTrainer:
             dh = self._ln_bwd(p + '.ln_1', dn1, h_in, M, res=dh_mid, also_bf16=res16 and i > 0, drop=drop_of(site_mlp(i - 1)))
             dh, dh16 = dh if (res16 and i > 0) else (dh, None)
             saved[i] = None
+            hd = None
             if overlap:                                                              # this layer's grads are final
                 self._join_side()
-                handles.append(self._allreduce_range(*self.layer_ranges[i]))
+                hd = self._allreduce_range(*self.layer_ranges[i])
+                handles.append(hd)
+            if early:
+                self._early_update_layer(i, hd[0] if hd is not None else None)
         # embeddings: dwte scatter, dwpe, d(add) -> pose embedding MLP / LOC token row
         if rate:
             T.dropout_add(dh, rate, seed, SITE_EMBED, out=dh, row0=row0)
@@ -787,7 +858,9 @@ class MIGTTrainer:
                 ev[1].record()
                 self._allreduce_events = ev
         if apply_update:
-            self.apply_gradients()
+            self.apply_gradients(layers_done=early)
+            if early:
+                torch.cuda.current_stream(self.dev).wait_stream(self._opt_stream())     # the next forward reads the layers' new weights and packings
         return metrics
 
     grad_allreduce_dtype = 'f32'      # 'bf16': each range is all-reduced as a bf16 copy (177 MB instead of 354 MB on the links; the sum
@@ -853,19 +926,27 @@ class MIGTTrainer:
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def apply_gradients(self):
+    def apply_gradients(self, layers_done: bool = False):
+        """``layers_done``: the transformer layers' ranges were already updated (and re-packed) by train_step's early per-layer optimizer: only the
+        head range (embeddings, pose heads, ln_f) is left"""
         c = self.cfg
-        step = self.step_count
-        lr = learning_rate(step, self.lr_init, self.lr_total_steps, self.warmup_steps, self.lr_offset)
-        t = step + 1
-        lr_adam = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        lr, lr_adam = self._adam_scalars()
         if self.fused_optimizer:
             # one launch over the flat buffer; the "bias" tensors (models/utils.py:424: the only names excluded) as no-decay ranges
             if self._nodecay is None:
                 r = [[self.slices[n][0], self.slices[n][1]] for n in self.names if 'bias' in n]
                 self._nodecay = torch.tensor(sorted(r), dtype=torch.int64, device=self.dev).reshape(-1, 2)
-            T.adamw_flat_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self._nodecay if c.weight_decay > 0 else None,
-                          lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam, self.b1, self.b2, self.eps)
+            if layers_done:
+                a, b = self.head_range
+                if self._head_nodecay is None:
+                    r = [[self.slices[n][0], self.slices[n][1]] for n in self.names if 'bias' in n and self.slices[n][0] < b]
+                    self._head_nodecay = torch.tensor(sorted(r), dtype=torch.int64, device=self.dev).reshape(-1, 2)
+                T.adamw_flat_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
+                              self._head_nodecay if c.weight_decay > 0 else None, lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam,
+                              self.b1, self.b2, self.eps)
+            else:
+                T.adamw_flat_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self._nodecay if c.weight_decay > 0 else None,
+                              lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam, self.b1, self.b2, self.eps)
         else:
             for n in self.names:
                 a, b, _ = self.slices[n]
@@ -873,7 +954,11 @@ class MIGTTrainer:
                 T.adamw_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
                          lr * c.weight_decay if decay else 0.0, lr_adam, self.b1, self.b2, self.eps)
         self.step_count += 1
-        self.repack()
+        self._early_layers_done = bool(layers_done)
+        try:
+            self.repack()
+        finally:
+            self._early_layers_done = False
 
     def state_dict(self):
         return {n: self.p(n).detach().cpu().clone() for n in self.names}
