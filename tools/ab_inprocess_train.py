@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-process A/B of the training step (bench.py --workload train: 10 scenes x 10 views, dropout 0.1, bf16 arm) over values of one module attribute,
-timed in alternating blocks on one box.  usage: python tools/ab_inprocess_train.py viewformer_amd.ops:TN_TARGET_WORKGROUPS 256 128 192 [rounds] [steps]"""
+timed in alternating blocks on one box.  usage: python tools/ab_inprocess_train.py viewformer_amd.ops:TN_TARGET_WORKGROUPS_BESIDE 256 128 192 [rounds] [steps]"""
 import ast
 import importlib
 import json

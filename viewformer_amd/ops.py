@@ -244,10 +244,13 @@ def gemm_bf16_splitk(x, w_packed, M, Cin, Cout, dst, splits, lda=None, accumulat
     return dst
 
 
-TN_TARGET_WORKGROUPS = 192      # row-range splits of the weight-gradient GEMM: tiles x splits ~ three quarters of the CUs (each split writes a slab that
-                                # vf_sum_slabs_f32 folds).  Round 6, in-process alternation of the training step: 256 (7 splits of the 36-tile layers) 19.72 ms,
-                                # 224 (6) 19.71, 208 / 192 (5) 19.47-19.49, 176 (4) 19.65, 128 19.85: the weight gradients run beside the dX GEMM of the main
-                                # stream, and five slabs instead of seven are 29 % less slab traffic (profiles/r6_small_kernels.txt)
+TN_TARGET_WORKGROUPS = 256             # row-range splits of the weight-gradient GEMM: tiles x splits ~ one workgroup per CU when the launch has the machine to
+TN_TARGET_WORKGROUPS_BESIDE = 192      # itself; ~ three quarters of the CUs when it is issued beside another GEMM (the trainer's second stream: the dX GEMM of the
+                                       # same layer runs on the main stream).  Every split writes an fp32 slab that vf_sum_slabs_f32 folds.  Round 6, in-process
+                                       # alternation of the training step over the "beside" value: 256 (7 splits of the 36-tile layers) 19.72 ms, 224 (6) 19.71,
+                                       # 208 / 192 (5) 19.47-19.49, 176 (4) 19.65, 128 19.85 — five slabs instead of seven are 29 % less slab traffic and the
+                                       # parallelism they give up was not there to have (profiles/r6_small_kernels.txt).  Alone (the serialised step bench.py
+                                       # instruments for the roofline section) the full-machine split is the faster one.
 
 
 def gemm_tn_bf16_supported(x, M, K, N):
@@ -270,13 +273,14 @@ def gemm_drop_supported(M, K, N, row0=0):
     return gemm_g256_shape_ok(M, K, N) and row0 % 4 == 0 and ((M + row0 + 3) // 4) * N < 2 ** 32
 
 
-def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True):
+def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True, beside_another_gemm=False):
     """dw[K][N] (+)= x16^T @ dy and db[N] (+)= column sums of dy, straight from the row-major bf16 activation x16 [M][K] and the fp32
     gradient dy [M][N] (csrc/gemm_tn_bf16.hip): split-K slabs folded in slab order (deterministic)."""
     lib = _lib.load()
     _chk(x16, torch.bfloat16, 'x16')
     tiles = (K // 256) * (N // 256)
-    splits = max(1, min(M // 64, TN_TARGET_WORKGROUPS // tiles if tiles <= TN_TARGET_WORKGROUPS else 1))
+    target = TN_TARGET_WORKGROUPS_BESIDE if beside_another_gemm else TN_TARGET_WORKGROUPS
+    splits = max(1, min(M // 64, target // tiles if tiles <= target else 1))
     # one array of `splits` records (weight slab | bias slab): where the gradient buffer holds the bias right behind the weight (the trainer's
     # flat buffer does), ONE slab sum folds both
     rec = K * N + (N if db is not None else 0)

@@ -332,7 +332,7 @@ class MIGTTrainer:
                 side = self._side()
                 side.wait_stream(main)                                                 # dy (and x) are complete
                 with torch.cuda.stream(side):
-                    ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb)
+                    ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, beside_another_gemm=True)
                 for t in (x, dy):
                     t.record_stream(side)                                              # (the allocator must not recycle them under the side stream)
                 self._side_busy = True
