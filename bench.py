@@ -169,10 +169,10 @@ class OpTimer:
             by = B * T * H * 64 * (3 * q.element_size() + out.element_size())             # q, k, v read once, o written once
             t.attn.append((e0, e1, 4.0 * H * 64 * L * L * pairs * B, arm, (B, H, T, L, twin_view), dma, by))
             return r
-        def gemm_tn(x16, dy, M, K, N, dw, db=None, accumulate=True):          # the training step's weight-gradient GEMM (+ its slab sums)
+        def gemm_tn(x16, dy, M, K, N, dw, db=None, accumulate=True, **kw):    # the training step's weight-gradient GEMM (+ its slab sums)
             e0, e1 = ev()
             e0.record()
-            r = t._orig[4](x16, dy, M, K, N, dw, db, accumulate)
+            r = t._orig[4](x16, dy, M, K, N, dw, db, accumulate, **kw)
             e1.record()
             t.gemm.append((e0, e1, 2.0 * M * K * N, ('tn', M, K, N, 1)))
             return r

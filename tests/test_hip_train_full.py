@@ -267,9 +267,16 @@ def test_full_size_step_at_the_reference_dropout(dev):
     tr16.fuse_dropout = True
     # the weight-gradient GEMMs on a second stream beside the dX GEMMs (default) vs everything on the compute stream: the same kernels on the
     # same operands -> the same bits
+    # (a weight-gradient launch that has the machine to itself is split into more row ranges than one issued beside the dX GEMM — another summation
+    # order: for this comparison the serial step takes the second stream's split, MIGTTrainer.serial_wgrad_split_as_overlapped)
     tr16.overlap_weight_gradients = False
+    tr16.serial_wgrad_split_as_overlapped = True
     tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    tr16.serial_wgrad_split_as_overlapped = False
     assert torch.equal(tr16.flat_g, g1)
+    # ... and with its own split the serial step agrees to rounding
+    tr16.train_step(poses, tokens, reduce_gradients=False, apply_update=False)
+    assert _rel(tr16.flat_g, g1) < 1e-5
     tr16.overlap_weight_gradients = True
     # the fp32-equivalent arm under the same masks
     tr32 = _trainer(cfg, dev, 'f32')

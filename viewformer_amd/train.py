@@ -337,7 +337,9 @@ class MIGTTrainer:
                     t.record_stream(side)                                              # (the allocator must not recycle them under the side stream)
                 self._side_busy = True
             else:
-                ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb)
+                # (alone on the compute stream the launch takes the full-machine split, another summation order; serial_wgrad_split_as_overlapped
+                # keeps the second stream's split, for bit-for-bit comparisons of the two modes)
+                ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, beside_another_gemm=self.serial_wgrad_split_as_overlapped and need_dx)
             return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u) if need_dx else None
         if dy.dtype != torch.float32:
             raise RuntimeError('a bf16 gradient operand needs the TN weight-gradient path')
@@ -374,6 +376,7 @@ class MIGTTrainer:
             return None
         return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u)
 
+    serial_wgrad_split_as_overlapped = False
     overlap_weight_gradients = True   # bf16 arm: the TN weight-gradient GEMM of a layer on a second stream beside that layer's dX GEMM
     early_optimizer = False           # (measured in round 6: 19.660 vs 19.665 ms per step — the update hides, and the backward beside it slows by as much: off)
                                       # bf16 arm: a layer's AdamWeightDecay update and the re-packing of its weights are issued on a third stream as soon as
