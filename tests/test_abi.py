@@ -122,6 +122,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.vf_dropout_add_f32(d, None, d, 4, 0, 0, 0.1, 1, 1, None) == -1  # cols <= 0
     assert lib.vf_dropout_add_f32(d, None, d, 0, 8, 0, 0.1, 1, 1, None) == 0   # empty
     assert lib.vf_dropout_add_f32(d, None, d, 4, 8, 0, 1.0, 1, 1, None) == -1  # rate must be < 1
+    # round 6's entries
+    assert lib.vf_dense_small_n_f32(d, d, d, d, 0, 1536, 7, 1536, None) == 0                       # empty input is a no-op
+    assert lib.vf_dense_small_n_f32(d, d, d, d, 4, 1536, 7, 1000, None) == -1                      # ldx < K
+    assert lib.vf_dense_small_n_f32(d, d, d, d, 4, 1536, 9, 1536, None) == -2                      # N > 8: not this kernel's shape
+    assert lib.vf_dense_small_n_f32(d, d, d, d, 4, 1534, 7, 1536, None) == -2                      # K % 4
+    assert lib.vf_dense_small_n_wgrad_f32(d, d, d, None, 4, 1536, 7, 1536, 0, None) == -1          # no workspace
+    assert lib.vf_dense_small_n_wgrad_f32(d, d, d, d, 4, 4096, 7, 4096, 0, None) == -2             # K > 2048
+    assert lib.vf_dense_small_n_wgrad_slabs(0) == 0 and lib.vf_dense_small_n_wgrad_slabs(6400) == 400 and lib.vf_dense_small_n_wgrad_slabs(19200) == 600
+    assert lib.vf_embed_bwd_f32(d, d, d, d, d, 4, 64, 770, 1026, d, None) == -2                    # d % 4 (rows are read as float4)
+    assert lib.vf_embed_bwd_f32(d, d, d, d, d, 4, 64, 768, 1026, None, None) == -1                 # no workspace
+    # vf_attn_bwd_bf16: one of its two launches may be skipped (NULL outputs), not both; dK without dV is an error
+    z = None
+    common = (1, 2, 2, 128, 64, 384, 384, 384, 128, 384, 384, 384, 1.0, -1, 0.0, 0, 0, 0, None)
+    assert lib.vf_attn_bwd_bf16(d, d, d, d, d, d, z, z, z, *common) == -1
+    assert lib.vf_attn_bwd_bf16(d, d, d, d, d, d, z, d, z, *common) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
