@@ -828,16 +828,19 @@ def test_bf16_flash_attention_forward_lse_and_backward(dev, B, H, S, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('BS,L,d,vocab', [(300, 64, 768, 1026), (7, 16, 128, 66), (3, 50, 2048, 10)])
+@pytest.mark.parametrize('BS,L,d,vocab', [(300, 64, 768, 1026), (7, 16, 128, 66), (3, 50, 2048, 10), (4200, 64, 128, 300), (1, 1, 64, 3),
+                                           (50, 64, 64, 3000), (20, 16, 64, 12000)])
 def test_embedding_backward_with_a_heavy_mask_id(dev, BS, L, d, vocab):
     """vf_embed_bwd_f32 at the training step's shape: a third of the tokens are whole views of the MASK id (the blocks that own it were the
-    kernel's whole duration until round 6), ragged token counts, ids outside the table clamped like tf.gather on GPU; fixed-order sums —
-    two runs agree bit for bit."""
+    kernel's whole duration until round 6), ragged token counts, ids outside the table clamped like tf.gather on GPU, a token count past the
+    indexed form's range (the scanning kernel), a single token, a vocabulary that leaves the index fewer than 16 chunks and one that leaves it
+    none (the scanning kernel again); fixed-order sums — two runs agree bit for bit."""
     from viewformer_amd import train_ops as T
     g = torch.Generator().manual_seed(BS + d)
     ids = torch.randint(0, vocab - 2, (BS, L), generator=g, dtype=torch.int32)
     ids[::3] = vocab - 2                                                # the MASK stream's views
-    ids[1, :3] = torch.tensor([-5, vocab + 7, vocab - 1], dtype=torch.int32)
+    if BS > 1 and L >= 3:
+        ids[1, :3] = torch.tensor([-5, vocab + 7, vocab - 1], dtype=torch.int32)
     dh = torch.randn(BS * L, d, generator=g)
     ref_ids = ids.long().clamp(0, vocab - 1).view(-1)
     wte0, wpe0 = torch.randn(vocab, d, generator=g), torch.randn(L, d, generator=g)
@@ -849,7 +852,9 @@ def test_embedding_backward_with_a_heavy_mask_id(dev, BS, L, d, vocab):
         dwte, dwpe = wte0.clone().to(dev), wpe0.clone().to(dev)
         dadd = T.embed_bwd(dh.to(dev), ids.view(-1).to(dev), dwte, dwpe, BS, L, d, vocab)
         outs.append((dwte, dwpe, dadd))
-    assert _err(outs[0][0], ref_wte) < 2e-6 and _err(outs[0][1], ref_wpe) < 2e-6 and _err(outs[0][2].view(BS, d), ref_add) < 2e-6
+    tol = 2e-6 * max(1.0, (BS * L / 19200.0) ** 0.5)                    # fp32 running sums: the bound grows with the root of the term count
+    errs = (_err(outs[0][0], ref_wte), _err(outs[0][1], ref_wpe), _err(outs[0][2].view(BS, d), ref_add))
+    assert max(errs) < tol, (errs, tol)
     for a, b in zip(*outs):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 

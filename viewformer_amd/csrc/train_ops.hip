@@ -466,6 +466,138 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_partial_kernel(const float*
     for (int c = threadIdx.x; c < d; c += 256)
         partial[((long long)sp * vocab + id) * d + c] = ((emb_s[c] + emb_s[d + c]) + emb_s[2 * d + c]) + emb_s[3 * d + c];
 }
+// Round 6 (second form): what was left of the kernel above was its SCAN — 16 400 blocks each reading their range's ids (8 rounds of ~19 dependent
+// window loads).  With an index built once per token range the row blocks know their rows:
+//   embed_bwd_index_kernel  (one block per token range): a stable counting sort in LDS.  The range is cut into T contiguous chunks; integer
+//                           atomics count hist[chunk][id] (exact), thread `id` turns its column into chunk offsets, one wave scans the per-id
+//                           totals into starts[range][id], and one lane per chunk walks ITS tokens in order, handing out list slots: within
+//                           an id the list is in ascending token order whatever the hardware's scheduling
+//   embed_bwd_wte_rows_kernel (block (id, range)): the block's rows in four contiguous quarters, one per wave, eight rows in flight, float4;
+//                           the four wave sums are added in wave order (a fixed order: deterministic)
+// Ranges longer than EMB_MAX_PER tokens, or vocabularies whose histogram does not fit the LDS with at least four chunks, take the scanning kernel above.
+constexpr int EMB_MAX_PER = 16384, EMB_IDX_THREADS = 1024, EMB_IDX_LDS = 152 * 1024, EMB_MAX_CHUNKS = 16;
+static int embed_index_chunks(long long per, int vocab) {              // chunk owners that fit the LDS budget (0: use the scanning kernel)
+    const long long fixed = (per + vocab + 1) * (long long)sizeof(int);
+    if (per > EMB_MAX_PER || fixed >= EMB_IDX_LDS) return 0;
+    const long long t = (EMB_IDX_LDS - fixed) / ((long long)vocab * (long long)sizeof(int));
+    return t >= EMB_MAX_CHUNKS ? EMB_MAX_CHUNKS : (t >= 4 ? (int)t : 0);
+}
+__global__ __launch_bounds__(EMB_IDX_THREADS) void embed_bwd_index_kernel(const int* __restrict__ ids, int* __restrict__ starts, int* __restrict__ list,
+                                                                          long long ntok, int vocab, int nchunk) {
+    extern __shared__ int emb_i[];                                    // [per] ids | [vocab + 1] totals -> starts | [nchunk][vocab] counts -> offsets
+    const int sp = blockIdx.x, tid = threadIdx.x;
+    const long long per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
+    const long long t0 = sp * per;
+    const int n = (int)(t0 >= ntok ? 0 : (t0 + per < ntok ? per : ntok - t0));
+    int* sid = emb_i;
+    int* tot = emb_i + per;
+    int* hist = tot + vocab + 1;
+    const int clen = (n + nchunk - 1) / nchunk;                       // tokens per chunk (the last may be short or empty)
+    for (int v = tid; v < nchunk * vocab; v += EMB_IDX_THREADS) hist[v] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += EMB_IDX_THREADS) {
+        int v = ids[t0 + i];
+        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        sid[i] = v;
+        atomicAdd(&hist[(i / clen) * vocab + v], 1);
+    }
+    __syncthreads();
+    for (int v = tid; v < vocab; v += EMB_IDX_THREADS) {              // counts of an id -> its chunks' offsets within the id; the id's total
+        int run = 0;
+        for (int t = 0; t < nchunk; ++t) { const int c = hist[t * vocab + v]; hist[t * vocab + v] = run; run += c; }
+        tot[v] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {                                                   // exclusive scan of tot[0 .. vocab) by one wave, in place; tot[vocab] = n
+        const int chunk = (vocab + 63) / 64;
+        const int lo = tid * chunk < vocab ? tid * chunk : vocab, hi = lo + chunk < vocab ? lo + chunk : vocab;
+        int sum = 0;
+        for (int v = lo; v < hi; ++v) sum += tot[v];
+        int incl = sum;                                               // inclusive wave scan of the per-lane sums
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (tid >= off) incl += o;
+        }
+        int run = incl - sum;
+        for (int v = lo; v < hi; ++v) { const int c = tot[v]; tot[v] = run; run += c; }
+        if (tid == 63) tot[vocab] = n;
+    }
+    __syncthreads();
+    int* st = starts + (long long)sp * (vocab + 1);
+    for (int v = tid; v <= vocab; v += EMB_IDX_THREADS) st[v] = tot[v];
+    int* ls = list + (long long)sp * EMB_MAX_PER;
+    if ((tid & 63) == 0 && (tid >> 6) < nchunk) {                     // one lane per chunk (in its own wave while there are waves)
+        for (int t = tid >> 6; t < nchunk; t += EMB_IDX_THREADS / 64) {
+            int* h = hist + t * vocab;
+            const int i1 = (t + 1) * clen < n ? (t + 1) * clen : n;
+            for (int i = t * clen; i < i1; ++i) {
+                const int v = sid[i];
+                const int k = h[v];
+                h[v] = k + 1;
+                ls[tot[v] + k] = i;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_wte_rows_kernel(const float* __restrict__ dh, const int* __restrict__ starts,
+                                                                 const int* __restrict__ list, float* __restrict__ partial, long long ntok, int d,
+                                                                 int vocab) {
+    extern __shared__ float emb_s[];                                  // [4 waves][d]
+    const int id = blockIdx.x, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int* st = starts + (long long)sp * (vocab + 1);
+    const int k0 = st[id], n = st[id + 1] - k0;
+    float* out = partial + ((long long)sp * vocab + id) * d;
+    if (n == 0) {                                                     // (most (id, range) pairs: nothing to read)
+        for (int c = threadIdx.x; c < d; c += 256) out[c] = 0.f;
+        return;
+    }
+    const long long per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
+    const float* base = dh + (long long)sp * per * d;
+    const int* ls = list + (long long)sp * EMB_MAX_PER + k0;
+    const int d4 = d >> 2;
+    const int q = (n + 3) >> 2;                                       // rows per wave: wave w owns rows [w q, (w + 1) q) of the block's list
+    const int r0 = wave * q, r1 = r0 + q < n ? r0 + q : n;
+    float4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; r += EMB_U) {
+        int tk[EMB_U];
+#pragma unroll
+        for (int u = 0; u < EMB_U; ++u) tk[u] = ls[r + u < r1 ? r + u : r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < d4) {
+                float4 x[EMB_U];
+#pragma unroll
+                for (int u = 0; u < EMB_U; ++u) x[u] = reinterpret_cast<const float4*>(base + (long long)tk[u] * d)[c4];
+#pragma unroll
+                for (int u = 0; u < EMB_U; ++u)
+                    if (r + u < r1) { acc[j].x += x[u].x; acc[j].y += x[u].y; acc[j].z += x[u].z; acc[j].w += x[u].w; }
+            }
+        }
+    }
+    if (n <= 1) {                                                     // one row: wave 0 holds it
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c4 = lane + j * 64;
+                if (c4 < d4) reinterpret_cast<float4*>(out)[c4] = acc[j];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c4 = lane + j * 64;
+        if (c4 < d4) reinterpret_cast<float4*>(emb_s + wave * d)[c4] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) out[c] = ((emb_s[c] + emb_s[d + c]) + emb_s[2 * d + c]) + emb_s[3 * d + c];
+}
 __global__ void embed_bwd_wte_sum_kernel(const float* __restrict__ partial, float* __restrict__ dwte, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = partial[i];
@@ -478,14 +610,32 @@ __global__ void embed_bwd_pos_kernel(const float* __restrict__ dh, float* __rest
                                      int L, int d) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long n_pos = (long long)L * d, n_add = BS * d;
+    // (eight independent loads in flight, added in ascending order: the sums are the one-load-at-a-time loop's, bit for bit)
     if (i < n_pos) {                                                  // dwpe[l][c]
         float s = 0.f;
-        for (long long bs = 0; bs < BS; ++bs) s += dh[bs * n_pos + i];
+        long long bs = 0;
+        for (; bs + 8 <= BS; bs += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = dh[(bs + u) * n_pos + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
+        }
+        for (; bs < BS; ++bs) s += dh[bs * n_pos + i];
         dwpe[i] += s;
     } else if (i < n_pos + n_add) {                                   // dadd[bs][c]
         const long long j = i - n_pos, bs = j / d, c = j - bs * d;
+        const float* p = dh + bs * L * d + c;
         float s = 0.f;
-        for (int l = 0; l < L; ++l) s += dh[(bs * L + l) * d + c];
+        int l = 0;
+        for (; l + 8 <= L; l += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p[(long long)(l + u) * d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
+        }
+        for (; l < L; ++l) s += p[(long long)l * d];
         dadd[j] = s;
     }
 }
@@ -868,7 +1018,8 @@ int vf_pose_mse_f32(const float* raw, const float* gt, const float* w_pos, const
 
 size_t vf_embed_bwd_workspace_bytes(int d, int vocab) {
     if (d <= 0 || vocab <= 0) return 0;
-    return (size_t)EMB_SPLITS * vocab * d * sizeof(float);
+    // partial sums [ranges][vocab][d] | starts [ranges][vocab + 1] | row lists [ranges][EMB_MAX_PER]
+    return (size_t)EMB_SPLITS * vocab * d * sizeof(float) + (size_t)EMB_SPLITS * ((size_t)vocab + 1 + EMB_MAX_PER) * sizeof(int);
 }
 
 int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dwpe, float* dadd, int64_t BS, int L, int d,
@@ -877,8 +1028,25 @@ int vf_embed_bwd_f32(const float* dh, const int32_t* ids, float* dwte, float* dw
     if (d > 2048 || d % 4 != 0 || (reinterpret_cast<uintptr_t>(dh) & 15) != 0) return VF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(embed_bwd_wte_partial_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), (size_t)4 * d * sizeof(float), s, dh, ids, partial,
-                       (long long)BS * L, d, vocab);
+    const long long ntok = (long long)BS * L, per = (ntok + EMB_SPLITS - 1) / EMB_SPLITS;
+    const int nchunk = embed_index_chunks(per, vocab);
+    if (nchunk) {
+        int* starts = reinterpret_cast<int*>(partial + (size_t)EMB_SPLITS * vocab * d);
+        int* list = starts + (size_t)EMB_SPLITS * (vocab + 1);
+        const size_t smem = ((size_t)per + vocab + 1 + (size_t)nchunk * vocab) * sizeof(int);
+        static unsigned long long attr_devs = 0;
+        if (vf_attr_needed(&attr_devs)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EMB_IDX_LDS);
+            if (e != hipSuccess) return (int)e;
+            vf_attr_done(&attr_devs);
+        }
+        hipLaunchKernelGGL(embed_bwd_index_kernel, dim3(EMB_SPLITS), dim3(EMB_IDX_THREADS), smem, s, ids, starts, list, ntok, vocab, nchunk);
+        hipLaunchKernelGGL(embed_bwd_wte_rows_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), (size_t)4 * d * sizeof(float), s, dh, starts, list, partial,
+                           ntok, d, vocab);
+    } else {
+        hipLaunchKernelGGL(embed_bwd_wte_partial_kernel, dim3((unsigned)vocab, EMB_SPLITS), dim3(256), (size_t)4 * d * sizeof(float), s, dh, ids, partial,
+                           ntok, d, vocab);
+    }
     const long long n = (long long)vocab * d;
     hipLaunchKernelGGL(embed_bwd_wte_sum_kernel, dim3(grid1(n, 256, 4096)), dim3(256), 0, s, partial, dwte, n);
     const long long m = (long long)L * d + (long long)BS * d;
