@@ -550,6 +550,29 @@ int vf_adamw_f32(float* param, const float* grad, float* m, float* v, int64_t n,
  * vf_adamw_f32 calls.  n % 4 == 0, 16-byte aligned buffers, tensors starting on 4-element boundaries, at most 256 ranges. */
 int vf_adamw_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n, const int64_t* nodecay_ranges, int nranges,
                       float lr_decay, float lr_adam, float beta1, float beta2, float eps, void* stream);
+/* Round 6: the same flat step with the bf16 re-packing of the dense layers' weights folded in (the training step ended with vf_adamw_flat_f32 and
+ * vf_gemm_bf16_pack_multi, which read every updated fp32 weight again twice).  Each descriptor names one weight matrix [rows][cols] (row-major,
+ * contiguous) at element `offset` of the flat buffer and the packed operands to refresh from its NEW values: dst_kn = what
+ * vf_gemm_bf16_pack(src, dst, K = rows, N = cols, sk = cols, sn = 1) writes (x @ W), dst_nk = what vf_gemm_bf16_pack(src, dst, K = cols, N = rows,
+ * sk = 1, sn = cols) writes (dY @ W^T; a tied head's h @ E^T); either may be NULL.  Parameters, moments and both packings are bit-identical to
+ * vf_adamw_flat_f32 followed by vf_gemm_bf16_pack_multi.  Descriptors: sorted by offset, disjoint, rows % 128 == 0, cols % 128 == 0 (no padding in either packing),
+ * offset % 4 == 0, 16-byte aligned destinations, at most 256 — vf_adamw_pack_check validates a HOST copy of the table (call it once when the
+ * table is built; the step itself takes the device copy and does not synchronise).  Replaces, for the bf16 arm, the reference's
+ * optimizer.apply_gradients (models/utils.py:507-537) + the per-step cast of the variables to the compute dtype that Keras mixed precision
+ * does inside every layer call (migt.py:89-96 under the mixed_float16 policy). */
+typedef struct vf_adamw_pack_desc {
+    int64_t offset;
+    void* dst_kn;
+    void* dst_nk;
+    int32_t rows, cols;
+    int32_t nodecay;            /* != 0: the matrix lies in one of nodecay_ranges (the caller resolves it once, on the host) */
+    int32_t reserved;
+} vf_adamw_pack_desc;
+size_t vf_sizeof_adamw_pack_desc(void);
+int vf_adamw_pack_check(const vf_adamw_pack_desc* descs_host, int ndesc, int64_t n);
+int vf_adamw_flat_pack_f32(float* param, const float* grad, float* m, float* v, int64_t n, const int64_t* nodecay_ranges, int nranges,
+                           float lr_decay, float lr_adam, float beta1, float beta2, float eps, const vf_adamw_pack_desc* descs_device, int ndesc,
+                           void* stream);
 int vf_add_inplace_f32(float* a, const float* b, int64_t n, void* stream);
 /* out = a*x + b*y (y may be NULL: out = a*x); out may alias x or y */
 int vf_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);

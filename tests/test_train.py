@@ -1368,3 +1368,79 @@ def test_early_per_layer_optimizer_leaves_the_same_parameters_bit_for_bit(dev):
     for r in res[1:]:
         for a, b in zip(res[0], r):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_fused_optimizer_repack_kernel_against_the_two_launches(dev):
+    """vf_adamw_flat_pack_f32 on a synthetic flat buffer: weight matrices with both packings, with only one, one inside a no-decay range, small
+    tensors between them — parameters, both moments and every packed buffer equal vf_adamw_flat_f32 + vf_gemm_bf16_pack_multi bit for bit."""
+    from viewformer_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(11)
+    shapes = [(12,), (128, 256), (256,), (128, 128), (4,), (256, 384), (384,), (1024, 128), (8,)]
+    offs, n = [], 0
+    for s in shapes:
+        offs.append(n)
+        n += (int(np.prod(s)) + 3) // 4 * 4
+    p0 = torch.randn(n, generator=g)
+    g0 = torch.randn(n, generator=g) * 0.1
+    m0 = torch.randn(n, generator=g) * 0.01
+    v0 = torch.rand(n, generator=g) * 0.01
+    nodecay = torch.tensor([[offs[2], offs[2] + 256], [offs[5], offs[5] + 256 * 384], [offs[6], offs[6] + 384]], dtype=torch.int64, device=dev)
+    want = {1: (True, True), 3: (True, False), 5: (False, True), 7: (True, True)}      # tensor index -> (kn, nk)
+    outs = []
+    for fused in (False, True):
+        p, gr, m, v = (t.clone().to(dev) for t in (p0, g0, m0, v0))
+        views = {i: p[offs[i]:offs[i] + int(np.prod(shapes[i]))].view(shapes[i]) for i in want}
+        kn = {i: torch.full((int(ops._lib.load().vf_gemm_bf16_packed_elems(*shapes[i])),), float('nan'), dtype=torch.bfloat16, device=dev) for i, w in want.items() if w[0]}
+        nk = {i: torch.full((int(ops._lib.load().vf_gemm_bf16_packed_elems(shapes[i][1], shapes[i][0])),), float('nan'), dtype=torch.bfloat16, device=dev)
+              for i, w in want.items() if w[1]}
+        if fused:
+            table = T.adamw_pack_table(p, [(views[i], kn.get(i), nk.get(i)) for i in want], nodecay)
+            assert table is not None and table[1] == 4
+            T.adamw_flat_pack_(p, gr, m, v, nodecay, 1e-3 * 0.05, 2e-3, 0.9, 0.999, 1e-7, table)
+        else:
+            T.adamw_flat_(p, gr, m, v, nodecay, 1e-3 * 0.05, 2e-3, 0.9, 0.999, 1e-7)
+            ops.pack_bf16_multi([(views[i], False, kn[i]) for i in kn] + [(views[i], True, nk[i]) for i in nk])
+        torch.cuda.synchronize()
+        outs.append([p, m, v] + [kn[i] for i in sorted(kn)] + [nk[i] for i in sorted(nk)])
+    assert not torch.equal(outs[0][0].cpu(), p0)
+    for a, b in zip(*outs):
+        assert not torch.isnan(a.float()).any()
+        assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+    # a table the tile kernel cannot take is refused on the host: rows % 128, overlapping descriptors
+    p = p0.clone().to(dev)
+    assert T.adamw_pack_table(p, [(p[:64 * 128].view(64, 128), torch.empty(64 * 128, dtype=torch.bfloat16, device=dev), None)]) is None
+    w = p[:128 * 128].view(128, 128)
+    buf = torch.empty(128 * 128, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(Exception):
+        T.adamw_pack_table(p, [(w, buf, None), (w, None, buf)])
+
+
+@pytest.mark.gpu
+def test_fused_optimizer_repack_leaves_the_same_trainer_state_bit_for_bit(dev):
+    """MIGTTrainer.fused_optimizer_repack: three steps with the optimizer writing the bf16 packings itself and with the separate re-pack launch:
+    parameters, moments, losses and every packed operand (layer weights both ways, the tied LM head both ways) identical."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(sequence_size=4, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.1, learning_rate=1e-3, weight_decay=0.05,
+                     total_steps=1000, batch_size=2, n_layer=2)
+    sd = make_migt_weights(cfg, seed=3)
+    g = np.random.Generator(np.random.PCG64(5))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(2, 4, 8, 8)))
+    poses = torch.from_numpy(g.standard_normal((2, 4, 7)).astype(np.float32))
+    res = []
+    for fused in (False, True):
+        tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev))
+        tr.fused_optimizer_repack = fused
+        losses = [tr.train_step(poses, tokens)['loss'].clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert tr._pack16 is not None and tr._adam_pack is not None and 2 * tr._adam_pack[1] == len(tr._pack16_keep) >= 2 * (4 * cfg.n_layer + 1)
+        assert tr._packs_fresh is False
+        packs = [out for _, _, out in tr._pack16_keep]               # every layer weight both ways, the tied LM head both ways
+        assert {id(x) for x in packs} >= {id(x) for x in tr._lm16} | {id(dn.wp16) for dn in tr.model._dense.values() if dn.wp16 is not None}
+        res.append([tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone(), torch.stack(losses)] + [x.clone() for x in packs])
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(*res):
+        assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))

@@ -39,6 +39,7 @@ SEL_GEMM_TAIL = 5             # 256-tile bf16 GEMM: tail tiles in the last round
 _ENV_SELECT = {'VF_ATTN_DMA': SEL_ATTN_DMA, 'VF_GEMM_G256': SEL_GEMM_G256, 'VF_LN_BWD_TWO_ROWS': SEL_LN_BWD_TWO_ROWS, 'VF_ATTN_Q32': SEL_ATTN_Q32,
                'VF_CONV_X3H_K32': SEL_CONV_X3H_K32, 'VF_GEMM_TAIL': SEL_GEMM_TAIL}
 
+ADAMW_PACK_DESC_BYTES = 40    # vf_adamw_pack_desc (train_ops.adamw_pack_table)
 PACK_DESC_BYTES = 40          # vf_pack_desc (ops.pack_bf16_multi builds the table as a numpy record array of this item size)
 P = c_void_p
 # name -> (restype, argtypes)
@@ -166,6 +167,9 @@ EXPORTS = {
     'vf_dense_small_n_wgrad_f32': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int64, c_int, P]),
     'vf_adamw_f32': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     'vf_adamw_flat_f32': (c_int, [P, P, P, P, c_int64, P, c_int, c_float, c_float, c_float, c_float, c_float, P]),
+    'vf_sizeof_adamw_pack_desc': (c_size_t, []),
+    'vf_adamw_pack_check': (c_int, [P, c_int, c_int64]),
+    'vf_adamw_flat_pack_f32': (c_int, [P, P, P, P, c_int64, P, c_int, c_float, c_float, c_float, c_float, c_float, P, c_int, P]),
     'vf_axpby_f32': (c_int, [c_float, P, c_float, P, P, c_int64, P]),
     'vf_add_inplace_f32': (c_int, [P, P, c_int64, P]),
     'vf_clip_by_norm_f32': (c_int, [P, c_int64, c_float, P, P]),
@@ -226,6 +230,8 @@ def load():
                       'viewformer_amd/_lib.py: rebuild the library or update the mirror')
     if int(lib.vf_sizeof_pack_desc()) != PACK_DESC_BYTES:
         raise VfError(f'vf_pack_desc is {int(lib.vf_sizeof_pack_desc())} bytes in {LIB_PATH}, {PACK_DESC_BYTES} expected')
+    if int(lib.vf_sizeof_adamw_pack_desc()) != ADAMW_PACK_DESC_BYTES:
+        raise VfError(f'vf_adamw_pack_desc is {int(lib.vf_sizeof_adamw_pack_desc())} bytes in {LIB_PATH}, {ADAMW_PACK_DESC_BYTES} expected')
     for env, which in _ENV_SELECT.items():
         if os.environ.get(env) in ('0', '1'):
             lib.vf_select(which, int(os.environ[env]))

@@ -657,19 +657,26 @@ __global__ void dense_small_k_bwd_kernel(const float* __restrict__ x, const floa
     db[n] += b;
 }
 
+// one element's step, shared by the per-tensor kernel, the flat kernel and the tile kernel below so that the three agree bit for bit
+// (contraction is spelled out: left to the compiler the three kernels fused different products of `b2 v + (1 - b2) g g` — 1-ulp differences in v)
+__device__ __forceinline__ void adamw_step(float& w, float gi, float& mi, float& vi, float ld, float lr_adam, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    const float we = __builtin_fmaf(-ld, w, w);
+    mi = __builtin_fmaf(b1, mi, (1.f - b1) * gi);
+    vi = __builtin_fmaf(b2, vi, ((1.f - b2) * gi) * gi);
+    const float q = (lr_adam * mi) / (sqrtf(vi) + eps);
+    w = we - q;
+}
 // ------------------------------------------------------------------ AdamWeightDecay (models/utils.py:507-537 + Keras Adam)
 // var -= lr_decay * var (decoupled, before the Adam update); m,v update; var -= lr_adam * m / (sqrt(v) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, float lr_decay, float lr_adam, float b1, float b2, float eps) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float w = p[i];
-        w -= lr_decay * w;
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float w = p[i], mi = m[i], vi = v[i];
+        adamw_step(w, g[i], mi, vi, lr_decay, lr_adam, b1, b2, eps);
         m[i] = mi;
         v[i] = vi;
-        p[i] = w - lr_adam * mi / (sqrtf(vi) + eps);
+        p[i] = w;
     }
 }
 
@@ -678,34 +685,109 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // else gets it.  Same expressions per element as adamw_kernel (lr_decay = 0 there), so the two forms agree bit for bit.  Tensors start
 // on 16-byte boundaries of the flat buffer, so a float4 never straddles two tensors; the padding between them holds zeros.
 constexpr int ADAMW_MAX_RANGES = 256;
+__device__ __forceinline__ int adamw_first_range_ending_after(const long long* re, int nranges, long long i) {
+    int lo = 0, hi = nranges;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (re[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+// SKIP: elements inside the (sorted, disjoint) ranges of the pack descriptors belong to adamw_pack_tiles_kernel and are left alone here
+template <bool SKIP>
 __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                   long long n4, const long long* __restrict__ nodecay, int nranges, float lr_decay, float lr_adam,
-                                  float b1, float b2, float eps) {
+                                  float b1, float b2, float eps, const vf_adamw_pack_desc* __restrict__ descs, int ndesc) {
     __shared__ long long rs[ADAMW_MAX_RANGES], re[ADAMW_MAX_RANGES];
+    __shared__ long long ss[SKIP ? ADAMW_MAX_RANGES : 1], se[SKIP ? ADAMW_MAX_RANGES : 1];
     for (int i = threadIdx.x; i < nranges; i += blockDim.x) { rs[i] = nodecay[2 * i]; re[i] = nodecay[2 * i + 1]; }
+    if (SKIP)
+        for (int i = threadIdx.x; i < ndesc; i += blockDim.x) { ss[i] = descs[i].offset; se[i] = descs[i].offset + (long long)descs[i].rows * descs[i].cols; }
     __syncthreads();
     for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4;
-        int lo = 0, hi = nranges;                       // first range with end > i
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (re[mid] > i) hi = mid; else lo = mid + 1;
+        if (SKIP) {
+            const int k = adamw_first_range_ending_after(se, ndesc, i);
+            if (k < ndesc && ss[k] <= i) continue;
         }
+        const int lo = adamw_first_range_ending_after(re, nranges, i);
         const float ld = (lo < nranges && rs[lo] <= i) ? 0.f : lr_decay;
         f32x4 w = *reinterpret_cast<const f32x4*>(p + i);
         const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i);
         f32x4 mi = *reinterpret_cast<const f32x4*>(m + i), vi = *reinterpret_cast<const f32x4*>(v + i);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float we = w[e];
-            we -= ld * we;
-            mi[e] = b1 * mi[e] + (1.f - b1) * gi[e];
-            vi[e] = b2 * vi[e] + (1.f - b2) * gi[e] * gi[e];
-            w[e] = we - lr_adam * mi[e] / (sqrtf(vi[e]) + eps);
-        }
+        for (int e = 0; e < 4; ++e) { float we = w[e], me = mi[e], ve = vi[e]; adamw_step(we, gi[e], me, ve, ld, lr_adam, b1, b2, eps); w[e] = we; mi[e] = me; vi[e] = ve; }
         *reinterpret_cast<f32x4*>(m + i) = mi;
         *reinterpret_cast<f32x4*>(v + i) = vi;
         *reinterpret_cast<f32x4*>(p + i) = w;
+    }
+}
+
+// Round 6: the optimizer step and the bf16 re-packing of the dense layers' weights in ONE pass.  The step used to end with adamw_flat (reads w g m v,
+// writes w m v) followed by pack_bf16_multi, which read every fp32 weight again TWICE (the [K][N] packing for x @ W and the [N][K] packing for dY @ W^T):
+// 0.7 GB of re-reads per step for 88 M weights.  Here a block owns a 16-row x 128-column tile of one weight matrix [rows][cols]: it updates the tile
+// (adamw_step: the same expressions, bit-identical parameters and moments), parks the new weights' bf16 roundings in LDS and writes both packings'
+// 16-byte groups from there —
+//   dst_kn ([K = rows][N = cols] operand, fragment-major [K/64][N/128][ks 4][half 2][n 128][8 k]): the tile is one (k-chunk, ks) x both halves x one
+//          128-column block = 256 consecutive groups, 4 KB contiguous;
+//   dst_nk ([K = cols][N = rows] operand): 16 column groups x 16 rows, 256-byte runs.
+// The layouts are gemm_bf16.hip's (CK = 64, BN = 128); tests/test_train.py compares the result with adamw_flat + pack_bf16_multi bit for bit.
+constexpr int AP_ROWS = 16, AP_COLS = 128, AP_LD = AP_COLS + 8, AP_CK = 64, AP_BN = 128;
+__global__ __launch_bounds__(256) void adamw_pack_tiles_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                               float lr_decay, float lr_adam, float b1, float b2, float eps,
+                                                               const vf_adamw_pack_desc* __restrict__ descs) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    __shared__ __attribute__((aligned(16))) __bf16 tile[AP_ROWS * AP_LD];
+    const vf_adamw_pack_desc d = descs[blockIdx.y];
+    if ((d.rows % AP_BN) != 0 || (d.cols % AP_COLS) != 0 || (d.offset & 3)) return;        // (vf_adamw_pack_check refuses such a table on the host)
+    const float ld = d.nodecay ? 0.f : lr_decay;                      // (a whole tensor either decays or not; a per-block search of the range table
+                                                                      // was eight dependent global loads in front of every tile: 750 us per step)
+    const int t = threadIdx.x;
+    const int tcols = d.cols / AP_COLS, ntiles = (d.rows / AP_ROWS) * tcols;
+    const int nb_kn = d.cols / AP_BN, nb_nk = (d.rows + AP_BN - 1) / AP_BN;
+    __bf16* __restrict__ dkn = reinterpret_cast<__bf16*>(d.dst_kn);
+    __bf16* __restrict__ dnk = reinterpret_cast<__bf16*>(d.dst_nk);
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int tr = ti / tcols, tc = ti - tr * tcols;
+        const int r0 = tr * AP_ROWS, c0 = tc * AP_COLS;
+        {   // update: thread (row t >> 4, eight columns (t & 15) * 8)
+            const int r = t >> 4, c8 = (t & 15) * 8;
+            const long long i = d.offset + (long long)(r0 + r) * d.cols + c0 + c8;
+            bf16x8_t o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 w = *reinterpret_cast<const f32x4*>(p + i + 4 * h);
+                const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i + 4 * h);
+                f32x4 mi = *reinterpret_cast<const f32x4*>(m + i + 4 * h), vi = *reinterpret_cast<const f32x4*>(v + i + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float we = w[e], me = mi[e], ve = vi[e]; adamw_step(we, gi[e], me, ve, ld, lr_adam, b1, b2, eps); w[e] = we; mi[e] = me; vi[e] = ve; }
+                *reinterpret_cast<f32x4*>(m + i + 4 * h) = mi;
+                *reinterpret_cast<f32x4*>(v + i + 4 * h) = vi;
+                *reinterpret_cast<f32x4*>(p + i + 4 * h) = w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = (__bf16)w[e];
+            }
+            *reinterpret_cast<bf16x8_t*>(tile + r * AP_LD + c8) = o;
+        }
+        __syncthreads();
+        if (dkn) {  // [K = rows][N = cols]: group (half = t >> 7, n = t & 127) = rows half * 8 .. + 7 of column n
+            const int half = t >> 7, nl = t & 127;
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = tile[(half * 8 + e) * AP_LD + nl];
+            const int chunk = r0 / AP_CK, ks = (r0 % AP_CK) >> 4;
+            const long long gi = ((((long long)chunk * nb_kn + tc) * 4 + ks) * 2 + half) * AP_BN + nl;
+            *reinterpret_cast<bf16x8_t*>(dkn + gi * 8) = o;
+        }
+        if (dnk) {  // [K = cols][N = rows]: group (eight columns j * 8 .., row rr)
+            const int j = t >> 4, rr = t & 15;
+            const bf16x8_t o = *reinterpret_cast<const bf16x8_t*>(tile + rr * AP_LD + j * 8);
+            const int c = c0 + j * 8, row = r0 + rr;
+            const int chunk = c / AP_CK, ks = (c % AP_CK) >> 4, half = (c & 15) >> 3;
+            const long long gi = ((((long long)chunk * nb_nk + row / AP_BN) * 4 + ks) * 2 + half) * AP_BN + (row % AP_BN);
+            *reinterpret_cast<bf16x8_t*>(dnk + gi * 8) = o;
+        }
+        __syncthreads();
     }
 }
 
@@ -1076,8 +1158,41 @@ int vf_adamw_flat_f32(float* param, const float* grad, float* m, float* v, int64
     if (!param || !grad || !m || !v || n < 0 || nranges < 0 || (nranges > 0 && !nodecay_ranges)) return VF_ERR_BAD_ARG;
     if ((n & 3) || nranges > ADAMW_MAX_RANGES || (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15)) return VF_ERR_UNSUPPORTED;
     if (n == 0) return VF_OK;
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid1(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
-                       (long long)(n / 4), reinterpret_cast<const long long*>(nodecay_ranges), nranges, lr_decay, lr_adam, beta1, beta2, eps);
+    hipLaunchKernelGGL(adamw_flat_kernel<false>, dim3(grid1(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                       (long long)(n / 4), reinterpret_cast<const long long*>(nodecay_ranges), nranges, lr_decay, lr_adam, beta1, beta2, eps,
+                       (const vf_adamw_pack_desc*)nullptr, 0);
+    return vf_last_status();
+}
+
+size_t vf_sizeof_adamw_pack_desc(void) { return sizeof(vf_adamw_pack_desc); }
+
+int vf_adamw_pack_check(const vf_adamw_pack_desc* descs_host, int ndesc, int64_t n) {
+    if (!descs_host || ndesc <= 0 || n < 0) return VF_ERR_BAD_ARG;
+    if (ndesc > ADAMW_MAX_RANGES) return VF_ERR_UNSUPPORTED;
+    int64_t prev_end = 0;
+    for (int i = 0; i < ndesc; ++i) {
+        const vf_adamw_pack_desc& d = descs_host[i];
+        if (d.rows <= 0 || d.cols <= 0 || d.offset < prev_end || (!d.dst_kn && !d.dst_nk)) return VF_ERR_BAD_ARG;      // sorted, disjoint
+        if ((d.rows % AP_BN) || (d.cols % AP_COLS) || (d.offset & 3)) return VF_ERR_UNSUPPORTED;      // (whole 128-blocks both ways: the packings have no padding to zero)
+        if (((uintptr_t)d.dst_kn | (uintptr_t)d.dst_nk) & 15) return VF_ERR_UNSUPPORTED;
+        prev_end = d.offset + (int64_t)d.rows * d.cols;
+        if (prev_end > n) return VF_ERR_BAD_ARG;
+    }
+    return VF_OK;
+}
+
+int vf_adamw_flat_pack_f32(float* param, const float* grad, float* m, float* v, int64_t n, const int64_t* nodecay_ranges, int nranges,
+                           float lr_decay, float lr_adam, float beta1, float beta2, float eps, const vf_adamw_pack_desc* descs_device, int ndesc,
+                           void* stream) {
+    if (!param || !grad || !m || !v || n < 0 || nranges < 0 || (nranges > 0 && !nodecay_ranges) || !descs_device || ndesc <= 0) return VF_ERR_BAD_ARG;
+    if ((n & 3) || nranges > ADAMW_MAX_RANGES || ndesc > ADAMW_MAX_RANGES || (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15))
+        return VF_ERR_UNSUPPORTED;
+    if (n == 0) return VF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamw_pack_tiles_kernel, dim3(1024, (unsigned)ndesc), dim3(256), 0, s, param, grad, m, v, lr_decay, lr_adam, beta1, beta2, eps,
+                       descs_device);
+    hipLaunchKernelGGL(adamw_flat_kernel<true>, dim3(grid1(n / 4, 256, 8192)), dim3(256), 0, s, param, grad, m, v, (long long)(n / 4),
+                       reinterpret_cast<const long long*>(nodecay_ranges), nranges, lr_decay, lr_adam, beta1, beta2, eps, descs_device, ndesc);
     return vf_last_status();
 }
 

@@ -175,7 +175,9 @@ class MIGTTrainer:
             shape = tuple(h[n].shape)
             k = int(np.prod(shape))
             self.slices[n] = (off, off + k, shape)
-            off += (k + 3) // 4 * 4                      # keep every tensor 16-byte aligned
+            off += (k + 127) // 128 * 128                # every tensor starts on a 512-byte boundary (float4 kernels need 16; the fused optimizer's
+                                                         # 16 x 128 tiles write whole 128-byte lines only when a matrix row starts on one — with the
+                                                         # 7-wide pose tensors in front, 16-byte alignment left every tile edge a shared line)
         self.total = off
         self.head_range = (0, self.slices[layers[0][0]][0] if layers else off)
         self.layer_ranges = [(self.slices[l[0]][0], self.slices[l[-1]][1]) for l in layers]
@@ -226,6 +228,7 @@ class MIGTTrainer:
         lm16 = bf16 and self.bf16_lm_head and d % 256 == 0 and nE % 256 == 0
         if lm16 and self._lm16 is None:
             self._pack16 = None                                  # (the LM-head packings join the descriptor table: rebuild it)
+            self._adam_pack = None
         if self._pack16 is not None and (not bf16 or any(
                 dn.wp16 is None or name not in self.wpT16 for name, dn in m._dense.items()
                 if dn.k % 128 == 0 and dn.n % 128 == 0)):
@@ -234,7 +237,9 @@ class MIGTTrainer:
             self._pack16 = None
             self._pack16_keep = None
             self._layer_pack_ranges = None
-        if self._pack16 is not None:
+            self._adam_pack = None
+        packs_fresh, self._packs_fresh = self._packs_fresh, False
+        if self._pack16 is not None and not packs_fresh:          # (fresh: apply_gradients' fused optimizer wrote them with the update)
             if self._early_layers_done and self._layer_pack_ranges is not None:
                 # the layers' packings were refreshed right after their early update (train_step): only the rest of the table here
                 lo = min(a for a, n_ in self._layer_pack_ranges)
@@ -280,6 +285,17 @@ class MIGTTrainer:
         if bf16 and self._pack16 is None and pack_items and self.one_launch_repack:
             self._pack16 = ops.pack_bf16_multi(pack_items)          # (re-packs once more; from now on the closure is the refresh)
             self._pack16_keep = pack_items                          # (the closure holds raw pointers: keep the tensors alive with it)
+            # the same packings as destinations of the fused optimizer (apply_gradients): one descriptor per weight matrix with both of its
+            # packed forms; None when a packing's source is not a whole [rows][cols] view of the flat buffer or a shape does not tile
+            by_src, ok = {}, True
+            for w, tr, out in pack_items:
+                e = by_src.setdefault(w.data_ptr(), [w, None, None])
+                ok = ok and e[0].shape == w.shape and e[2 if tr else 1] is None
+                e[2 if tr else 1] = out
+            if self._nodecay is None:
+                r = [[self.slices[n][0], self.slices[n][1]] for n in self.names if 'bias' in n]
+                self._nodecay = torch.tensor(sorted(r), dtype=torch.int64, device=self.dev).reshape(-1, 2)
+            self._adam_pack = T.adamw_pack_table(self.flat_p, [tuple(e) for e in by_src.values()], self._nodecay) if ok else None
             # descriptor ranges per transformer layer (early_optimizer: a layer's weights are re-packed as soon as they are updated); valid only
             # when every layer's descriptors are contiguous and every wide layer weight is in the table
             rng, ok = [], True
@@ -383,6 +399,10 @@ class MIGTTrainer:
                                       # that layer's gradients are final (its backward and weight-gradient GEMMs done, its all-reduce complete) — HBM-bound
                                       # work beside the matrix-bound backward of the layers below instead of 0.65 ms at the end of the step.  Same kernels on
                                       # the same values: the parameters after a step are bit-identical (tests/test_train.py)
+    fused_optimizer_repack = True     # bf16 arm: the optimizer step writes the dense layers' bf16 packings from the updated weights in the same pass
+                                      # (vf_adamw_flat_pack_f32) instead of a re-pack launch that reads every weight again twice; bit-identical
+    _adam_pack = None
+    _packs_fresh = False
     _opt_stream_obj = None
     _layer_pack_ranges = None
     _early_layers_done = False
@@ -947,6 +967,10 @@ class MIGTTrainer:
                 T.adamw_flat_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
                               self._head_nodecay if c.weight_decay > 0 else None, lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam,
                               self.b1, self.b2, self.eps)
+            elif self.fused_optimizer_repack and self._adam_pack is not None and self._pack16 is not None:
+                T.adamw_flat_pack_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self._nodecay if c.weight_decay > 0 else None,
+                                   lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam, self.b1, self.b2, self.eps, self._adam_pack)
+                self._packs_fresh = True
             else:
                 T.adamw_flat_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self._nodecay if c.weight_decay > 0 else None,
                               lr * c.weight_decay if c.weight_decay > 0 else 0.0, lr_adam, self.b1, self.b2, self.eps)

@@ -171,6 +171,46 @@ def adamw_flat_(param, grad, m, v, nodecay_ranges, lr_decay, lr_adam, beta1, bet
                                         _stream()), 'vf_adamw_flat_f32')
 
 
+def adamw_pack_table(flat_param, items, nodecay_ranges=None):
+    """descriptor table of vf_adamw_flat_pack_f32.  ``items`` = [(w, packed_kn or None, packed_nk or None)] with every ``w`` a contiguous 2-D fp32
+    VIEW into ``flat_param`` (rows % 128 == 0, cols % 128 == 0), ``packed_kn`` the bf16 buffer ops.pack_dense_kn_bf16(w) fills, ``packed_nk`` the
+    one ops.pack_dense_nk_bf16(w) fills; ``nodecay_ranges`` = the [R][2] element ranges adamw_flat_pack_ will be given (a matrix inside one
+    carries the flag in its descriptor).  Returns (device table, n) after the library validated the host copy; None when a shape does not tile."""
+    import numpy as np
+    lib = _lib.load()
+    dt = np.dtype([('offset', '<i8'), ('dst_kn', '<u8'), ('dst_nk', '<u8'), ('rows', '<i4'), ('cols', '<i4'), ('nodecay', '<i4'), ('reserved', '<i4')])
+    assert dt.itemsize == _lib.ADAMW_PACK_DESC_BYTES
+    base, rows_ = _f32(flat_param).data_ptr(), []
+    nd = [] if nodecay_ranges is None else [tuple(int(x) for x in r) for r in nodecay_ranges.cpu().tolist()]
+    for w, kn, nk in items:
+        _f32(w)
+        assert w.dim() == 2 and w.is_contiguous() and (w.data_ptr() - base) % 4 == 0
+        off = (w.data_ptr() - base) // 4
+        assert 0 <= off and off + w.numel() <= flat_param.numel()
+        for buf, (K, N) in ((kn, w.shape), (nk, (w.shape[1], w.shape[0]))):
+            if buf is not None:
+                _chk(buf, torch.bfloat16)
+                assert buf.numel() >= int(lib.vf_gemm_bf16_packed_elems(K, N))
+        inside = [a <= off and off + w.numel() <= b for a, b in nd]
+        assert all(i or b <= off or off + w.numel() <= a for i, (a, b) in zip(inside, nd)), 'a no-decay range cuts a weight matrix'
+        rows_.append((off, 0 if kn is None else kn.data_ptr(), 0 if nk is None else nk.data_ptr(), w.shape[0], w.shape[1], int(any(inside)), 0))
+    a = np.array(sorted(rows_), dtype=dt)
+    rc = lib.vf_adamw_pack_check(a.ctypes.data, len(a), flat_param.numel())
+    if rc == -2:                                                   # VF_ERR_UNSUPPORTED: a shape that does not tile
+        return None
+    check(rc, 'vf_adamw_pack_check')
+    return torch.from_numpy(a.view(np.uint8).copy()).to(flat_param.device), len(a)
+
+
+def adamw_flat_pack_(param, grad, m, v, nodecay_ranges, lr_decay, lr_adam, beta1, beta2, eps, table):
+    """adamw_flat_ with the bf16 re-packing of the table's weight matrices in the same pass (bit-identical to adamw_flat_ + ops.pack_bf16_multi)"""
+    descs, n = table
+    check(_lib.load().vf_adamw_flat_pack_f32(_p(_f32(param)), _p(_f32(grad)), _p(_f32(m)), _p(_f32(v)), param.numel(),
+                                             _p(nodecay_ranges) if nodecay_ranges is not None and nodecay_ranges.numel() else None,
+                                             0 if nodecay_ranges is None else nodecay_ranges.shape[0], lr_decay, lr_adam, beta1, beta2, eps,
+                                             descs.data_ptr(), n, _stream()), 'vf_adamw_flat_pack_f32')
+
+
 def add_(a, b):
     check(_lib.load().vf_add_inplace_f32(_p(_f32(a)), _p(_f32(b)), a.numel(), _stream()), 'vf_add_inplace_f32')
     return a
