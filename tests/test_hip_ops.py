@@ -328,3 +328,28 @@ def test_conv3_small_cout(dev, cin, cout, H, W, pro):
     _close(out.view(n, H, W, cout).permute(0, 3, 1, 2), ref, 3e-5, 3e-5, 'conv_out')
     with pytest.raises(ops._lib.VfError):
         ops.conv3_small_cout(xn.view(-1, cin), _rand((8, cin, 3, 3), 1).to(dev), None, n, H, W, cin, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_img,nslots,C', [(7, 64, 128), (3, 16, 512), (5, 1, 256), (2, 37, 128), (33, 4, 64), (3, 128, 128), (2, 200, 64), (1, 512, 128)])
+def test_groupnorm_finalize_eight_lane_form_equals_the_wave_form(dev, n_img, nslots, C):
+    """round 6: for <= 512 partial slots vf_groupnorm_finalize_f32 reduces on eight lanes per (image, group) in the wave kernel's butterfly order.  The same
+    partials zero-padded to 513 slots take the wave kernel (the extra slots add exact zeros): mean and scale must agree bit for bit; both against fp64."""
+    from viewformer_amd import ops
+    g = torch.Generator().manual_seed(n_img * 100 + nslots)
+    HW = 64 * nslots
+    cnt = HW * (C // 32) / nslots
+    s1 = torch.randn(n_img, nslots, 32, generator=g) * cnt ** 0.5 + 0.3 * cnt
+    s2 = (torch.rand(n_img, nslots, 32, generator=g) + 0.5) * cnt + s1 * s1 / cnt
+    part = torch.stack([s1, s2], -1).contiguous()
+    gamma = torch.randn(C, generator=g)
+    padded = torch.zeros(n_img, 513, 32, 2)                             # (slots past 512: the wave kernel; the extra slots add exact zeros)
+    padded[:, :nslots] = part
+    m8, s8 = ops.groupnorm_finalize(part.to(dev), gamma.to(dev), n_img, HW, C)
+    mw, sw = ops.groupnorm_finalize(padded.to(dev), gamma.to(dev), n_img, HW, C)
+    assert torch.equal(m8.view(torch.int32), mw.view(torch.int32)) and torch.equal(s8.view(torch.int32), sw.view(torch.int32))
+    tot = part.double().sum(1) / (HW * (C // 32))
+    mean = tot[..., 0]
+    rstd = 1.0 / torch.sqrt((tot[..., 1] - mean * mean).clamp_min(0) + 1e-6)
+    assert torch.allclose(m8.cpu().double(), mean.repeat_interleave(C // 32, 1), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(s8.cpu().double(), rstd.repeat_interleave(C // 32, 1) * gamma.double(), rtol=2e-6, atol=1e-7)

@@ -1444,3 +1444,48 @@ def test_fused_optimizer_repack_leaves_the_same_trainer_state_bit_for_bit(dev):
     assert len(res[0]) == len(res[1])
     for a, b in zip(*res):
         assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+
+
+@pytest.mark.gpu
+def test_lazy_gradient_zero_gives_the_same_step_and_never_leaves_a_stale_gradient(dev):
+    """MIGTTrainer.lazy_gradient_zero: the layers' gradient tensors are not zero-filled, their first writer stores.  Three steps with it and with the
+    whole-buffer fill: gradients, parameters, moments and losses equal; the fp32-equivalent arm (accumulating fallback writers) as well; a tensor
+    that no kernel wrote is zero-filled when its layer's backward ends, whatever the buffer held."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(sequence_size=4, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.1, learning_rate=1e-3, weight_decay=0.05,
+                     total_steps=1000, batch_size=2, n_layer=2)
+    sd = make_migt_weights(cfg, seed=3)
+    g = np.random.Generator(np.random.PCG64(5))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(2, 4, 8, 8)))
+    poses = torch.from_numpy(g.standard_normal((2, 4, 7)).astype(np.float32))
+    for precision in ('bf16', 'f32'):
+        res = []
+        for lazy in (False, True):
+            tr = MIGTTrainer(MIGT(cfg, precision=precision).load_state_dict(sd).to(dev))
+            tr.lazy_gradient_zero = lazy
+            tr.flat_g.fill_(float('nan'))                              # whatever the buffer held
+            losses = [tr.train_step(poses, tokens)['loss'].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            assert not tr._unset and torch.isfinite(tr.flat_g).all()
+            res.append([tr.flat_g.clone(), tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone(), torch.stack(losses)])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev))
+    tr.flat_g.fill_(7.0)
+    tr._begin_gradients()
+    a, b = tr.head_range
+    assert float(tr.flat_g[a:b].abs().max()) == 0.0 and len(tr._unset) == 6 * cfg.n_layer
+    assert tr._first_write('h.1.mlp.c_fc') and not tr._first_write('h.1.mlp.c_fc') and not tr._first_write('ln_f')
+    tr._flush_unset('h.1.')
+    a1, b1 = tr.layer_ranges[1]
+    kept = tr.g('h.1.mlp.c_fc.weight')                                 # its writer was announced: not flushed
+    assert float(kept.min()) == 7.0
+    z = tr.flat_g[a1:b1].clone()
+    lo, hi = tr.slices['h.1.mlp.c_fc.weight'][0] - a1, tr.slices['h.1.mlp.c_fc.bias'][1] - a1
+    z[lo:hi] = 0
+    assert float(z.abs().max()) == 0.0 and len(tr._unset) == 6
+    tr._flush_unset()
+    assert not tr._unset and float(tr.flat_g[tr.layer_ranges[0][0]:tr.layer_ranges[0][1]].abs().max()) == 0.0

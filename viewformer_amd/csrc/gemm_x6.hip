@@ -237,8 +237,19 @@ __global__ void pack_gemm_x6_kernel(const float* __restrict__ src, __bf16* __res
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long n4,
                                  float* __restrict__ dst, int accumulate) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(dst + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nslabs; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + s * stride + i * 4);
+        // eight slabs' loads in flight, added in slab order (the sums are the one-load-at-a-time loop's bit for bit: that loop's trip count is a
+        // run-time value, so the compiler kept it rolled — six dependent load latencies per element for the training step's five slabs + dst)
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accumulate) acc = *reinterpret_cast<const f32x4*>(dst + i * 4);
+        for (int s0 = 0; s0 < nslabs; s0 += 8) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nslabs) x[u] = *reinterpret_cast<const f32x4*>(slabs + (s0 + u) * stride + i * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nslabs) acc += x[u];
+        }
         *reinterpret_cast<f32x4*>(dst + i * 4) = acc;
     }
 }

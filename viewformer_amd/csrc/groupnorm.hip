@@ -102,6 +102,66 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// The same reduction for nsplit <= 512 on EIGHT lanes per (image, group) instead of a wave (896 images x 32 groups = 28 672 waves per launch, 67 launches per
+// inference step at 11 us each, most of it waves whose lanes hold one value or none): lane j of an item holds, for k < 8, the wave kernel's lane j + 8 k (its slots j + 8 k + 64 r added in ascending order) and adds the eight in the wave kernel's
+// butterfly order — (k, k + 4) is its xor-32 level, (k, k + 2) xor 16, (k, k + 1) xor 8 — then three shuffles finish levels xor 4, 2, 1: the same additions of
+// the same doubles (addition commutes), so mean and scale are bit-identical.
+__global__ __launch_bounds__(256) void gn_finalize8_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                           float* __restrict__ mean_c, float* __restrict__ scale_c, int n_img,
+                                                           int HW, int C, int groups, int nsplit, float eps) {
+    const int j = threadIdx.x & 7;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = i < n_img * groups;                  // (dead items keep their lanes in the shuffles)
+    const int ii = live ? i : 0;
+    const int img = ii / groups, g = ii - img * groups;
+    double a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = 0.0; b[k] = 0.0; }
+    for (int s0 = j; s0 < nsplit; s0 += 64) {              // (a round = the wave kernel's lanes j + 8 k, k < 8, at their next slot: eight loads in flight)
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = s0 + 8 * k;
+            v[k] = make_float2(0.f, 0.f);
+            if (s < nsplit) v[k] = *reinterpret_cast<const float2*>(part + (((size_t)img * nsplit + s) * groups + g) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + 8 * k < nsplit) { a[k] += (double)v[k].x; b[k] += (double)v[k].y; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] += a[k + 4]; b[k] += b[k + 4]; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { a[k] += a[k + 2]; b[k] += b[k + 2]; }
+    double sa = a[0] + a[1], sb = b[0] + b[1];
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        sa += __shfl_xor(sa, o, 64);
+        sb += __shfl_xor(sb, o, 64);
+    }
+    if (!live) return;
+    const int cg = C / groups;
+    const double cnt = (double)HW * cg;
+    const double mean = sa / cnt;
+    double var = sb / cnt - mean * mean;   // biased variance, as torch
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    for (int k = j; k < cg; k += 8) {
+        const int c = g * cg + k;
+        mean_c[(size_t)img * C + c] = fmean;
+        scale_c[(size_t)img * C + c] = rstd * gamma[c];
+    }
+}
+static void gn_finalize_launch(hipStream_t s, const float* part, const float* gamma, float* mean_c, float* scale_c, int n_img, int HW, int C, int groups,
+                               int nsplit, float eps) {
+    const int n = n_img * groups;
+    if (nsplit <= 512)
+        hipLaunchKernelGGL(gn_finalize8_kernel, dim3((n + 31) / 32), dim3(256), 0, s, part, gamma, mean_c, scale_c, n_img, HW, C, groups, nsplit, eps);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, part, gamma, mean_c, scale_c, n_img, HW, C, groups, nsplit, eps);
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_c,
                                                        const float* __restrict__ scale_c, const float* __restrict__ beta,
                                                        float* __restrict__ out, long long total4, int HW, int C,
@@ -153,9 +213,7 @@ int vf_groupnorm_stats_f32(const float* x, const float* gamma, int n_img, int HW
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, n_img), dim3(256), 0, s, x, (float*)ws, HW, C, groups, nsplit);
     int st = vf_last_status();
     if (st) return st;
-    const int n = n_img * groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)ws, gamma, mean_c,
-                       scale_c, n_img, HW, C, groups, nsplit, eps);
+    gn_finalize_launch(s, (const float*)ws, gamma, mean_c, scale_c, n_img, HW, C, groups, nsplit, eps);
     return vf_last_status();
 }
 
@@ -163,9 +221,7 @@ int vf_groupnorm_finalize_f32(const float* part, const float* gamma, int n_img, 
                               float eps, float* mean_c, float* scale_c, void* stream) {
     if (!part || !gamma || !mean_c || !scale_c || n_img <= 0 || HW <= 0 || nslots <= 0) return VF_ERR_BAD_ARG;
     if (C <= 0 || groups <= 0 || C % groups != 0) return VF_ERR_UNSUPPORTED;
-    const int n = n_img * groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, gamma, mean_c,
-                       scale_c, n_img, HW, C, groups, nslots, eps);
+    gn_finalize_launch((hipStream_t)stream, part, gamma, mean_c, scale_c, n_img, HW, C, groups, nslots, eps);
     return vf_last_status();
 }
 

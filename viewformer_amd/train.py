@@ -336,6 +336,7 @@ class MIGTTrainer:
         dn = self.model._dense[name]
         K, N = dn.k, dn.n
         bf16 = name in self.wpT16 and dn.wp16 is not None and M % 128 == 0
+        first = self._first_write(name)                   # (lazy_gradient_zero: this layer's gradient pair holds last step's values, not zeros)
         if bf16 and self.tn_weight_gradient and ops.gemm_tn_bf16_supported(x, M, K, N):
             # bf16 arm with a saved bf16 activation: dW and db in ONE pass over x and dy as they lie (csrc/gemm_tn_bf16.hip) — no widening
             # transpose of x, no packed bf16 copy of dy, no column-sum pass
@@ -348,17 +349,20 @@ class MIGTTrainer:
                 side = self._side()
                 side.wait_stream(main)                                                 # dy (and x) are complete
                 with torch.cuda.stream(side):
-                    ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, beside_another_gemm=True)
+                    ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, accumulate=not first, beside_another_gemm=True)
                 for t in (x, dy):
                     t.record_stream(side)                                              # (the allocator must not recycle them under the side stream)
                 self._side_busy = True
             else:
                 # (alone on the compute stream the launch takes the full-machine split, another summation order; serial_wgrad_split_as_overlapped
                 # keeps the second stream's split, for bit-for-bit comparisons of the two modes)
-                ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, beside_another_gemm=self.serial_wgrad_split_as_overlapped and need_dx)
+                ops.gemm_tn_bf16(x, dy, M, K, N, gw, gb, accumulate=not first, beside_another_gemm=self.serial_wgrad_split_as_overlapped and need_dx)
             return self._linear_dx(name, dy, M, res, dx_bf16, gelu_bwd_u) if need_dx else None
         if dy.dtype != torch.float32:
             raise RuntimeError('a bf16 gradient operand needs the TN weight-gradient path')
+        if first:                                          # the paths below accumulate
+            self.g(name + '.weight').zero_()
+            self.g(name + '.bias').zero_()
         T.colsum(dy, self.g(name + '.bias'), M, N, accumulate=True)
         Mp = (M + 31) // 32 * 32                                                     # reduction length padded to the K stage
         xt = None
@@ -492,10 +496,49 @@ class MIGTTrainer:
             ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
+    lazy_gradient_zero = True         # the transformer layers' gradient tensors (85 M of the 88 M) are not zero-filled at the start of a step: each is written
+                                      # exactly once per step, so its first writer STORES (sum_slabs / LayerNorm backward with accumulate off) instead of adding
+                                      # to a zero — one 337 MB fill and one 337 MB read of zeros less per step.  Keys still unset when a layer's (or the
+                                      # step's) backward ends are zero-filled then, so a tensor no kernel wrote is a zero gradient, as before.  The head range
+                                      # (embeddings, pose heads, ln_f: several contributions each) is zero-filled as before.  Same bits: x + 0 == x.
+    _unset = frozenset()
+    _layer_grad_keys = None
+
+    def _begin_gradients(self):
+        if not (self.lazy_gradient_zero and self.layer_ranges):
+            self.flat_g.zero_()
+            self._unset = set()
+            return
+        if self._layer_grad_keys is None:
+            lo = self.layer_ranges[0][0]
+            self._layer_grad_keys = ([n[:-7] for n in self.names if n.endswith('.weight') and self.slices[n][0] >= lo and n[:-7] + '.bias' in self.slices]
+                                     + [n[:-6] for n in self.names if n.endswith('.gamma') and self.slices[n][0] >= lo and n[:-6] + '.beta' in self.slices])
+            covered = sum(self.slices[k + a][1] - self.slices[k + a][0] for k in self._layer_grad_keys
+                          for a in (('.weight', '.bias') if k + '.weight' in self.slices else ('.gamma', '.beta')))
+            if covered != sum(self.slices[n][1] - self.slices[n][0] for n in self.names if self.slices[n][0] >= lo):
+                raise RuntimeError('lazy_gradient_zero: a layer tensor is neither a dense layer\'s weight | bias nor a LayerNorm\'s gamma | beta')
+        a, b = self.head_range
+        self.flat_g[a:b].zero_()
+        self._unset = set(self._layer_grad_keys)
+
+    def _first_write(self, key):
+        """True once per step for a layer tensor pair that was not zero-filled: its writer must store, not accumulate"""
+        if key in self._unset:
+            self._unset.discard(key)
+            return True
+        return False
+
+    def _flush_unset(self, prefix=''):
+        """zero-fill what no kernel wrote (keys under ``prefix``)"""
+        for k in [k for k in self._unset if k.startswith(prefix)]:
+            for a in (('.weight', '.bias') if k + '.weight' in self.slices else ('.gamma', '.beta')):
+                self.g(k + a).zero_()
+            self._unset.discard(k)
+
     def _ln_bwd(self, name, dy, x, M, res=None, also_bf16=False, drop=(0.0, 0, 0)):
         d = self.cfg.d_model
-        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, res=res, also_bf16=also_bf16,
-                               drop=drop if also_bf16 else (0.0, 0, 0))
+        return T.layernorm_bwd(dy, x, self.p(name + '.gamma'), self.g(name + '.gamma'), self.g(name + '.beta'), M, d, accumulate=not self._first_write(name),
+                               res=res, also_bf16=also_bf16, drop=drop if also_bf16 else (0.0, 0, 0))
 
     bf16_preactivation = True         # bf16 arm, with both GELU fusions: c_fc's pre-activation u is SAVED as bf16 (the reference's mixed_float16 policy
                                       # keeps every activation in half precision); gelu(u) is still taken from the fp32 accumulator, gelu'(u)
@@ -615,7 +658,7 @@ class MIGTTrainer:
             raise ValueError('train_step needs sequences of at least 2 views (the STREAMS attention mask encodes the stream '
                              'length as -S <= -2; a 1-view sequence has nothing to condition on)')
         if not _forward_only:
-            self.flat_g.zero_()
+            self._begin_gradients()
 
         # ---- forward with saved activations --------------------------------------------------------------
         seed = self.step_seed(self.step_count)
@@ -839,6 +882,7 @@ class MIGTTrainer:
             dh, dh16 = dh if (res16 and i > 0) else (dh, None)
             saved[i] = None
             hd = None
+            self._flush_unset(p + '.')
             if overlap:                                                              # this layer's grads are final
                 self._join_side()
                 hd = self._allreduce_range(*self.layer_ranges[i])
@@ -857,6 +901,7 @@ class MIGTTrainer:
         T.dense_small_k_bwd(pin, du1, self.g('pose_embedding.c_fc.weight'), self.g('pose_embedding.c_fc.bias'), B * S, 7, fc.n)
 
         # ---- clip (per replica, per tensor, before aggregation), all-reduce SUM, AdamWeightDecay ------------
+        self._flush_unset()
         self._join_side()
         if c.gradient_clip_val and c.gradient_clip_val > 0:
             for n in self.names:
