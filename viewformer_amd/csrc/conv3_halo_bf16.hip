@@ -94,7 +94,7 @@ __device__ __forceinline__ void halo_epilogue16(const vf_igemm_args& p, const f3
                     for (int r = 0; r < 16; r += 2) {
                         const unsigned mine = rw[j][mi][r >> 1];
                         const unsigned give = odd ? (mine << 16) : (mine & 0xffff0000u);          // as fp32 bits
-                        const unsigned got = (unsigned)__shfl_xor((int)give, 1, 64);
+                        const unsigned got = vf_lane_xor1(give);
                         v[r] += __builtin_bit_cast(float, odd ? got : (mine << 16));
                         v[r + 1] += __builtin_bit_cast(float, odd ? (mine & 0xffff0000u) : got);
                     }
@@ -106,7 +106,7 @@ __device__ __forceinline__ void halo_epilogue16(const vf_igemm_args& p, const f3
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float give = odd ? v[r] : v[r + 1];
-                    const float got = __shfl_xor(give, 1, 64);
+                    const float got = vf_lane_xor1(give);
                     bf16x2_t h;
                     h[0] = (__bf16)(odd ? got : v[r]);
                     h[1] = (__bf16)(odd ? v[r + 1] : got);

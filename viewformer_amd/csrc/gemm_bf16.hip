@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_direct_kernel(vf_igemm_args 
                     for (int r = 0; r < 16; r += 2) {
                         // even lane: row r of columns (n, n+1); odd lane: row r+1 of columns (n-1, n)
                         const float give = odd ? t[r] : t[r + 1];
-                        const float got = __shfl_xor(give, 1, 64);
+                        const float got = vf_lane_xor1(give);
                         const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
                         bf16x2_t v;
                         v[0] = (__bf16)(odd ? got : t[r]);

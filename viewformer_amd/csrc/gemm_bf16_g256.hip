@@ -115,7 +115,7 @@ __device__ __forceinline__ void g256_store_f32(const vf_igemm_args& p, const f32
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float give = odd ? v[r] : v[r + 1];
-                    const float got = __shfl_xor(give, 1, 64);
+                    const float got = vf_lane_xor1(give);
                     const int row = ((r + odd) & 3) + 8 * ((r + odd) >> 2);
                     bf16x2_t h;
                     h[0] = (__bf16)(odd ? got : v[r]);
@@ -171,7 +171,7 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
                     for (int r = 0; r < 16; r += 2) {
                         const unsigned mine = w[r >> 1];
                         const unsigned give = odd ? (mine << 16) : (mine & 0xffff0000u);      // as fp32 bits: odd gives its low half, even its high half
-                        const unsigned got = (unsigned)__shfl_xor((int)give, 1, 64);
+                        const unsigned got = vf_lane_xor1(give);
                         uu[r] = __builtin_bit_cast(float, odd ? got : (mine << 16));
                         uu[r + 1] = __builtin_bit_cast(float, odd ? (mine & 0xffff0000u) : got);
                     }
@@ -211,7 +211,7 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float give = odd ? t[r] : t[r + 1];
-                    const float got = __shfl_xor(give, 1, 64);
+                    const float got = vf_lane_xor1(give);
                     const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
                     bf16x2_t v;
                     v[0] = (__bf16)(odd ? got : t[r]);

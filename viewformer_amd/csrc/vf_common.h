@@ -112,6 +112,12 @@ __device__ __forceinline__ float vf_gelu_erf_fast(float v) {
     return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
+// the value of the neighbouring lane (lane ^ 1) on the vector ALU's DPP path (quad_perm [1, 0, 3, 2]) — __shfl_xor(v, 1) is a ds_bpermute_b32: a trip
+// through the LDS pipeline with its address register and lgkmcnt wait; the bf16 epilogues exchange 64 values per thread and tile this way
+__device__ __forceinline__ int vf_lane_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned vf_lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float vf_lane_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+
 __device__ __forceinline__ float vf_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
