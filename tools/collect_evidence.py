@@ -78,7 +78,7 @@ def main():
     rows = [r for r in trace_rows(src) if any(k in r[0] for k in GEMM_FAMILY)]
     line = last_json_line(src) if '{"metric"' in body else None
     steps = (line['steps'] + line['warmup']) if line else 4
-    calls_adamw = [r[1] for r in trace_rows(src) if 'adamw_flat' in r[0]]
+    calls_adamw = [r[1] for r in trace_rows(src) if 'adamw_pack_tiles' in r[0] or 'adamw_flat' in r[0]]      # one optimizer launch per step
     n_steps = calls_adamw[0] if calls_adamw else steps
     tot = sum(r[3] for r in rows) / n_steps
     terms = ' + '.join(f'{r[3]:.3f} [{r[0][2:22]}]' for r in rows)
