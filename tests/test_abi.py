@@ -38,6 +38,7 @@ def test_host_queries(lib):
     from viewformer_amd import _lib as L
     assert int(lib.vf_sizeof_igemm_args()) == ctypes.sizeof(L.VfIgemmArgs)
     assert int(lib.vf_sizeof_pack_desc()) == L.PACK_DESC_BYTES
+    assert int(lib.vf_sizeof_adamw_pack_desc()) == L.ADAMW_PACK_DESC_BYTES
     assert lib.vf_build_arch() == b'gfx950'
     # [chunks=4][taps=9][nblk=1][32][128]
     assert lib.vf_igemm_packed_floats(128, 128, 9) == 4 * 9 * 32 * 128
@@ -46,6 +47,31 @@ def test_host_queries(lib):
     assert lib.vf_vq_packed_floats(256, 1024) == 256 * 1024
     assert lib.vf_vq_packed_floats(32, 64) == 32 * 128                     # codes padded to 128
     assert lib.vf_groupnorm_workspace_bytes(4, 16384, 128) == 4 * 64 * 256 * 2 * 4
+
+
+def test_adamw_pack_table_validation_is_host_side(lib):
+    """vf_adamw_pack_check (round 6) validates a HOST copy of the fused optimizer's descriptor table — no device, no launch: sorted disjoint ranges
+    inside the flat buffer, whole 128-blocks both ways, 16-byte aligned destinations, at least one destination, at most 256 descriptors."""
+    import numpy as np
+    from viewformer_amd import _lib as L
+    dt = np.dtype([('offset', '<i8'), ('dst_kn', '<u8'), ('dst_nk', '<u8'), ('rows', '<i4'), ('cols', '<i4'), ('nodecay', '<i4'), ('reserved', '<i4')])
+    assert dt.itemsize == L.ADAMW_PACK_DESC_BYTES
+
+    def check(rows, n=1 << 24):
+        a = np.array(rows, dtype=dt)
+        return lib.vf_adamw_pack_check(a.ctypes.data, len(a), n)
+    ok = [(0, 4096, 8192, 128, 256, 0, 0), (128 * 256, 0, 16384, 256, 128, 1, 0)]
+    assert check(ok) == 0
+    assert check(ok[::-1]) == -1                                           # not sorted
+    assert check([ok[0], (100, 4096, 0, 128, 128, 0, 0)]) == -1            # overlapping
+    assert check([(0, 0, 0, 128, 128, 0, 0)]) == -1                        # no destination
+    assert check([(0, 4096, 0, 128, 128, 0, 0)], n=128 * 128 - 4) == -1    # past the end of the flat buffer
+    assert check([(0, 4096, 0, 64, 128, 0, 0)]) == -2                      # rows % 128
+    assert check([(0, 4096, 0, 128, 192, 0, 0)]) == -2                     # cols % 128
+    assert check([(2, 4096, 0, 128, 128, 0, 0)]) == -2                     # offset % 4
+    assert check([(0, 4100, 0, 128, 128, 0, 0)]) == -2                     # destination alignment
+    assert check([(i * 128 * 128, 4096, 0, 128, 128, 0, 0) for i in range(257)], n=1 << 30) == -2
+    assert lib.vf_adamw_pack_check(None, 1, 16) == -1
 
 
 def test_shipped_library_has_no_developer_switch_compiled_in(lib):
