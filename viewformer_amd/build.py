@@ -76,6 +76,8 @@ VARIANTS = {
     'ln_bwd_rpb32': (['-DVF_LN_BWD_RPB=32'], ['train_ops']),
     # A/B only: the dQ kernel with a two-slot ring (48 KB: three workgroups per CU instead of two, one tile ahead instead of two)
     'dq_ring2': (['-DATB_DQ_RING=2'], ['attention_train_bf16']),
+    # A/B only: the dK / dV kernel's dropout words hashed by every lane (one per score) instead of once per lane quad (same words, same masks)
+    'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 
 

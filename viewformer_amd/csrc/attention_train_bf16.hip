@@ -466,14 +466,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
             for (int j = 0; j < 4; ++j) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + 256 + (32 * u + 8 * j + 4 * half) * 4);
+                // accumulator row r = 4 j + e = query 64 qt + 32 u + 8 j + e + 4 half; its mask word belongs to (query, key >> 2): the SAME word in the
+                // four lanes of a quad (keys 4 m .. 4 m + 3, each using its own byte).  Lane c of the quad hashes the word of e = c, a DPP quad
+                // broadcast hands it round: 4 hashes per 16 scores instead of 16 (two 8-cycle integer multiplies each) — same words, same masks
+                uint32_t w4[4] = {0u, 0u, 0u, 0u};
+                if constexpr (DROP) {
+                    const int wq = (int)vf_dropout_word(drop_key, drop_k + (uint32_t)(qt * 64 + 32 * u + 8 * j + (lane & 3)) * (uint32_t)(T >> 2));
+                    w4[0] = (uint32_t)__builtin_amdgcn_mov_dpp(wq, 0x00, 0xF, 0xF, true);      // quad_perm [0, 0, 0, 0]
+                    w4[1] = (uint32_t)__builtin_amdgcn_mov_dpp(wq, 0x55, 0xF, 0xF, true);      // [1, 1, 1, 1]
+                    w4[2] = (uint32_t)__builtin_amdgcn_mov_dpp(wq, 0xAA, 0xF, 0xF, true);      // [2, 2, 2, 2]
+                    w4[3] = (uint32_t)__builtin_amdgcn_mov_dpp(wq, 0xFF, 0xF, 0xF, true);      // [3, 3, 3, 3]
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * j + e;
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e] * LOG2E));
                     float dpr = dp[r];
                     bool keep = true;
-                    if constexpr (DROP) {                            // accumulator row r = query 64 qt + 32 u + 8 j + e + 4 half
+                    if constexpr (DROP) {
+#ifdef VF_X_DKV_HASH_PER_ELEMENT
                         const uint32_t w = vf_dropout_word(drop_key, drop_k + (uint32_t)(qt * 64 + 32 * u + 8 * j + e) * (uint32_t)(T >> 2));
+#else
+                        const uint32_t w = w4[e];
+#endif
                         keep = vf_dropout_keep(w, drop_j, drop_thresh);
                         dpr = keep ? dpr * drop_scale : 0.f;
                     }

@@ -302,6 +302,9 @@ VF_REG_FLAG(VF_X3H_X_NOPATCH)
 #ifdef VF_X6_CLOCKPROBE
 VF_REG_FLAG(VF_X6_CLOCKPROBE)
 #endif
+#ifdef VF_X_DKV_HASH_PER_ELEMENT      // A/B: the dK / dV kernel's dropout words hashed by every lane (round 5's form) instead of once per lane quad
+VF_REG_FLAG(VF_X_DKV_HASH_PER_ELEMENT)
+#endif
 #ifdef VF_X_TRINTRIN      // A/B: the transposing LDS reads through the compiler intrinsic again (hipcc then drains vmcnt in front of them)
 VF_REG_FLAG(VF_X_TRINTRIN)
 #endif
