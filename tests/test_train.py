@@ -608,22 +608,23 @@ def test_fused_output_dropout_of_the_projection_gemm(dev, M, K, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('rows,d', [(1920, 768), (19200, 768), (515, 256)])
-def test_layernorm_backward_masked_bf16_copy(dev, rows, d):
-    """layernorm_bwd(also_bf16=True, drop=...): the bf16 copy == bf16(dropout_add(dx)) of that site, while dx, dgamma, dbeta keep their bits"""
+@pytest.mark.parametrize('rows,d,row0', [(1920, 768, 0), (19200, 768, 0), (515, 256, 0), (1920, 768, 6400), (515, 512, 6), (77, 1024, 12), (64, 768, 3)])
+def test_layernorm_backward_masked_bf16_copy(dev, rows, d, row0):
+    """layernorm_bwd(also_bf16=True, drop=...): the bf16 copy == bf16(dropout_add(dx)) of that site, while dx, dgamma, dbeta keep their bits.
+    (row offsets of a data-parallel shard on and off a mask-group boundary)"""
     from viewformer_amd import train_ops as T
     g = np.random.Generator(np.random.PCG64(rows))
     dy, x, res = (torch.from_numpy(g.standard_normal((rows, d)).astype(np.float32)).to(dev) for _ in range(3))
     gamma = torch.from_numpy((1 + 0.1 * g.standard_normal(d)).astype(np.float32)).to(dev)
     outs = []
-    for drop in ((0.0, 0, 0), (0.1, 99, 17)):
+    for drop in ((0.0, 0, 0, 0), (0.1, 99, 17, row0)):
         dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
         dx, dx16 = T.layernorm_bwd(dy, x, gamma, dg, db, rows, d, res=res, also_bf16=True, drop=drop)
         outs.append((dx, dx16, dg, db))
     (dx0, c0, dg0, db0), (dx1, c1, dg1, db1) = outs
     assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
     assert torch.equal(c0, dx0.to(torch.bfloat16))
-    assert torch.equal(c1, T.dropout_add(dx0, 0.1, 99, 17).to(torch.bfloat16))
+    assert torch.equal(c1, T.dropout_add(dx0, 0.1, 99, 17, row0=row0).to(torch.bfloat16))
 
 
 @pytest.mark.gpu
