@@ -89,7 +89,11 @@ enum { VF_EPI_NONE = 0, VF_EPI_GELU_ERF = 1,
        VF_EPI_GELU_DUAL = 3 };  /* vf_gemm_bf16, bf16 activations in, 256-aligned shapes only: out = acc + bias (fp32, or bf16 with the
                                    bf16-output flag) AND out_aux = bf16(gelu(acc + bias)) — see vf_igemm_args.out_aux.
                                    vf_gemm_bf16's dtype flags live in reserved0: bit 0 bf16 activations in, bit 1 bf16 out, bit 2
-                                   (VF_EPI_GELU_BWD only) the pre-activation behind `res` is bf16 [M][ldr] */
+                                   (VF_EPI_GELU_BWD only) the pre-activation behind `res` is bf16 [M][ldr]; bit 3 (round 6, 256-tile shapes, bf16
+                                   out): the SAVED-DERIVATIVE forms — with VF_EPI_GELU_DUAL `out` receives bf16(gelu'(acc + bias)) instead of the
+                                   pre-activation (from the erf / exp evaluation of the GELU beside it, whose bits do not change), with
+                                   VF_EPI_GELU_BWD (bit 2 set) `res` holds that table and out = bf16(acc * res[m][n]): the backward's epilogue
+                                   loads what the forward already evaluated (VF_ERR_BAD_ARG on other combinations) */
 
 typedef struct vf_igemm_args {
     const float* x;          /* GEMM: [M][lda]; conv: NHWC [Nimg][Hin][Win][Cin] */

@@ -1490,3 +1490,78 @@ def test_lazy_gradient_zero_gives_the_same_step_and_never_leaves_a_stale_gradien
     assert float(z.abs().max()) == 0.0 and len(tr._unset) == 6
     tr._flush_unset()
     assert not tr._unset and float(tr.flat_g[tr.layer_ranges[0][0]:tr.layer_ranges[0][1]].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [512, 640, 19200])
+def test_saved_gelu_derivative_forms_of_the_256_tile_kernel(dev, M):
+    """round 6: VF_EPI_GELU_DUAL with gelu_grad writes gelu'(u) (bf16) where the plain form writes u — from the same erf / exp evaluation as the GELU
+    beside it, which keeps its bits — and VF_EPI_GELU_BWD with gelu_grad multiplies by that saved derivative.  gelu' against fp64 on the fp32
+    pre-activation: one bf16 rounding; the backward product against fp64 of (dy @ W) * gelu'(u): two bf16 roundings; the plain forms refuse the flag."""
+    from viewformer_amd import ops, _lib
+    K, N = 768, 3072
+    g = np.random.Generator(np.random.PCG64(M + 11))
+    x16 = torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    w = torch.from_numpy((g.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(g.standard_normal(N).astype(np.float32)).to(dev)
+    wp = ops.pack_dense_kn_bf16(w)
+    u32 = torch.empty((M, N), device=dev)
+    ops.igemm(x16, wp, M, K, N, u32, bias=b, bf16=True, a16=True)
+    u16, f = (torch.empty((M, N), dtype=torch.bfloat16, device=dev) for _ in range(2))
+    ops.igemm(x16, wp, M, K, N, u16, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=True, out_aux=f)
+    gp, f2 = torch.full_like(u16, float('nan')), torch.full_like(f, float('nan'))
+    ops.igemm(x16, wp, M, K, N, gp, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=True, out_aux=f2, gelu_grad=True)
+    assert torch.equal(f2, f)                                                  # the GELU output keeps its bits
+    ud = u32.double()
+    ref = 0.5 * (1 + torch.erf(ud / 2 ** 0.5)) + ud * torch.exp(-0.5 * ud * ud) / (2 * np.pi) ** 0.5
+    assert bool(((gp.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all())
+    # the backward epilogue on the saved derivative
+    dy16 = torch.from_numpy((g.standard_normal((M, N)) * 0.1).astype(np.float32)).to(dev).to(torch.bfloat16)
+    wt = ops.pack_dense_nk_bf16(w)                                              # dY @ W^T: [N][K] read as the transposed operand
+    du = torch.full((M, K), float('nan'), dtype=torch.bfloat16, device=dev)
+    gpk = gp[:, :K].contiguous()                                               # (any [M][K] bf16 table serves as the derivative)
+    ops.igemm(dy16, wt, M, N, K, du, res=gpk, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True, gelu_grad=True)
+    plain = torch.empty((M, K), device=dev)
+    ops.igemm(dy16, wt, M, N, K, plain, bf16=True, a16=True)
+    assert torch.equal(du, (plain * gpk.float()).to(torch.bfloat16))          # fp32 product of the GEMM's own sums and the loaded value, rounded once
+    # old form on the same operands for reference: gelu' evaluated in the epilogue from a bf16 u — the two agree to bf16 precision
+    du_old = torch.empty_like(du)
+    ops.igemm(dy16, wt, M, N, K, du_old, res=u16[:, :K].contiguous(), epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True)
+    gk = (0.5 * (1 + torch.erf(ud[:, :K] / 2 ** 0.5)) + ud[:, :K] * torch.exp(-0.5 * ud[:, :K] ** 2) / (2 * np.pi) ** 0.5)
+    want = plain.double() * gk
+    tol = want.abs() * 2 ** -6 + 1e-3 * float(plain.abs().max())
+    assert bool(((du.double() - want).abs() <= tol).all()) and bool(((du_old.double() - want).abs() <= tol).all())
+    with pytest.raises(_lib.VfError):
+        ops.igemm(x16, wp, M, K, N, u32, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, out_aux=f, gelu_grad=True)      # fp32 out
+    with pytest.raises(_lib.VfError):
+        ops.igemm(dy16, wt, M, N, K, du, res=plain, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, gelu_grad=True)       # fp32 table
+
+
+@pytest.mark.gpu
+def test_saved_gelu_derivative_training_step_stays_within_the_bf16_arm_bound(dev):
+    """MIGTTrainer.save_gelu_derivative on / off: the two forms round gelu' at different places (from the fp32 pre-activation once; from the bf16-rounded
+    pre-activation in the backward), so gradients agree to the bf16 arm's own precision, not bit for bit; forward outputs (losses of step 1) are identical."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(sequence_size=4, n_loss_skip=1, localization_weight='5', pose_multiplier=0.05, dropout=0.1, learning_rate=1e-3, weight_decay=0.05,
+                     total_steps=1000, batch_size=2, n_layer=2)
+    sd = make_migt_weights(cfg, seed=3)
+    g = np.random.Generator(np.random.PCG64(5))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(2, 4, 8, 8)))
+    poses = torch.from_numpy(g.standard_normal((2, 4, 7)).astype(np.float32))
+    res = []
+    for flag in (False, True):
+        tr = MIGTTrainer(MIGT(cfg, precision='bf16').load_state_dict(sd).to(dev))
+        tr.save_gelu_derivative = flag
+        loss = tr.train_step(poses, tokens, apply_update=False)['loss'].clone()
+        torch.cuda.synchronize()
+        assert tr._u_is_derivative == flag
+        res.append((loss, tr.flat_g.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    ga, gb = res[0][1].double(), res[1][1].double()
+    for name in ('h.0.mlp.c_fc.weight', 'h.1.mlp.c_fc.weight', 'h.0.attn.c_attn.weight', 'wte.weight'):
+        a, b, _ = tr.slices[name]
+        assert float((ga[a:b] - gb[a:b]).abs().max() / ga[a:b].abs().max()) < 1.5e-2, name
+    assert float((ga - gb).abs().max()) > 0

@@ -25,6 +25,8 @@ cases = {
     'dual (bf16 u + bf16 f)': lambda: ops.igemm(x16, wp, M, K, N, o16, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=True, out_aux=f16),
     'GELU-backward, fp32 u': lambda: ops.igemm(x16, wp, M, K, N, o16, res=u32, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True),
     'GELU-backward, bf16 u': lambda: ops.igemm(x16, wp, M, K, N, o16, res=u16, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True),
+    "dual, saved derivative (bf16 gelu'(u) + bf16 f)": lambda: ops.igemm(x16, wp, M, K, N, o16, bias=b, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=True, out_aux=f16, gelu_grad=True),
+    "GELU-backward on the saved derivative": lambda: ops.igemm(x16, wp, M, K, N, o16, res=u16, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=True, o16=True, res16=True, gelu_grad=True),
 }
 for name, fn in cases.items():
     for _ in range(3):

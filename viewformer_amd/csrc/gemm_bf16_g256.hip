@@ -145,7 +145,8 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
         for (int i = 0; i < IC; ++i) {
             const int m0 = m_tile0 + wrow0 + i * 32 + 4 * half;
             float t[16];
-            if (EPI == 2) {
+            if (EPI == 2 || EPI == 4) {
+                // (EPI 4, round 6: `res` holds the SAVED DERIVATIVE gelu'(u) as bf16 — written by the forward's EPI 5 — and the epilogue multiplies by it)
                 // u through an SGPR buffer resource based at the tile's first row (32-bit lane offsets, no 64-bit lane addresses) that ends
                 // with the matrix's last row: rows of a ragged last tile beyond M read as zero instead of faulting.  All of a 32 x 32 block's
                 // loads are issued first; the gelu' evaluations then run four at a time, fenced (sixteen interleaved beside the 128
@@ -188,7 +189,7 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        t[4 * q + e] = __fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bias), vf_gelu_grad_fast(uu[4 * q + e]));
+                        t[4 * q + e] = __fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bias), EPI == 4 ? uu[4 * q + e] : vf_gelu_grad_fast(uu[4 * q + e]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -199,23 +200,30 @@ __device__ __forceinline__ void g256_store_bf16(const vf_igemm_args& p, const f3
                 }
             }
             // EPI 3 (VF_EPI_GELU_DUAL with a bf16 `out`): first the pre-activation as bf16 to `out`, then — from the fp32 value, not the
-            // rounded one — its GELU as bf16 to `out_aux`
+            // rounded one — its GELU as bf16 to `out_aux`.  EPI 5 (round 6, reserved0 bit 3): `out` receives gelu'(u) instead of u — what the
+            // backward needs u for — from the same erf / exp evaluation as the GELU (vf_gelu_and_grad_fast)
+            float gq[EPI == 5 ? 16 : 1];
+            if (EPI == 5) {
 #pragma unroll
-            for (int pass = 0; pass < (EPI == 3 ? 2 : 1); ++pass) {
+                for (int r = 0; r < 16; ++r) { float f, g; vf_gelu_and_grad_fast(t[r], f, g); t[r] = f; gq[r] = g; }
+            }
+#pragma unroll
+            for (int pass = 0; pass < ((EPI == 3 || EPI == 5) ? 2 : 1); ++pass) {
                 __bf16* __restrict__ dst = pass == 0 ? O : reinterpret_cast<__bf16*>(p.out_aux);
-                if (pass == 1) {
+                if (EPI == 3 && pass == 1) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t[r] = vf_gelu_erf_fast(t[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float give = odd ? t[r] : t[r + 1];
+                    const float lo = (EPI == 5 && pass == 0) ? gq[r] : t[r], hi = (EPI == 5 && pass == 0) ? gq[r + 1] : t[r + 1];
+                    const float give = odd ? lo : hi;
                     const float got = vf_lane_xor1(give);
                     const int m = m0 + ((r + odd) & 3) + 8 * ((r + odd) >> 2);
                     bf16x2_t v;
-                    v[0] = (__bf16)(odd ? got : t[r]);
-                    v[1] = (__bf16)(odd ? t[r + 1] : got);
+                    v[0] = (__bf16)(odd ? got : lo);
+                    v[1] = (__bf16)(odd ? hi : got);
                     if (FULL || m < p.M) *reinterpret_cast<bf16x2_t*>(dst + (size_t)m * p.ldc + (n - odd)) = v;
                 }
             }
@@ -351,7 +359,14 @@ __device__ __forceinline__ void g256_tile(const vf_igemm_args& p, unsigned char*
     if (O16) {
         const bool gbwd = p.epilogue == VF_EPI_GELU_BWD;
         const bool dual16 = p.epilogue == VF_EPI_GELU_DUAL;
-        if (dual16) {
+        const bool deriv = p.reserved0 & 8;                // (round 6) DUAL: `out` receives gelu'(u); GELU_BWD: `res` holds it
+        if (dual16 && deriv) {
+            if (full) g256_store_bf16<5, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else g256_store_bf16<5, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+        } else if (gbwd && deriv) {
+            if (full) g256_store_bf16<4, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+            else g256_store_bf16<4, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
+        } else if (dual16) {
             if (full) g256_store_bf16<3, true, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
             else g256_store_bf16<3, false, IC>(p, acc, m_tile0, n_tile0, wrow0, wave_n, half, l31);
         } else if (full) {
@@ -463,6 +478,9 @@ int vf_gemm_bf16_g256_launch(const vf_igemm_args& a, hipStream_t stream) {
     if (a.epilogue == VF_EPI_GELU_BWD && !(o16 && a.res)) return VF_ERR_UNSUPPORTED;
     if (a.epilogue == VF_EPI_GELU_DUAL && (a.res || !a.out_aux || (a.ldc & 1))) return VF_ERR_UNSUPPORTED;      // (out fp32 or bf16)
     if ((a.reserved0 & 4) && a.epilogue != VF_EPI_GELU_BWD) return VF_ERR_BAD_ARG;                             // (bit 2: a bf16 u for GELU_BWD)
+    if (a.reserved0 & 8) {                                                                                     // (bit 3, round 6: the saved-derivative forms)
+        if (a.epilogue == VF_EPI_GELU_BWD ? !(a.reserved0 & 4) : !(a.epilogue == VF_EPI_GELU_DUAL && o16)) return VF_ERR_BAD_ARG;
+    }
     if (a.res && a.epilogue == VF_EPI_GELU_ERF) return VF_ERR_UNSUPPORTED;      // (no layer has both; the 128-tile kernel contracts gelu * + res)
     // fused output dropout (drop_rate > 0): the fp32-output path with no epilogue function; mask group indices are 32-bit here
     if (a.drop_rate != 0.f && (!(a.drop_rate > 0.f && a.drop_rate < 1.f) || o16 || a.epilogue != VF_EPI_NONE || a.drop_row0 < 0 || (a.drop_row0 & 3) ||

@@ -112,6 +112,23 @@ __device__ __forceinline__ float vf_gelu_erf_fast(float v) {
     return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
+// GELU and its derivative from ONE evaluation of the erf pieces (round 6: the c_fc epilogue can save gelu'(u) instead of u, so that the backward's
+// epilogue multiplies by a loaded value instead of evaluating erf + exp per element again).  f is vf_gelu_erf_fast(v) operation for operation (same bits);
+// g = Phi(v) + v phi(v) = 0.5 (1 + erf) + v (1 / sqrt(2 pi)) exp(-v^2 / 2) reuses its (1 + erf) and its exponential: three more instructions.
+__device__ __forceinline__ void vf_gelu_and_grad_fast(float v, float& f, float& g) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = __builtin_fmaf(-p * t, e, 1.0f);
+    const float one_plus = 1.0f + copysignf(erf_abs, v);
+    f = 0.5f * v * one_plus;
+    g = __builtin_fmaf(v, 0.39894228040143267794f * e, 0.5f * one_plus);
+}
+
 // the value of the neighbouring lane (lane ^ 1) on the vector ALU's DPP path (quad_perm [1, 0, 3, 2]) — __shfl_xor(v, 1) is a ds_bpermute_b32: a trip
 // through the LDS pipeline with its address register and lgkmcnt wait; the bf16 epilogues exchange 64 values per thread and tile this way
 __device__ __forceinline__ int vf_lane_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }

@@ -302,7 +302,7 @@ def gemm_tn_bf16(x16, dy, M, K, N, dw, db=None, accumulate=True, beside_another_
 def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, epilogue=EPI_NONE,
           pro=None, pro_swish=False, pro_rows_per_img=0, Hin=0, Win=0, Hout=0, Wout=0,
           lda=None, ldc=None, ldr=None, batch=1, stride_x=0, stride_w=0, stride_out=0, stride_res=0, bf16=False, x6=False, gn_part=None, split_k=0,
-          x3h=False, a16=False, o16=False, out_aux=None, res16=False, drop=None):
+          x3h=False, a16=False, o16=False, out_aux=None, res16=False, drop=None, gelu_grad=False):
     """``bf16=True``: w_packed is a bf16 packing (pack_*_bf16) and the launch goes to the bf16-MFMA arm
     (vf_gemm_bf16 / vf_conv3_halo_bf16); unsupported shapes raise (no silent fallback).
     ``x6=True``: w_packed is the 3-plane split packing (pack_conv3_x6) and the launch goes to the fp32-equivalent
@@ -311,6 +311,8 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
     output (halo kernels only; reduce with groupnorm_finalize).
     ``out_aux`` (with ``epilogue=EPI_GELU_DUAL``, bf16 arm, bf16 x, fp32 or bf16 out): bf16 [M][ldc] that receives gelu(out).
     ``res16`` (with ``epilogue=EPI_GELU_BWD``): the pre-activation behind ``res`` was saved as bf16.
+    ``gelu_grad`` (round 6, 256-tile shapes): with ``EPI_GELU_DUAL`` and bf16 out, ``out`` receives gelu'(x @ W + b) instead of the pre-activation;
+    with ``EPI_GELU_BWD`` and ``res16``, ``res`` holds that saved derivative and the epilogue multiplies by it instead of evaluating gelu' again.
     ``drop`` = (rate, seed, site), bf16 arm with bf16 x and fp32 out only: the training step's output dropout in the epilogue, before the
     residual joins (vf_igemm_args.drop_rate; the masks of train_ops.dropout_add with cols = Cout).  Shapes outside the 256-tile kernel
     raise 'unsupported' (callers run the GEMM, then dropout_add)."""
@@ -370,6 +372,10 @@ def igemm(x, w_packed, M, Cin, Cout, out, bias=None, res=None, mode=MODE_GEMM, e
             raise _lib.VfError('res16 is the bf16 pre-activation of EPI_GELU_BWD (bf16 in, bf16 out)')
         _chk(res, torch.bfloat16, 'res')
         a.reserved0 |= 4
+    if gelu_grad:
+        if not ((epilogue == EPI_GELU_DUAL and a16 and o16) or (epilogue == EPI_GELU_BWD and res16)):
+            raise _lib.VfError('gelu_grad: EPI_GELU_DUAL with bf16 in / out, or EPI_GELU_BWD with res16')
+        a.reserved0 |= 8
     for t in ((None if a16 else x), (None if o16 else out), bias, (None if (res16 or conv16) else res)):
         if t is not None:
             _f32(t)

@@ -483,8 +483,9 @@ class MIGTTrainer:
         if gelu_bwd_u is not None:
             if not (bf16 and dx_bf16 and res is None):
                 raise RuntimeError('the fused GELU backward needs the bf16 arm, a bf16 result and no residual')
+            u16 = gelu_bwd_u.dtype == torch.bfloat16
             ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=gelu_bwd_u, epilogue=ops.EPI_GELU_BWD, bf16=True, a16=dy.dtype == torch.bfloat16, o16=True,
-                      res16=gelu_bwd_u.dtype == torch.bfloat16)
+                      res16=u16, gelu_grad=u16 and self._u_is_derivative)       # (save_gelu_derivative: the tensor holds gelu'(u) already)
         elif bf16:
             ops.igemm(dy, self.wpT16[name], M, N, K, dx, res=res, bf16=True, a16=dy.dtype == torch.bfloat16, o16=dx_bf16)   # (bf16 dY: the 256-tile kernel)
         elif x6:
@@ -543,6 +544,12 @@ class MIGTTrainer:
     bf16_preactivation = True         # bf16 arm, with both GELU fusions: c_fc's pre-activation u is SAVED as bf16 (the reference's mixed_float16 policy
                                       # keeps every activation in half precision); gelu(u) is still taken from the fp32 accumulator, gelu'(u)
                                       # in the backward epilogue from the rounded u.  False: u saved as fp32.
+    save_gelu_derivative = True       # bf16 arm, with bf16_preactivation: what c_fc saves for the backward is gelu'(u) (bf16, from the erf / exp evaluation its GELU
+                                      # makes anyway: three more instructions per element) instead of u, whose only reader — the GELU-backward epilogue of the
+                                      # mlp.c_proj dX GEMM — then multiplies by a loaded value instead of evaluating erf + exp per element again (that epilogue
+                                      # was 22 us of a 148 us launch).  gelu' is taken from the fp32 pre-activation and rounded once; before it was evaluated
+                                      # on the bf16-rounded u
+    _u_is_derivative = False
     fuse_gelu_forward = True          # bf16 arm: c_fc writes u (fp32, saved) and bf16 gelu(u) from one epilogue (VF_EPI_GELU_DUAL); the GELU there
                                       # is the inference arm's vf_gelu_erf_fast (|err| 1.5e-7: a few outputs round to the neighbouring bf16)
 
@@ -740,8 +747,11 @@ class MIGTTrainer:
                 # GELU-backward epilogue of the 256-tile kernel, fed by the bf16 residual-stream gradient)
                 u = torch.empty((M, dn.n), dtype=torch.bfloat16 if u16 else torch.float32, device=dev)
                 f = torch.empty((M, dn.n), dtype=torch.bfloat16, device=dev)
-                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=u16, out_aux=f)
+                self._u_is_derivative = bool(u16 and self.save_gelu_derivative)           # (`u` then holds gelu'(u): see save_gelu_derivative)
+                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=u16, out_aux=f,
+                          gelu_grad=self._u_is_derivative)
             else:
+                self._u_is_derivative = False
                 u = self._linear(n2, p + '.mlp.c_fc', M)
                 f = T.gelu(u, out_bf16=act16)
             h_out = self._proj_dropout(f, p + '.mlp.c_proj', M, h_mid, drop_of(site_mlp(i)))           # h + dropout(mlp(...)), migt.py:72,237
