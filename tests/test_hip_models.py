@@ -258,6 +258,32 @@ def test_fused_generate_and_localize_is_bit_identical_to_two_passes(dev, full_vq
         assert torch.equal(a['generated_cameras'], b['generated_cameras'])
 
 
+@pytest.mark.parametrize('precision,S,B', [('f32', 4, 2), ('bf16', 7, 5), ('bf16', 2, 3)])
+def test_last_block_on_the_two_returned_views_only_keeps_their_bits(dev, precision, S, B):
+    """MIGT.prune_last_block (round 6): generate_and_localize runs the LAST block's projection, LayerNorm, MLP and ln_f on the MASK and LOC views' rows
+    only (the other rows of the last block feed nothing).  Codes / logits and the pose prediction equal the full-rows pass bit for bit, on the fp32
+    arm and on the bf16 arm (256-tile GEMMs at the reduced row count), for a two-view sequence as well."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.weights import make_migt_weights
+    mcfg = MIGTConfig(sequence_size=S, localization_weight='1', pose_multiplier=0.2, n_layer=2)
+    msd = make_migt_weights(mcfg, seed=6, std=0.05)
+    g = np.random.Generator(np.random.PCG64(S * 10 + B))
+    codes = torch.from_numpy(g.integers(0, 1024, size=(B, S, 8, 8)))
+    cams = torch.from_numpy(g.standard_normal((B, S, 7)).astype(np.float32))
+    m = MIGT(mcfg, precision=precision).load_state_dict(msd).to(dev)
+    outs = []
+    for prune in (False, True):
+        m.prune_last_block = prune
+        for codes_only in (False, True):
+            first, pose = m.generate_and_localize(codes, cams, codes_only=codes_only)
+            outs.append((prune, codes_only, first.clone(), pose.clone()))
+    torch.cuda.synchronize()
+    for (p0, c0, f0, q0), (p1, c1, f1, q1) in zip(outs[:2], outs[2:]):
+        assert c0 == c1 and not p0 and p1
+        assert torch.equal(f0, f1) and torch.equal(q0.view(torch.int32), q1.view(torch.int32))
+
+
 def test_generate_codes_dataset_with_the_gpu_codebook(dev, tiny_vq, tmp_path):
     """generate-codes end to end: frames -> VQGAN.encode on the GPU -> TFRecord code dataset -> read back"""
     from viewformer_amd import codes_dataset as cd

@@ -212,9 +212,15 @@ class MIGT:
         """MIGT.reduce_cameras, migt.py:532-533"""
         return geometry.reduce_cameras(cameras, axis)
 
-    def _blocks(self, ids, add_emb, B, V, L, mask_spec=-1):
+    prune_last_block = True           # callers that read only the last views' hidden states (generate_and_localize: the MASK and LOC views) get the LAST
+                                      # block's projection, LayerNorm, MLP and ln_f on those views' rows only: every earlier block needs all rows (they are the
+                                      # keys and values of the next block), the last block's other rows feed nothing.  Row for row the same launches on fewer
+                                      # rows (GEMM rows, LayerNorm rows are independent of each other): the rows that are returned keep their bits
+
+    def _blocks(self, ids, add_emb, B, V, L, mask_spec=-1, tail_views=0):
         """embedding sum -> n_layer x Block -> ln_f over V views of L tokens.  ids [B,V,...] int,
-        add_emb [B,V,d] (pose embedding or LOC-token row per view).  Returns [B*V*L, d]."""
+        add_emb [B,V,d] (pose embedding or LOC-token row per view).  Returns [B*V*L, d]; with ``tail_views`` = k > 0 (and prune_last_block)
+        the hidden states of the last k views only, [B*k*L, d]."""
         c, dev = self.config, self.device
         d, H = c.d_model, c.n_head
         T, M = V * L, B * V * L
@@ -241,10 +247,20 @@ class MIGT:
             ops.attn_blockcausal(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, T, L,
                                  3 * d, 3 * d, 3 * d, d, 1.0, self.skip_masked, mask_spec, bf16=self.precision == 'bf16',
                                  x6=self.precision == 'f32' and self.dense_arith in ('x6', 'x3h'), fp8=self.attention == 'fp8')
-            h = self._gemm(att, p + '.attn.c_proj', M, res=h)
+            att_i = att
+            if i == c.n_layer - 1 and 0 < tail_views < V:
+                # the last block: only the requested views' rows go on (their attention rows and residual rows, gathered; see prune_last_block)
+                k = tail_views
+                M = B * k * L
+                att_i = att.view(B, V, L, d)[:, V - k:].reshape(M, d)
+                h = h.view(B, V, L, d)[:, V - k:].reshape(M, d)
+            h = self._gemm(att_i, p + '.attn.c_proj', M, res=h)
             m = ops.layernorm(h, *self._ln[p + '.ln_2'], M, d, out_bf16=act16)
             f = self._gemm(m, p + '.mlp.c_fc', M, epilogue=ops.EPI_GELU, out_bf16=act16)
             h = self._gemm(f, p + '.mlp.c_proj', M, res=h)
+        if 0 < tail_views < V and c.n_layer == 0:
+            h = h.view(B, V, L, d)[:, V - tail_views:].reshape(B * tail_views * L, d)
+            M = B * tail_views * L
         return ops.layernorm(h, *self._ln['ln_f'], M, d)                    # migt.py:408
 
     def generate_and_localize(self, codes, cameras, codes_only: bool = False):
@@ -277,9 +293,14 @@ class MIGT:
         add = torch.cat([pose_emb, lpe], 1)                                             # [B,S+1,d]
         mask = torch.full_like(codes[:, :1], self.mask_token)
         ids = torch.cat([codes[:, :-1], mask, codes[:, -1:]], 1)                        # [B,S+1,t,t]
-        hf = self._blocks(ids, add, B, S + 1, L, mask_spec=S - 1).view(B, S + 1, L, d)
-        h_mask = hf[:, S - 1].contiguous().view(B * L, d)
-        h_loc = hf[:, S].contiguous().view(B * L, d)
+        if self.prune_last_block:
+            hf = self._blocks(ids, add, B, S + 1, L, mask_spec=S - 1, tail_views=2).view(B, 2, L, d)      # the MASK view and the LOC view
+            h_mask = hf[:, 0].contiguous().view(B * L, d)
+            h_loc = hf[:, 1].contiguous().view(B * L, d)
+        else:
+            hf = self._blocks(ids, add, B, S + 1, L, mask_spec=S - 1).view(B, S + 1, L, d)
+            h_mask = hf[:, S - 1].contiguous().view(B * L, d)
+            h_loc = hf[:, S].contiguous().view(B * L, d)
         gen = self._lm_argmax(h_mask, B * L) if codes_only else None
         if gen is None:
             lg = torch.empty((B * L, nE), dtype=torch.float32, device=dev)
