@@ -197,8 +197,12 @@ class DropoutMasks:
     NS tensors [B, S, L, d] here: element (row m, column c) sits in group (m >> 2) * d + c at position m & 3.  Attention weights are indexed
     by absolute (query, key) token positions in the T = V*L sequence: plane b*H + h, group q * ceil(T/4) + (k >> 2), position k & 3."""
 
-    def __init__(self, rate, seed, B, NS, S, L, d, H, dtype=torch.float64, b0=0):
+    def __init__(self, rate, seed, B, NS, S, L, d, H, dtype=torch.float64, b0=0, pruned_layer=None):
         self.rate, self.seed, self.B, self.NS, self.S, self.L, self.d, self.H, self.dtype = rate, seed, B, NS, S, L, d, H, dtype
+        # MIGTTrainer.prune_last_block (round 6): from the last block's projection on, the build runs on the NS - 1 branch streams' rows only
+        # (gathered: [B][NS - 1][S][L]) and indexes that block's 'resid' and 'mlp' masks by the gathered rows; the main stream's rows of that
+        # block reach no loss, so whatever mask they get here is without effect
+        self.pruned_layer = pruned_layer
         self.b0 = b0                                               # index of the first scene in the global batch (MIGTTrainer.scene_offset)
         self.thresh = int(rate * 4294967296.0)
         self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))      # fp32 like the kernels
@@ -212,6 +216,8 @@ class DropoutMasks:
         site = {'embed': 1, 'resid': 17 + 4 * layer, 'mlp': 18 + 4 * layer}[kind]
         B, S, L, d = self.B, self.S, self.L, self.d
         V = self.NS * S
+        if self.pruned_layer is not None and layer == self.pruned_layer and kind in ('resid', 'mlp') and stream >= 1:
+            V, stream = (self.NS - 1) * S, stream - 1                  # row index among the gathered branch-stream rows
         b, i, t, c = np.meshgrid(np.arange(B), np.arange(S), np.arange(L), np.arange(d), indexing='ij')
         m = (((b.astype(np.uint64) + np.uint64(self.b0)) * np.uint64(V) + np.uint64(stream * S) + i.astype(np.uint64)) * np.uint64(L)
              + t.astype(np.uint64))
@@ -242,17 +248,18 @@ class DropoutMasks:
         return torch.cat([old, own], -1)
 
 
-def losses_with_dropout(sd, cfg, poses, tokens, step, rate, seed, dtype=torch.float64):
+def losses_with_dropout(sd, cfg, poses, tokens, step, rate, seed, dtype=torch.float64, pruned_last_block=True):
     B, S = tokens.shape[:2]
     L = int(np.prod(tokens.shape[2:]))
     NS = 3 if cfg.use_localization else 2
-    with mg.dropout_masks(DropoutMasks(rate, seed, B, NS, S, L, cfg.d_model, cfg.n_head, dtype)):
+    pruned = cfg.n_layer - 1 if (pruned_last_block and cfg.n_layer > 0) else None
+    with mg.dropout_masks(DropoutMasks(rate, seed, B, NS, S, L, cfg.d_model, cfg.n_head, dtype, pruned_layer=pruned)):
         return losses(sd, cfg, poses, tokens, step, dtype)
 
 
-def gradients_with_dropout(sd_np, cfg, poses, tokens, step, rate, seed):
+def gradients_with_dropout(sd_np, cfg, poses, tokens, step, rate, seed, pruned_last_block=True):
     sd = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd_np.items()}
-    total, metrics = losses_with_dropout(sd, cfg, torch.as_tensor(poses), torch.as_tensor(tokens), step, rate, seed)
+    total, metrics = losses_with_dropout(sd, cfg, torch.as_tensor(poses), torch.as_tensor(tokens), step, rate, seed, pruned_last_block=pruned_last_block)
     total.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
     return grads, {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in metrics.items()}

@@ -1565,3 +1565,41 @@ def test_saved_gelu_derivative_training_step_stays_within_the_bf16_arm_bound(dev
         a, b, _ = tr.slices[name]
         assert float((ga[a:b] - gb[a:b]).abs().max() / ga[a:b].abs().max()) < 1.5e-2, name
     assert float((ga - gb).abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,loc', [('f32', True), ('bf16', True), ('bf16', False)])
+def test_last_block_on_the_branch_streams_only(dev, precision, loc):
+    """MIGTTrainer.prune_last_block (round 6): forward and backward of the last block's projection / LayerNorm / MLP and of ln_f on the MASK / LOC streams'
+    rows only — the main stream's rows of the last block reach no loss.  Without dropout the step equals the all-rows step: losses bit for bit (the rows
+    that are kept are the same launches' rows), gradients within fp32 summation order (the weight gradients of the last block add exact zeros for
+    the pruned rows in the all-rows step, in another slab partition).  With dropout the two steps draw the last block's masks at different row indices
+    (the oracle follows the pruned indexing: test_train_step_with_dropout_...), so only finiteness and determinism are compared here."""
+    from viewformer_amd.config import MIGTConfig
+    from viewformer_amd.migt import MIGT
+    from viewformer_amd.train import MIGTTrainer
+    from viewformer_amd.weights import make_migt_weights
+    cfg = MIGTConfig(sequence_size=4, n_loss_skip=1, localization_weight='5' if loc else '0', pose_multiplier=0.05, dropout=0.0, learning_rate=1e-3,
+                     weight_decay=0.05, total_steps=1000, batch_size=2, n_layer=2)
+    sd = make_migt_weights(cfg, seed=3)
+    g = np.random.Generator(np.random.PCG64(5))
+    tokens = torch.from_numpy(g.integers(0, 1024, size=(2, 4, 8, 8)))
+    poses = torch.from_numpy(g.standard_normal((2, 4, 7)).astype(np.float32))
+    res = []
+    for prune in (False, True, True):
+        tr = MIGTTrainer(MIGT(cfg, precision=precision).load_state_dict(sd).to(dev))
+        tr.prune_last_block = prune
+        met = tr.train_step(poses, tokens, apply_update=False)
+        torch.cuda.synchronize()
+        res.append((met['loss'].clone(), tr.flat_g.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0])
+    assert torch.equal(res[1][1], res[2][1])                                   # deterministic
+    ga, gb = res[0][1].double(), res[1][1].double()
+    for name in tr.names:
+        a, b, _ = tr.slices[name]
+        scale = float(ga[a:b].abs().max()) + 1e-30
+        assert float((ga[a:b] - gb[a:b]).abs().max()) / scale < (2e-5 if precision == 'f32' else 2e-3), name
+    cfg2 = MIGTConfig(**{**cfg.__dict__, 'dropout': 0.1}) if hasattr(cfg, '__dict__') else cfg
+    tr = MIGTTrainer(MIGT(cfg2, precision=precision).load_state_dict(sd).to(dev))
+    out = [tr.train_step(poses, tokens, apply_update=False)['loss'].clone() for _ in range(1)]
+    assert torch.isfinite(out[0]) and torch.isfinite(tr.flat_g).all()

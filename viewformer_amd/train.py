@@ -497,6 +497,8 @@ class MIGTTrainer:
             ops.igemm(dy, wpT, M, N, K, dx, res=res)
         return dx
 
+    prune_last_block = True           # the last block's projection / LayerNorm / MLP (forward and backward) and ln_f on the branch streams' rows only: the main
+                                      # stream's rows of the last block reach no loss (see train_step); its dropout masks there are indexed by the gathered rows
     lazy_gradient_zero = True         # the transformer layers' gradient tensors (85 M of the 88 M) are not zero-filled at the start of a step: each is written
                                       # exactly once per step, so its first writer STORES (sum_slabs / LayerNorm backward with accumulate off) instead of adding
                                       # to a zero — one 337 MB fill and one 337 MB read of zeros less per step.  Keys still unset when a layer's (or the
@@ -723,6 +725,15 @@ class MIGTTrainer:
                  and (rate == 0.0 or (self.fuse_dropout and row0 % 4 == 0 and ((M + row0 + 3) // 4) * d < 2 ** 32)))
         drop_of = lambda site: (rate, seed, site, row0)                              # noqa: E731  (elementwise sites: row offset)
         drop_attn = lambda i_: (rate, seed, site_attn(i_), plane0)                   # noqa: E731  (attention: plane offset)
+        # prune_last_block: the losses read the branch streams only (MASK -> LM head, LOC -> pose head: migt.py:416-448); every block but the last needs
+        # the main stream's rows as keys and values of the next one, the LAST block's projection / LayerNorm / MLP on them feed nothing — and their
+        # backward multiplies zeros.  From the last block's attention on, forward and backward run on the NS - 1 branch streams' rows (gathered:
+        # they are contiguous per scene), ln_f with them; the attention backward and everything below it get the two gradients scattered back with
+        # zeros in the main stream's rows, which is what they were.  The dropout masks of the last block's two sites are indexed by the gathered rows
+        nb = NS - 1
+        tail = bool(self.prune_last_block and NS > 1 and c.n_layer > 0)
+        Mx = B * nb * S * L if tail else M                                           # rows from the last block's projection on
+        drop_x = (lambda site: (rate, seed, site, row0 // NS * nb)) if tail else drop_of      # noqa: E731
         for i in range(c.n_layer):
             p = f'h.{i}'
             n1 = ops.layernorm(h, *m._ln[p + '.ln_1'], M, d, out_bf16=act16)
@@ -738,32 +749,39 @@ class MIGTTrainer:
                 att = torch.empty((M, d), dtype=torch.float32, device=dev)
                 lse = T.attn_fwd_lse(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, B, H, Tn, L, 3 * d, 3 * d, 3 * d, d, 1.0, -S,
                                      drop=drop_attn(i))
-            h_mid = self._proj_dropout(att, p + '.attn.c_proj', M, h, drop_of(site_resid(i)))          # h + resid_dropout(c_proj(a)), migt.py:216,233
-            n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], M, d, out_bf16=act16)
-            if act16 and self.fuse_gelu_forward and self._gelu_dual_ok(M):
+            last = tail and i == c.n_layer - 1
+            Mi, drop_i = (Mx, drop_x) if last else (M, drop_of)
+            att_i, h_i = att, h
+            if last:
+                att_i = att.view(B, NS, S * L, att.shape[-1])[:, 1:].reshape(Mx, att.shape[-1])
+                h_i = h.view(B, NS, S * L, d)[:, 1:].reshape(Mx, d)
+            h_mid = self._proj_dropout(att_i, p + '.attn.c_proj', Mi, h_i, drop_i(site_resid(i)))      # h + resid_dropout(c_proj(a)), migt.py:216,233
+            n2 = ops.layernorm(h_mid, *m._ln[p + '.ln_2'], Mi, d, out_bf16=act16)
+            if act16 and self.fuse_gelu_forward and self._gelu_dual_ok(Mi):
                 # c_fc keeps the fp32 pre-activation for the backward pass AND hands bf16 gelu(u) to mlp.c_proj from one epilogue
                 dn = m._dense[p + '.mlp.c_fc']
                 u16 = res16 and self.bf16_preactivation      # (its only reader then: the
                 # GELU-backward epilogue of the 256-tile kernel, fed by the bf16 residual-stream gradient)
-                u = torch.empty((M, dn.n), dtype=torch.bfloat16 if u16 else torch.float32, device=dev)
-                f = torch.empty((M, dn.n), dtype=torch.bfloat16, device=dev)
-                self._u_is_derivative = bool(u16 and self.save_gelu_derivative)           # (`u` then holds gelu'(u): see save_gelu_derivative)
-                ops.igemm(n2, dn.wp16, M, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=u16, out_aux=f,
-                          gelu_grad=self._u_is_derivative)
+                u = torch.empty((Mi, dn.n), dtype=torch.bfloat16 if u16 else torch.float32, device=dev)
+                f = torch.empty((Mi, dn.n), dtype=torch.bfloat16, device=dev)
+                u_deriv = bool(u16 and self.save_gelu_derivative)                         # (`u` then holds gelu'(u): see save_gelu_derivative)
+                ops.igemm(n2, dn.wp16, Mi, dn.k, dn.n, u, bias=dn.bias, epilogue=ops.EPI_GELU_DUAL, bf16=True, a16=True, o16=u16, out_aux=f,
+                          gelu_grad=u_deriv)
             else:
-                self._u_is_derivative = False
-                u = self._linear(n2, p + '.mlp.c_fc', M)
+                u_deriv = False
+                u = self._linear(n2, p + '.mlp.c_fc', Mi)
                 f = T.gelu(u, out_bf16=act16)
-            h_out = self._proj_dropout(f, p + '.mlp.c_proj', M, h_mid, drop_of(site_mlp(i)))           # h + dropout(mlp(...)), migt.py:72,237
+            h_out = self._proj_dropout(f, p + '.mlp.c_proj', Mi, h_mid, drop_i(site_mlp(i)))           # h + dropout(mlp(...)), migt.py:72,237
             if not _forward_only:
-                saved.append((h, n1, qkv, att, h_mid, n2, u, f, lse))
+                saved.append((h, n1, qkv, att, att_i, h_mid, n2, u, f, lse, u_deriv))
             h = h_out
-        hf = ops.layernorm(h, *m._ln['ln_f'], M, d).view(B, NS, S, L, d)
+        so = 1 if tail else 0                                                         # (hf's first stream: the main stream is not there when pruned)
+        hf = ops.layernorm(h, *m._ln['ln_f'], Mx, d).view(B, NS - so, S, L, d)
 
         # ---- losses (migt.py:416-448) ---------------------------------------------------------------------
         view_ok = (torch.arange(S, device=dev) >= skip).float().view(1, S, 1).expand(B, S, L).reshape(M1)
         denom = float((S - skip) * L * B)
-        hmask = hf[:, 1].contiguous().view(M1, d)
+        hmask = hf[:, 1 - so].contiguous().view(M1, d)
         logits = torch.empty((M1, nE), dtype=torch.float32, device=dev)
         lm16 = self._lm16 is not None and m.precision == 'bf16' and self.bf16_lm_head and M1 % 64 == 0
         if lm16:
@@ -780,7 +798,7 @@ class MIGTTrainer:
         metrics['acc'] = (pred[:, skip:] == tok[:, skip:]).float().mean()
         if use_loc:
             loc_w = float(self.loc_weight(self.step_count))
-            hloc = hf[:, 2].contiguous().view(M1, d)
+            hloc = hf[:, 2 - so].contiguous().view(M1, d)
             up = self._linear(hloc, 'pose_criterion.pose_classifier.c_fc', M1)
             p1 = T.gelu(up)
             dn_p = m._dense['pose_criterion.pose_classifier.c_proj']
@@ -820,7 +838,7 @@ class MIGTTrainer:
                                  pose_head_raw=raw.view(B, S, L, 7) if use_loc else None)
 
         # ---- backward -------------------------------------------------------------------------------------
-        dhf = torch.zeros((B, NS, S, L, d), dtype=torch.float32, device=dev)
+        dhf = torch.zeros((B, NS - so, S, L, d), dtype=torch.float32, device=dev)
         # tied LM head: dH = dlogits @ wte[:nE];  dwte[:nE] = dlogits^T @ H
         dhm = torch.empty((M1, d), dtype=torch.float32, device=dev)
         gwte = self.g('wte.weight')
@@ -837,7 +855,7 @@ class MIGTTrainer:
             dlt = T.transpose(dlogits, M1, nE)
             hp = ops.pack(hmask, M1, d, 1, sk=d, sn=1, st=0)
             ops.igemm(dlt, hp, nE, M1, d, gwte)                                       # rows [0, nE) of the (zeroed) grad
-        dhf[:, 1] = dhm.view(B, S, L, d)
+        dhf[:, 1 - so] = dhm.view(B, S, L, d)
         if use_loc:
             name = 'pose_criterion.pose_classifier.c_proj'
             dn = m._dense[name]
@@ -852,11 +870,11 @@ class MIGTTrainer:
             dp1 = ops.dense_small_k(draw, w2t, None, M1, 7, dn.k, gelu=False)
             dup = T.gelu_bwd(up, dp1)
             dhl = self._linear_bwd('pose_criterion.pose_classifier.c_fc', hloc, dup, M1)
-            dhf[:, 2] = dhl.view(B, S, L, d)
+            dhf[:, 2 - so] = dhl.view(B, S, L, d)
         # with dropout, the bf16 copy of a residual-stream gradient is the dY of the projection layer that consumes it, i.e. that gradient
         # under the layer's OUTPUT mask: the LayerNorm backward applies it while it writes the copy (the fp32 gradient stays unmasked)
         nl = c.n_layer
-        dh = self._ln_bwd('ln_f', dhf.view(M, d), h, M, also_bf16=res16 and nl > 0, drop=drop_of(site_mlp(nl - 1)))
+        dh = self._ln_bwd('ln_f', dhf.view(Mx, d), h, Mx, also_bf16=res16 and nl > 0, drop=drop_x(site_mlp(nl - 1)))
         dh, dh16 = dh if (res16 and nl > 0) else (dh, None)
         handles = []
         overlap = reduce_gradients and self._world() > 1 and not (c.gradient_clip_val and c.gradient_clip_val > 0)
@@ -867,19 +885,30 @@ class MIGTTrainer:
                  and (self._world() == 1 or not reduce_gradients or (overlap and self.grad_allreduce_dtype == 'f32')))
         for i in reversed(range(c.n_layer)):
             p = f'h.{i}'
-            h_in, n1, qkv, att, h_mid, n2, u, f, lse = saved[i]
-            dy_mlp = dh16 if res16 else (T.dropout_add(dh, rate, seed, site_mlp(i), row0=row0) if rate else dh)      # d(mlp.c_proj output)
+            h_in, n1, qkv, att, att_i, h_mid, n2, u, f, lse, self._u_is_derivative = saved[i]
+            last = tail and i == c.n_layer - 1
+            Mi, drop_i = (Mx, drop_x) if last else (M, drop_of)
+            dy_mlp = dh16 if res16 else (T.dropout_add(dh, rate, seed, site_mlp(i), row0=drop_i(0)[3]) if rate else dh)      # d(mlp.c_proj output)
             if grad16 and self.fuse_gelu_backward:                                   # GELU backward in the epilogue of the dX GEMM that feeds it
-                du = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, M, dx_bf16=True, gelu_bwd_u=u)
+                du = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, Mi, dx_bf16=True, gelu_bwd_u=u)
             else:
-                df = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, M)
+                df = self._linear_bwd(p + '.mlp.c_proj', f, dy_mlp, Mi)
                 du = T.gelu_bwd(u, df, out_bf16=grad16)
-            dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, M)
-            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, M, res=dh, also_bf16=res16, drop=drop_of(site_resid(i)))  # (+ the residual branch's gradient)
+            dn2 = self._linear_bwd(p + '.mlp.c_fc', n2, du, Mi)
+            dh_mid = self._ln_bwd(p + '.ln_2', dn2, h_mid, Mi, res=dh, also_bf16=res16, drop=drop_i(site_resid(i)))  # (+ the residual branch's gradient)
             dh_mid, dh_mid16 = dh_mid if res16 else (dh_mid, None)
-            datt = self._linear_bwd(p + '.attn.c_proj', att,
-                                    dh_mid16 if res16 else (T.dropout_add(dh_mid, rate, seed, site_resid(i), row0=row0) if rate else dh_mid), M,
+            datt = self._linear_bwd(p + '.attn.c_proj', att_i,
+                                    dh_mid16 if res16 else (T.dropout_add(dh_mid, rate, seed, site_resid(i), row0=drop_i(0)[3]) if rate else dh_mid), Mi,
                                     dx_bf16=attn16)
+            if last:
+                # back to all rows for the attention backward and the block's first half: the main stream's rows of d(attention output) and of the
+                # residual-stream gradient are zeros (nothing downstream of them reached a loss)
+                full = torch.zeros((B, NS, S * L, datt.shape[-1]), dtype=datt.dtype, device=dev)
+                full[:, 1:] = datt.view(B, nb, S * L, datt.shape[-1])
+                datt = full.view(M, datt.shape[-1])
+                full = torch.zeros((B, NS, S * L, d), dtype=torch.float32, device=dev)
+                full[:, 1:] = dh_mid.view(B, nb, S * L, d)
+                dh_mid = full.view(M, d)
             if attn16:
                 dqkv = torch.empty((M, 3 * d), dtype=torch.bfloat16 if grad16 else torch.float32, device=dev)
                 T.attn_bwd_bf16(qkv[:, d:2 * d], qkv[:, 2 * d:], qkv[:, :d], att, datt, lse, dqkv[:, d:2 * d], dqkv[:, 2 * d:], dqkv[:, :d],
