@@ -77,6 +77,11 @@ VARIANTS = {
     # A/B only: the dQ kernel with a two-slot ring (48 KB: three workgroups per CU instead of two, one tile ahead instead of two)
     'dq_ring2': (['-DATB_DQ_RING=2'], ['attention_train_bf16']),
     # A/B only: the dK / dV kernel's dropout words hashed by every lane (one per score) instead of once per lane quad (same words, same masks)
+    # ablations of the backward attention kernels (results WRONG; timing only): no "tr" image DMAs / no tile compute / no tile DMAs
+    'atb_abl1': (['-DATB_ABL=1'], ['attention_train_bf16']),
+    'atb_abl2': (['-DATB_ABL=2'], ['attention_train_bf16']),
+    'atb_abl4': (['-DATB_ABL=4'], ['attention_train_bf16']),
+    'atb_abl9': (['-DATB_ABL=9'], ['attention_train_bf16']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 

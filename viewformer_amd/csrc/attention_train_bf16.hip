@@ -38,6 +38,10 @@ constexpr int DH = 64, KT = 64;
 constexpr int IMG = KT * DH * 2;             // one 64 x 64 bf16 image: 8 KB
 constexpr int OT = 128;                      // owner rows per workgroup: 4 waves x 32
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ATB_ABL
+#define ATB_ABL 0           // ablation builds (results WRONG, timing only; build.py 'atb_abl*'): 1 = no "tr" image DMAs, 2 = no tile compute, 4 = no tile DMAs at all,
+                            // 9 = 1 + the tr reads aliased onto the rows images: slots of 2 images, ring 3, three workgroups per CU (the timing a unified image would have)
+#endif
 #ifndef ATB_HEAVY_FIRST
 #define ATB_HEAVY_FIRST 1   // owner blocks dispatched heaviest first (round 6, vf_common.h: vf_attn_block_order); 0 = in index order
 #endif
@@ -86,6 +90,8 @@ template <int N>
 __device__ __forceinline__ void wait_loads() {                                   // this wave's loads: at most N outstanding; its LDS reads: done
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
 }
 
@@ -183,7 +189,8 @@ __device__ __forceinline__ void store_transposed_bf16(const f32x16 (&acc)[2], un
                                   // 'dq_ring2') measured the same within the order effect of an alternation (round 6: 162.3 vs 165.6 us for dQ + dK/dV
                                   // as second library, 160.5 vs 160.3 as first; bit-identical): occupancy is not what holds this kernel back
 #endif
-constexpr int DQ_SLOT = 3 * IMG, DQ_RING = ATB_DQ_RING, DQ_NL = 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
+constexpr int DQ_TRK = (ATB_ABL & 8) ? 0 : 2 * IMG;
+constexpr int DQ_SLOT = DQ_TRK + IMG < 2 * IMG ? 2 * IMG : DQ_TRK + IMG, DQ_RING = ATB_DQ_RING, DQ_NL = (ATB_ABL & 4) ? 0 : (ATB_ABL & 1) ? 4 : 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
 
 template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
@@ -256,9 +263,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
+            if (ATB_ABL & 4) continue;
             dma_rows_piece(k_rs, slot, pi, lane, ldk, kt);
             dma_rows_piece(v_rs, slot + IMG, pi, lane, ldv, kt);
-            dma_tr_piece(k_rs, slot + 2 * IMG, pi, lane, ldk, kt);
+            if (!(ATB_ABL & 1)) dma_tr_piece(k_rs, slot + DQ_TRK, pi, lane, ldk, kt);
         }
     };
     unsigned long long pend = need;                                  // tiles not issued yet
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         if (issued - 1 > i) wait_loads<DQ_NL>(); else wait_loads<0>();            // tile i has landed (at most the next tile is in flight)
         __builtin_amdgcn_s_barrier();                                              // ... for every wave; the slot of tile i - 1 is free
         if (issued < n) { issue(issued, next_tile()); ++issued; }
-        if (!active || !visible(qview, kt)) continue;
+        if (!active || !visible(qview, kt) || (ATB_ABL & 2)) continue;
         const unsigned char* slot = smem + (i % DQ_RING) * DQ_SLOT;
 
         f32x16 st[2], dp[2];
@@ -327,13 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 #ifdef VF_X_TRINTRIN
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const bf16x8 ka = tr_frag(slot + 2 * IMG + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
+                    const bf16x8 ka = tr_frag(slot + DQ_TRK + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
                     ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, ds[t2][ks2], ot[d], 0, 0, 0);   // dQ^T += K^T.dS^T
                 }
 #else
             {   // (vf_tr_frag2_wait, vf_common.h: through the intrinsic these reads drained the DMA ring — the NEXT tile — before this product)
                 bf16x8 ka0, ka1;
-                vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + tr_off, 2 * IMG + (t2 * 32 + ks2 * 16) * 64, 2 * IMG + 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
+                vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + tr_off, DQ_TRK + (t2 * 32 + ks2 * 16) * 64, DQ_TRK + 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
                 ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ds[t2][ks2], ot[0], 0, 0, 0);      // dQ^T += K^T.dS^T
                 ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ds[t2][ks2], ot[1], 0, 0, 0);
             }
@@ -347,7 +355,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
-constexpr int KV_SLOT = 4 * IMG + 512, KV_RING = 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
+constexpr int KV_QTR = (ATB_ABL & 8) ? 0 : 2 * IMG, KV_DOTR = (ATB_ABL & 8) ? IMG : 3 * IMG, KV_TAB = (ATB_ABL & 8) ? 2 * IMG : 4 * IMG;
+constexpr int KV_NL = (ATB_ABL & 4) ? 2 : (ATB_ABL & 1) ? 6 : 10;
+constexpr int KV_SLOT = KV_TAB + 512, KV_RING = (ATB_ABL & 8) ? 3 : 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
 
 template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
@@ -411,16 +421,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
+            if (ATB_ABL & 4) continue;
             dma_rows_piece(q_rs, slot, pi, lane, ldq, qt);
             dma_rows_piece(do_rs, slot + IMG, pi, lane, lddo, qt);
-            dma_tr_piece(q_rs, slot + 2 * IMG, pi, lane, ldq, qt);
-            dma_tr_piece(do_rs, slot + 3 * IMG, pi, lane, lddo, qt);
+            if (ATB_ABL & 1) continue;
+            dma_tr_piece(q_rs, slot + KV_QTR, pi, lane, ldq, qt);
+            dma_tr_piece(do_rs, slot + KV_DOTR, pi, lane, lddo, qt);
         }
         // lse / D of the tile's 64 queries (256 B each): 16 lanes x 16 B; every wave issues them (same bytes) so that all waves count
         // the same number of loads per tile
         if (lane < 16) {
-            bufds16(l_rs, slot + 4 * IMG, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
-            bufds16(d_rs, slot + 4 * IMG + 256, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
+            bufds16(l_rs, slot + KV_TAB, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
+            bufds16(d_rs, slot + KV_TAB + 256, (unsigned)(lane * 16), (unsigned)(qt * KT * 4));
         }
     };
     unsigned long long pend = need;
@@ -441,10 +453,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     for (int i = 0; i < n; ++i) {
         const int qt = __builtin_ctzll(todo);
         todo &= todo - 1;
-        wait_loads<0>();                                                           // (ring of 2: nothing else is in flight yet)
+        if (KV_RING > 2 && issued - 1 > i) wait_loads<KV_NL>(); else wait_loads<0>();   // (ring of 2: nothing else is in flight yet)
         __builtin_amdgcn_s_barrier();
         if (issued < n) { issue(issued, next_tile()); ++issued; }
-        if (!active || !visible(qt, kview)) continue;
+        if (!active || !visible(qt, kview) || (ATB_ABL & 2)) continue;
         const unsigned char* slot = smem + (i % KV_RING) * KV_SLOT;
 
 #pragma unroll
@@ -464,8 +476,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
             bf16x8 pf[2], sf[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + (32 * u + 8 * j + 4 * half) * 4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(slot + 4 * IMG + 256 + (32 * u + 8 * j + 4 * half) * 4);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(slot + KV_TAB + (32 * u + 8 * j + 4 * half) * 4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(slot + KV_TAB + 256 + (32 * u + 8 * j + 4 * half) * 4);
                 // accumulator row r = 4 j + e = query 64 qt + 32 u + 8 j + e + 4 half; its mask word belongs to (query, key >> 2): the SAME word in the
                 // four lanes of a quad (keys 4 m .. 4 m + 3, each using its own byte).  Lane c of the quad hashes the word of e = c, a DPP quad
                 // broadcast hands it round: 4 hashes per 16 scores instead of 16 (two 8-cycle integer multiplies each) — same words, same masks
@@ -502,12 +514,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
                 for (int d = 0; d < 2; ++d) {
 #ifdef VF_X_TRINTRIN
                     const unsigned off = tr_off + d * 4096 + (u * 32 + ks2 * 16) * 64;
-                    const bf16x8 oa = tr_frag(slot + 3 * IMG + off);
-                    const bf16x8 qa = tr_frag(slot + 2 * IMG + off);
+                    const bf16x8 oa = tr_frag(slot + KV_DOTR + off);
+                    const bf16x8 qa = tr_frag(slot + KV_QTR + off);
 #else
                     bf16x8 oa, qa;      // (vf_tr_frag2_wait: as intrinsics these reads made hipcc wait for the NEXT tile's DMA — no overlap at all)
-                    vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + tr_off, 3 * IMG + d * 4096 + (u * 32 + ks2 * 16) * 64,
-                                     2 * IMG + d * 4096 + (u * 32 + ks2 * 16) * 64, 8 * 64);
+                    vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + tr_off, KV_DOTR + d * 4096 + (u * 32 + ks2 * 16) * 64,
+                                     KV_QTR + d * 4096 + (u * 32 + ks2 * 16) * 64, 8 * 64);
 #endif
                     dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, pf[ks2], dvacc[d], 0, 0, 0);   // dV^T += dO^T.P
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sf[ks2], dkacc[d], 0, 0, 0);   // dK^T += Q^T.dS
