@@ -228,7 +228,9 @@ class OpTimer:
                         'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
                         'traffic': (lambda t: None if t is None else {'bytes': t['bytes'], 'over_algorithmic': round(t['bytes'] / (by // len(self.attn)), 3),
                                                                       'source': t['source']})(
-                            pmc_traffic('attn_dma_kernel', shape[1], 512, self.workload) if dma else None)},
+                            # (the counter passes ran over the default workload's launch — 128 scenes x 12 heads x 512 tokens; the trace's grid_x only carries the
+                            # head count, so any other shape would match it by accident: no figure for those)
+                            pmc_traffic('attn_dma_kernel', shape[1], 512, self.workload) if (dma and tuple(shape[:3]) == (128, 12, 512)) else None)},
                 'binding_roof_note': 'the north star prices this kernel against the MFMA peak; at 64 features per head and 64-token views its arithmetic intensity '
                                      '(useful FLOP per byte of q, k, v, o) puts the HBM roof BELOW the matrix roof — see hbm.frac (algorithmic bytes) and '
                                      'hbm.traffic (counter bytes incl. the re-read of key tiles by the second query block)',

@@ -13,7 +13,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(REPO, 'gpurun_out')
 E = os.path.join(OUT, 'evidence')
-TRAIN_GFLOP = 9861.0                 # GEMM family of one training step
+TRAIN_GFLOP = 9861.0                 # GEMM family of one ALL-ROWS training step; the run's own figure (bench line: summed over the launches made) is used when present
 GEMM_FAMILY = ('gemm_bf16_g256_kernel', 'gemm_tn_bf16_kernel', 'sum_slabs_kernel', 'igemm_f32_kernel', 'gemm_bf16_direct_kernel',
                'dense_small_n')
 
@@ -82,13 +82,14 @@ def main():
     n_steps = calls_adamw[0] if calls_adamw else steps
     tot = sum(r[3] for r in rows) / n_steps
     terms = ' + '.join(f'{r[3]:.3f} [{r[0][2:22]}]' for r in rows)
+    gflop = float(train['roofline'].get('algorithmic_gflop_per_step') or TRAIN_GFLOP)      # (the same code ran both: the launches' own flops)
     with open(P('train_step_kernel_trace.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats of: python bench.py --no-cpu-baseline --no-f32-arm --workload train --serial-wgrad --steps 3 '
                 '--warmup 1   (final code, tools/prof_bench.sh evidence_train)\n')
         f.write(f'# --serial-wgrad keeps the weight-gradient GEMMs on the main stream in EVERY step, so no duration below is stretched by a '
                 f'concurrent kernel ({n_steps} steps in the run).\n')
-        f.write(f'# GEMM family per step, recomputed from this table: ({terms}) / {n_steps} = {tot:.2f} ms -> {TRAIN_GFLOP:.0f} GFLOP / {tot:.2f} ms = '
-                f'{TRAIN_GFLOP / tot:.0f} TF = {TRAIN_GFLOP / tot / 2500:.3f} of the bf16 peak;\n')
+        f.write(f'# GEMM family per step, recomputed from this table: ({terms}) / {n_steps} = {tot:.2f} ms -> {gflop:.0f} GFLOP (summed over the launches made: figure of the bench line) / {tot:.2f} ms = '
+                f'{gflop / tot:.0f} TF = {gflop / tot / 2500:.3f} of the bf16 peak;\n')
         r = train['roofline']
         f.write(f'#   bench.py --workload train (HIP events, one serialised step, same gpurun call): {r.get("kernel_ms_per_step")} ms, '
                 f'{r["achieved"]} TF, {r["frac"]}\n')
