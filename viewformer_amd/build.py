@@ -82,6 +82,8 @@ VARIANTS = {
     'atb_abl2': (['-DATB_ABL=2'], ['attention_train_bf16']),
     'atb_abl4': (['-DATB_ABL=4'], ['attention_train_bf16']),
     'atb_abl9': (['-DATB_ABL=9'], ['attention_train_bf16']),
+    # A/B only: the dK / dV kernel's mask rotation as shl / shr / or (before the third session of round 6)
+    'dkv_rot3': (['-DVF_X_DKV_ROT3'], ['attention_train_bf16']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 

@@ -404,6 +404,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     // attention dropout: this lane's key is element krow & 3 of group (krow >> 2) of every query's row of groups
     uint32_t drop_key = 0u, drop_k = 0u;
     const int drop_j = krow & 3;
+#ifndef VF_X_DKV_ROT3
+    const uint32_t drop_rr = vf_dropout_rotr(drop_j);
+#endif
     if constexpr (DROP) {
         drop_key = vf_dropout_key(drop_seed, drop_site, drop_plane0 + (uint32_t)(b * H + h));
         drop_k = (uint32_t)(krow >> 2) + (uint32_t)(4 * half) * (uint32_t)(T >> 2);
@@ -501,7 +504,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 #else
                         const uint32_t w = w4[e];
 #endif
+#ifdef VF_X_DKV_ROT3
                         keep = vf_dropout_keep(w, drop_j, drop_thresh);
+#else
+                        keep = vf_dropout_keep_rotr(w, drop_rr, drop_thresh);           // (one v_alignbit_b32 instead of shl / shr / or: same decision)
+#endif
                         dpr = keep ? dpr * drop_scale : 0.f;
                     }
                     pf[r >> 3][r & 7] = keep ? (__bf16)p : (__bf16)0.f;          // (its 1 / (1 - rate) joins dV at the end)

@@ -218,6 +218,10 @@ __host__ __device__ __forceinline__ bool vf_dropout_keep(uint32_t word, int j, u
     const uint32_t s = 8u * ((uint32_t)j & 3u);
     return ((word << s) | (word >> ((32u - s) & 31u))) >= thresh;
 }
+// the same decision for a lane whose position j is a RUN-TIME value (the dK / dV kernel: j = key & 3 of the lane's key): rotl(word, 8 j) as ONE
+// v_alignbit_b32 by rr = vf_dropout_rotr(j), computed once per lane — hipcc does not fuse the shl / shr / or of the form above for a variable shift
+__device__ __forceinline__ uint32_t vf_dropout_rotr(int j) { return (32u - 8u * ((uint32_t)j & 3u)) & 31u; }
+__device__ __forceinline__ bool vf_dropout_keep_rotr(uint32_t word, uint32_t rr, uint32_t thresh) { return __builtin_amdgcn_alignbit(word, word, rr) >= thresh; }
 // one element of an [M][N] activation (generic, 64-bit safe; kernels that hold a whole group hash once and call vf_dropout_keep four times)
 __host__ __device__ __forceinline__ bool vf_dropout_keep_elem(uint32_t seed, uint32_t site, uint64_t m, uint32_t n, uint32_t N, uint32_t thresh) {
     const uint64_t g = (m >> 2) * (uint64_t)N + n;
