@@ -84,6 +84,13 @@ VARIANTS = {
     'atb_abl9': (['-DATB_ABL=9'], ['attention_train_bf16']),
     # A/B only: the dK / dV kernel's mask rotation as shl / shr / or (before the third session of round 6)
     'dkv_rot3': (['-DVF_X_DKV_ROT3'], ['attention_train_bf16']),
+    # A/B only: the dK / dV kernel with a rows image AND a tr image per streamed operand, ring of 2, two workgroups per CU (before the third session of round 6)
+    'dkv_two_images': (['-DATB_KV_UNI=0'], ['attention_train_bf16']),
+    # A/B only: the dQ kernel with K rows | V rows | K tr per slot (72 KB ring, two workgroups per CU)
+    'dq_three_images': (['-DATB_DQ_UNI=0'], ['attention_train_bf16']),
+    'dq_ring4': (['-DATB_DQ_RING=4'], ['attention_train_bf16']),
+    # A/B only: both backward attention kernels as before the third session of round 6 (separate rows / tr images, two workgroups per CU, shl / shr / or rotation)
+    'atb_session2': (['-DATB_KV_UNI=0', '-DATB_DQ_UNI=0', '-DVF_X_DKV_ROT3'], ['attention_train_bf16']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 

@@ -42,6 +42,14 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define ATB_ABL 0           // ablation builds (results WRONG, timing only; build.py 'atb_abl*'): 1 = no "tr" image DMAs, 2 = no tile compute, 4 = no tile DMAs at all,
                             // 9 = 1 + the tr reads aliased onto the rows images: slots of 2 images, ring 3, three workgroups per CU (the timing a unified image would have)
 #endif
+#ifndef ATB_KV_UNI
+#define ATB_KV_UNI 1        // dK / dV kernel: ONE LDS image per streamed operand serves the row reads AND the transposing reads (see dma_uni_piece); slots of two
+                            // images, ring of 3, three workgroups per CU.  0 = round 6's earlier form (rows image + tr image per operand, ring of 2; build.py 'dkv_two_images')
+#endif
+#ifndef ATB_DQ_UNI
+#define ATB_DQ_UNI 1        // dQ kernel: the K tile as ONE uni image (row reads for S^T, transposing reads for dQ^T), V as a uni image too; slots of two images
+                            // (48 KB ring: three workgroups per CU).  0 = K rows | V rows | K tr (build.py 'dq_three_images')
+#endif
 #ifndef ATB_HEAVY_FIRST
 #define ATB_HEAVY_FIRST 1   // owner blocks dispatched heaviest first (round 6, vf_common.h: vf_attn_block_order); 0 = in index order
 #endif
@@ -65,8 +73,8 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
     const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(p)));
     return __builtin_bit_cast(bf16x4, r);
 }
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {             // 8 consecutive k of the accumulator order: two 4-row groups
-    const bf16x4 v0 = tr_read(p), v1 = tr_read(p + 8 * 64);
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int gap = 8 * 64) {             // 8 consecutive k of the accumulator order: two 4-row groups
+    const bf16x4 v0 = tr_read(p), v1 = tr_read(p + gap);
     bf16x8 a;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { a[e] = v0[e]; a[4 + e] = v1[e]; }
@@ -90,6 +98,8 @@ template <int N>
 __device__ __forceinline__ void wait_loads() {                                   // this wave's loads: at most N outstanding; its LDS reads: done
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
@@ -105,6 +115,22 @@ __device__ __forceinline__ void dma_rows_piece(__amdgpu_buffer_rsrc_t rs, unsign
 __device__ __forceinline__ void dma_tr_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* img, int pi, int lane, int ld, int t) {
     const int row = (pi & 3) * 16 + (lane >> 2);
     bufds16(rs, img + pi * 1024, (unsigned)(row * ld * 2 + (pi >> 2) * 64 + (lane & 3) * 16), (unsigned)(t * KT * ld * 2));
+}
+
+// "uni" image of a 64 x 64 bf16 tile (8 KB = 512 cells of 16 B; r = tile row, c = 16-byte chunk of its 128-byte row):
+//     cell(r, c) = 16 ((r >> 2) 2 + (c >> 2)) + 4 (r & 3) + ((c & 3) ^ m(r >> 2)),     m(j) = (j & 1) | ((j >> 2 & 1) << 1)
+// i.e. a block of 4 rows x 64 bytes is one 256-byte bank line, its 16 cells ordered [row & 3][chunk & 3 ^ m].
+//   * the transposing read of a 32x32x16 A fragment (ds_read_b64_tr_b16: per 32-lane pass 4 rows x 64 bytes of one feature half) takes exactly one
+//     bank line — conflict-free like the contiguous "tr" image;
+//   * the row read (ds_read_b128, lane = row, one chunk column per pass) is served in 16-lane passes over rows {0-3, 12-15, 20-27} / {4-11, 16-19,
+//     28-31}: r & 3 takes every value four times per pass, with r >> 2 in {0, 3, 5, 6} resp. {1, 2, 4, 7} — m() is distinct on each of the two sets, so
+//     the 16 rows land in 16 distinct 16-byte slots — conflict-free like the XOR-swizzled "rows" image.
+// The LDS side of the DMA is lane-linear (lane i of piece pi writes cell 64 pi + i), so the permutation sits on the SOURCE address
+__device__ __forceinline__ int uni_m(int j) { return (j & 1) | (((j >> 2) & 1) << 1); }
+__device__ __forceinline__ void dma_uni_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* img, int pi, int lane, int ld, int t) {
+    const int j = 2 * pi + (lane >> 5), d = (lane >> 4) & 1, slot = lane & 15;
+    const int r = 4 * j + (slot >> 2), c = 4 * d + ((slot & 3) ^ uni_m(j));
+    bufds16(rs, img + pi * 1024, (unsigned)(r * ld * 2 + (c << 4)), (unsigned)(t * KT * ld * 2));
 }
 
 // D[b][h][t] = sum_d dO[t][h*64+d] * O[t][h*64+d] (bf16 in, fp32 out); 8 lanes per (row, head), 8 features each
@@ -189,8 +215,9 @@ __device__ __forceinline__ void store_transposed_bf16(const f32x16 (&acc)[2], un
                                   // 'dq_ring2') measured the same within the order effect of an alternation (round 6: 162.3 vs 165.6 us for dQ + dK/dV
                                   // as second library, 160.5 vs 160.3 as first; bit-identical): occupancy is not what holds this kernel back
 #endif
-constexpr int DQ_TRK = (ATB_ABL & 8) ? 0 : 2 * IMG;
-constexpr int DQ_SLOT = DQ_TRK + IMG < 2 * IMG ? 2 * IMG : DQ_TRK + IMG, DQ_RING = ATB_DQ_RING, DQ_NL = (ATB_ABL & 4) ? 0 : (ATB_ABL & 1) ? 4 : 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
+constexpr bool DQ_UNI = ATB_DQ_UNI != 0 && !(ATB_ABL & 8);
+constexpr int DQ_TRK = (DQ_UNI || (ATB_ABL & 8)) ? 0 : 2 * IMG;
+constexpr int DQ_SLOT = DQ_TRK + IMG < 2 * IMG ? 2 * IMG : DQ_TRK + IMG, DQ_RING = ATB_DQ_RING, DQ_NL = (ATB_ABL & 4) ? 0 : (DQ_UNI || (ATB_ABL & 1)) ? 4 : 6;      // K rows | V rows | K tr; 6 one-KB pieces per wave and tile
 
 template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
@@ -264,6 +291,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
             if (ATB_ABL & 4) continue;
+            if constexpr (DQ_UNI) {
+                dma_uni_piece(k_rs, slot, pi, lane, ldk, kt);
+                dma_uni_piece(v_rs, slot + IMG, pi, lane, ldv, kt);
+                continue;
+            }
             dma_rows_piece(k_rs, slot, pi, lane, ldk, kt);
             dma_rows_piece(v_rs, slot + IMG, pi, lane, ldv, kt);
             if (!(ATB_ABL & 1)) dma_tr_piece(k_rs, slot + DQ_TRK, pi, lane, ldk, kt);
@@ -282,12 +314,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
     const unsigned swz = (unsigned)((l31 >> 1) & 7);
     const unsigned row_off = (unsigned)(l31 * 128);
     const unsigned tr_off = (unsigned)((4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    // uni image (dma_uni_piece): row-read base of row l31, transposing-read bases for the 8-row groups with (r >> 4) & 1 = ks2
+    const int uni_ml = uni_m(l31 >> 2);
+    const unsigned uni_row = (unsigned)(512 * (l31 >> 2) + 64 * (l31 & 3));
+    const int uni_cq = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const unsigned uni_tr[2] = {(unsigned)(512 * half + 64 * ((lane & 15) >> 2) + 16 * (uni_cq ^ half) + 8 * (lane & 1)),
+                                (unsigned)(512 * half + 64 * ((lane & 15) >> 2) + 16 * (uni_cq ^ (half | 2)) + 8 * (lane & 1))};
 
     unsigned long long todo = need;
     for (int i = 0; i < n; ++i) {
         const int kt = __builtin_ctzll(todo);
         todo &= todo - 1;
-        if (issued - 1 > i) wait_loads<DQ_NL>(); else wait_loads<0>();            // tile i has landed (at most the next tile is in flight)
+        if (DQ_RING > 3 && issued - 2 > i) wait_loads<2 * DQ_NL>();               // tile i has landed (at most the next DQ_RING - 2 tiles are in flight)
+        else if (issued - 1 > i) wait_loads<DQ_NL>();
+        else wait_loads<0>();
         __builtin_amdgcn_s_barrier();                                              // ... for every wave; the slot of tile i - 1 is free
         if (issued < n) { issue(issued, next_tile()); ++issued; }
         if (!active || !visible(qview, kt) || (ATB_ABL & 2)) continue;
@@ -303,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                const unsigned off = row_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
+                const unsigned off = DQ_UNI ? uni_row + t2 * 4096 + (ks >> 1) * 256 + ((((unsigned)((ks & 1) * 2 + half)) ^ (unsigned)uni_ml) << 4)
+                                            : row_off + t2 * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + off);
                 const bf16x8 c = *reinterpret_cast<const bf16x8*>(slot + IMG + off);
                 st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], st[t2], 0, 0, 0);      // S^T = K.Q^T
@@ -335,13 +376,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 #ifdef VF_X_TRINTRIN
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const bf16x8 ka = tr_frag(slot + DQ_TRK + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
+                    const bf16x8 ka = DQ_UNI ? tr_frag(slot + DQ_TRK + uni_tr[ks2] + t2 * 4096 + ks2 * 2048 + d * 256, 1024)
+                                             : tr_frag(slot + DQ_TRK + tr_off + d * 4096 + (t2 * 32 + ks2 * 16) * 64);
                     ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, ds[t2][ks2], ot[d], 0, 0, 0);   // dQ^T += K^T.dS^T
                 }
 #else
             {   // (vf_tr_frag2_wait, vf_common.h: through the intrinsic these reads drained the DMA ring — the NEXT tile — before this product)
                 bf16x8 ka0, ka1;
-                vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + tr_off, DQ_TRK + (t2 * 32 + ks2 * 16) * 64, DQ_TRK + 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
+                if constexpr (DQ_UNI)
+                    vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + uni_tr[ks2], DQ_TRK + t2 * 4096 + ks2 * 2048, DQ_TRK + t2 * 4096 + ks2 * 2048 + 256, 1024);
+                else
+                    vf_tr_frag2_wait(ka0, ka1, vf_lds_addr(slot) + tr_off, DQ_TRK + (t2 * 32 + ks2 * 16) * 64, DQ_TRK + 4096 + (t2 * 32 + ks2 * 16) * 64, 8 * 64);
                 ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ds[t2][ks2], ot[0], 0, 0, 0);      // dQ^T += K^T.dS^T
                 ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ds[t2][ks2], ot[1], 0, 0, 0);
             }
@@ -355,9 +400,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
-constexpr int KV_QTR = (ATB_ABL & 8) ? 0 : 2 * IMG, KV_DOTR = (ATB_ABL & 8) ? IMG : 3 * IMG, KV_TAB = (ATB_ABL & 8) ? 2 * IMG : 4 * IMG;
-constexpr int KV_NL = (ATB_ABL & 4) ? 2 : (ATB_ABL & 1) ? 6 : 10;
-constexpr int KV_SLOT = KV_TAB + 512, KV_RING = (ATB_ABL & 8) ? 3 : 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
+constexpr bool KV_UNI = ATB_KV_UNI != 0 && !(ATB_ABL & 8);
+constexpr int KV_QTR = (KV_UNI || (ATB_ABL & 8)) ? 0 : 2 * IMG, KV_DOTR = (KV_UNI || (ATB_ABL & 8)) ? IMG : 3 * IMG, KV_TAB = (KV_UNI || (ATB_ABL & 8)) ? 2 * IMG : 4 * IMG;
+constexpr int KV_NL = (ATB_ABL & 4) ? 2 : (KV_UNI || (ATB_ABL & 1)) ? 6 : 10;
+constexpr int KV_SLOT = KV_TAB + 512, KV_RING = (KV_UNI || (ATB_ABL & 8)) ? 3 : 2;      // Q rows | dO rows | Q tr | dO tr | lse[64] | D[64]; 10 loads per wave and tile
 
 template <bool O16, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
@@ -425,6 +471,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
         for (int j = 0; j < 2; ++j) {
             const int pi = wave * 2 + j;
             if (ATB_ABL & 4) continue;
+            if constexpr (KV_UNI) {
+                dma_uni_piece(q_rs, slot, pi, lane, ldq, qt);
+                dma_uni_piece(do_rs, slot + IMG, pi, lane, lddo, qt);
+                continue;
+            }
             dma_rows_piece(q_rs, slot, pi, lane, ldq, qt);
             dma_rows_piece(do_rs, slot + IMG, pi, lane, lddo, qt);
             if (ATB_ABL & 1) continue;
@@ -451,6 +502,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     const unsigned swz = (unsigned)((l31 >> 1) & 7);
     const unsigned row_off = (unsigned)(l31 * 128);
     const unsigned tr_off = (unsigned)((4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    // uni image (dma_uni_piece): this lane's row-read base (row l31 of a 32-row half, chunk column added per k-step) and its two transposing-read bases
+    // (rows 4 half + ((lane & 15) >> 2) of an 8-row group whose (r >> 4) & 1 = ks2; 8-byte piece (lane & 3) of the 32-byte column block (lane >> 4) & 1)
+    const int uni_ml = uni_m(l31 >> 2);
+    const unsigned uni_row = (unsigned)(512 * (l31 >> 2) + 64 * (l31 & 3));
+    const int uni_cq = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const unsigned uni_tr[2] = {(unsigned)(512 * half + 64 * ((lane & 15) >> 2) + 16 * (uni_cq ^ half) + 8 * (lane & 1)),
+                                (unsigned)(512 * half + 64 * ((lane & 15) >> 2) + 16 * (uni_cq ^ (half | 2)) + 8 * (lane & 1))};
 
     unsigned long long todo = need;
     for (int i = 0; i < n; ++i) {
@@ -469,7 +527,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const unsigned off = row_off + u * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
+                const unsigned off = KV_UNI ? uni_row + u * 4096 + (ks >> 1) * 256 + ((((unsigned)((ks & 1) * 2 + half)) ^ (unsigned)uni_ml) << 4)
+                                            : row_off + u * 4096 + ((((unsigned)(ks * 2 + half)) ^ swz) << 4);
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + off);
                 const bf16x8 c = *reinterpret_cast<const bf16x8*>(slot + IMG + off);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb[ks], st, 0, 0, 0);              // S = Q.K^T   [query][key]
@@ -520,13 +579,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
 #ifdef VF_X_TRINTRIN
-                    const unsigned off = tr_off + d * 4096 + (u * 32 + ks2 * 16) * 64;
-                    const bf16x8 oa = tr_frag(slot + KV_DOTR + off);
-                    const bf16x8 qa = tr_frag(slot + KV_QTR + off);
+                    const unsigned off = KV_UNI ? uni_tr[ks2] + u * 4096 + ks2 * 2048 + d * 256 : tr_off + d * 4096 + (u * 32 + ks2 * 16) * 64;
+                    const bf16x8 oa = tr_frag(slot + KV_DOTR + off, KV_UNI ? 1024 : 8 * 64);
+                    const bf16x8 qa = tr_frag(slot + KV_QTR + off, KV_UNI ? 1024 : 8 * 64);
 #else
                     bf16x8 oa, qa;      // (vf_tr_frag2_wait: as intrinsics these reads made hipcc wait for the NEXT tile's DMA — no overlap at all)
-                    vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + tr_off, KV_DOTR + d * 4096 + (u * 32 + ks2 * 16) * 64,
-                                     KV_QTR + d * 4096 + (u * 32 + ks2 * 16) * 64, 8 * 64);
+                    if constexpr (KV_UNI)
+                        vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + uni_tr[ks2], KV_DOTR + u * 4096 + ks2 * 2048 + d * 256,
+                                         KV_QTR + u * 4096 + ks2 * 2048 + d * 256, 1024);
+                    else
+                        vf_tr_frag2_wait(oa, qa, vf_lds_addr(slot) + tr_off, KV_DOTR + d * 4096 + (u * 32 + ks2 * 16) * 64,
+                                         KV_QTR + d * 4096 + (u * 32 + ks2 * 16) * 64, 8 * 64);
 #endif
                     dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, pf[ks2], dvacc[d], 0, 0, 0);   // dV^T += dO^T.P
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, sf[ks2], dkacc[d], 0, 0, 0);   // dK^T += Q^T.dS
