@@ -91,6 +91,8 @@ VARIANTS = {
     'dq_ring4': (['-DATB_DQ_RING=4'], ['attention_train_bf16']),
     # A/B only: both backward attention kernels as before the third session of round 6 (separate rows / tr images, two workgroups per CU, shl / shr / or rotation)
     'atb_session2': (['-DATB_KV_UNI=0', '-DATB_DQ_UNI=0', '-DVF_X_DKV_ROT3'], ['attention_train_bf16']),
+    # A/B only: the forward DMA-ring attention with a three-slot ring (48 KB: three workgroups per CU, two tiles in flight)
+    'adma_ring3': (['-DADMA_RING=3'], ['attention_dma']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 

@@ -64,7 +64,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int DH = 64, KT = 64, QT = 256;
 constexpr int K_BYTES = KT * DH * 2;         // 8192
 constexpr int TILE_BYTES = 2 * K_BYTES;      // K image then V image
-constexpr int RING = 4;
+#ifndef ADMA_RING
+#define ADMA_RING 4         // 4 slots = 64 KB: two workgroups per CU, three tiles in flight.  3 slots = 48 KB: THREE workgroups per CU, two tiles in flight, and the
+                            // first tile steps one ahead only (Q lands in slots 1-2, so tiles 1 and 2 are issued behind the first barrier) — build.py 'adma_ring3'
+#endif
+constexpr int RING = ADMA_RING;
+static_assert(RING == 3 || RING == 4, "ring depth");
 constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_PSWAP
 #define ADMA_PSWAP 1
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         }
     };
     // Q: the wave's 32 U rows -> its private slice of ring slots 2-3 (same swizzled row image as K)
-    unsigned char* Qs = smem + 2 * TILE_BYTES + wave * QB;
+    unsigned char* Qs = smem + (RING - 2) * TILE_BYTES + wave * QB;
 #pragma unroll
     for (int pi = 0; pi < 4 * U; ++pi) {
         const int r = pi * 8 + pr;
@@ -264,8 +269,8 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         bufds16(q_rs, Qs + pi * 1024, (unsigned)(row * ldq * 2 + ((pc ^ ((r >> 1) & 7)) << 4)), 0u);
     }
     issue_tile(0);
-    if (ntiles > 1) issue_tile(1);
-    if (ntiles > 1) wait_vm<2 * LPT>(); else wait_vm<LPT>();         // Q has landed (vmcnt retires in issue order)
+    if (RING == 4 && ntiles > 1) issue_tile(1);
+    if (RING == 4 && ntiles > 1) wait_vm<2 * LPT>(); else wait_vm<LPT>();         // Q has landed (vmcnt retires in issue order)
     // Q fragments (B operand of S^T = K.Q^T): qb[u][ks] = Q[32 u + l31][16 ks + 8 half + 0..7] * scale * log2 e, re-rounded to bf16 (FOLD)
     const unsigned swz = (unsigned)((l31 >> 1) & 7);
     const float c2 = scale * LOG2E;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         // this wave's pieces of tile kt have landed (counted: up to two later tiles stay in flight), its LDS reads of tile kt - 1 (and
         // of Q) are done; the barrier extends both to the workgroup, which frees the slot of tile kt - 1 (kt = 0: the Q slots)
         ADMA_STAMP(0);
-        const int last_issued = min(ntiles - 1, kt == 0 ? 1 : kt + 2);
+        const int last_issued = RING == 4 ? min(ntiles - 1, kt == 0 ? 1 : kt + 2) : min(ntiles - 1, kt == 0 ? 0 : kt + 1);
         if (last_issued - kt >= 2) wait_vm_lgkm0<2 * LPT>();
         else if (last_issued - kt == 1) wait_vm_lgkm0<LPT>();
         else wait_vm_lgkm0<0>();
@@ -466,10 +471,10 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         else if (kt + 3 < ntiles) { asm volatile("s_nop 0"); }
 #else
         if (kt == 0) {
-            if (ntiles > 2) issue_tile(2);
-            if (ntiles > 3) issue_tile(3);
-        } else if (kt + 3 < ntiles) {
-            issue_tile(kt + 3);
+            if (ntiles > RING - 2) issue_tile(RING - 2);
+            if (ntiles > RING - 1) issue_tile(RING - 1);
+        } else if (kt + RING - 1 < ntiles) {
+            issue_tile(kt + RING - 1);
         }
 #endif
 #ifdef ADMA_X_NOCOMPUTE
