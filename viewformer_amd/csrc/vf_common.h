@@ -326,6 +326,21 @@ VF_REG_FLAG(VF_X6_CLOCKPROBE)
 #ifdef VF_X_DKV_HASH_PER_ELEMENT      // A/B: the dK / dV kernel's dropout words hashed by every lane (round 5's form) instead of once per lane quad
 VF_REG_FLAG(VF_X_DKV_HASH_PER_ELEMENT)
 #endif
+#ifdef VF_X_DKV_ROT3      // A/B: the dK / dV kernel's mask rotation as shl / shr / or (before the third session of round 6)
+VF_REG_FLAG(VF_X_DKV_ROT3)
+#endif
+#if defined(ATB_ABL) && ATB_ABL      // ablation builds of the backward attention kernels (results wrong, timing only)
+VF_REG_FLAG(ATB_ABL)
+#endif
+#if defined(ATB_KV_UNI) && !ATB_KV_UNI      // A/B: rows image + tr image per streamed operand in the dK / dV kernel
+VF_REG_FLAG(ATB_KV_UNI)
+#endif
+#if defined(ATB_DQ_UNI) && !ATB_DQ_UNI      // A/B: K rows | V rows | K tr per slot in the dQ kernel
+VF_REG_FLAG(ATB_DQ_UNI)
+#endif
+#if defined(ADMA_RING) && ADMA_RING != 4    // A/B: the forward DMA-ring attention with three slots
+VF_REG_FLAG(ADMA_RING)
+#endif
 #ifdef VF_X_TRINTRIN      // A/B: the transposing LDS reads through the compiler intrinsic again (hipcc then drains vmcnt in front of them)
 VF_REG_FLAG(VF_X_TRINTRIN)
 #endif
