@@ -10,13 +10,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from viewformer_amd import geometry  # noqa: E402
+from viewformer_amd import _lib, geometry  # noqa: E402
 from viewformer_amd.config import MIGTConfig  # noqa: E402
 from viewformer_amd.migt import MIGT  # noqa: E402
 from viewformer_amd.train import MIGTTrainer  # noqa: E402
 from viewformer_amd.weights import make_migt_weights, synthetic_scene_batch  # noqa: E402
 
-from viewformer_amd import _lib  # noqa: E402
 libs = {os.path.basename(p): _lib.load_variant(p) for p in sys.argv[1:]}
 vals = list(libs)
 rounds = int(os.environ.get('AB_ROUNDS', 6))
@@ -34,21 +33,19 @@ poses = geometry.normalize_cameras(geometry.to_relative_cameras(torch.from_numpy
 for _ in range(3):
     tr.train_step(poses, tokens)
 torch.cuda.synchronize()
-ms = {repr(v): [] for v in vals}
+ms = {v: [] for v in vals}
 for r in range(rounds):
     order = vals if r % 2 == 0 else vals[::-1]
     for v in order:
-        ctx = _lib.use(libs[v])
-        ctx.__enter__()
-        tr.train_step(poses, tokens)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(steps):
-            met = tr.train_step(poses, tokens)
-        e1.record()
-        torch.cuda.synchronize()
-        ms[repr(v)].append(e0.elapsed_time(e1) / steps)
-        ctx.__exit__()
+        with _lib.use(libs[v]):
+            tr.train_step(poses, tokens)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                met = tr.train_step(poses, tokens)
+            e1.record()
+            torch.cuda.synchronize()
+            ms[v].append(e0.elapsed_time(e1) / steps)
 print(json.dumps({'libraries': vals, 'ms_per_step_median': {k: round(statistics.median(v), 3) for k, v in ms.items()},
                   'ms_per_step_all': {k: [round(x, 3) for x in v] for k, v in ms.items()}, 'loss_finite': bool(torch.isfinite(met['loss']))}))
