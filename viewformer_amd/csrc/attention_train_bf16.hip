@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
     // attention dropout: this lane's key is element krow & 3 of group (krow >> 2) of every query's row of groups
     uint32_t drop_key = 0u, drop_k = 0u;
     const int drop_j = krow & 3;
+    const float drop_cs = drop_scale * scale;
 #ifndef VF_X_DKV_ROT3
     const uint32_t drop_rr = vf_dropout_rotr(drop_j);
 #endif
@@ -568,8 +569,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 #else
                         keep = vf_dropout_keep_rotr(w, drop_rr, drop_thresh);           // (one v_alignbit_b32 instead of shl / shr / or: same decision)
 #endif
+#ifdef VF_X_DKV_SEL2
                         dpr = keep ? dpr * drop_scale : 0.f;
+#endif
                     }
+#ifndef VF_X_DKV_SEL2
+                    if constexpr (DROP) {
+                        // one select instead of two: dS = scale (c keep P dP - P D) with keep P formed once (it is dV's operand too)
+                        const float pk = keep ? p : 0.f;
+                        pf[r >> 3][r & 7] = (__bf16)pk;                         // (its 1 / (1 - rate) joins dV at the end)
+                        sf[r >> 3][r & 7] = (__bf16)__builtin_fmaf(pk, dpr * drop_cs, -(p * (d4[e] * scale)));
+                        continue;
+                    }
+#endif
                     pf[r >> 3][r & 7] = keep ? (__bf16)p : (__bf16)0.f;          // (its 1 / (1 - rate) joins dV at the end)
                     sf[r >> 3][r & 7] = (__bf16)(p * (dpr - d4[e]) * scale);
                 }

@@ -326,6 +326,9 @@ VF_REG_FLAG(VF_X6_CLOCKPROBE)
 #ifdef VF_X_DKV_HASH_PER_ELEMENT      // A/B: the dK / dV kernel's dropout words hashed by every lane (round 5's form) instead of once per lane quad
 VF_REG_FLAG(VF_X_DKV_HASH_PER_ELEMENT)
 #endif
+#ifdef VF_X_DKV_SEL2      // A/B: the dK / dV kernel's dropout with two selects per score (dP and P) instead of one
+VF_REG_FLAG(VF_X_DKV_SEL2)
+#endif
 #ifdef VF_X_DKV_ROT3      // A/B: the dK / dV kernel's mask rotation as shl / shr / or (before the third session of round 6)
 VF_REG_FLAG(VF_X_DKV_ROT3)
 #endif
