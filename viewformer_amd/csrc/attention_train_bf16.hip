@@ -3,7 +3,11 @@
 // Flash-style like attention_bwd_f32.hip — P is re-materialised tile by tile from q, k and the forward's per-query log-sum-exp, masked
 // tiles are skipped, no atomics (a query-major dQ kernel and a key-major dK / dV kernel) — but on v_mfma_f32_32x32x16_bf16 with bf16
 // q / k / v / dO in HBM (the c_attn GEMM and the c_proj dX GEMM write them as bf16) and every streamed tile moved HBM -> LDS by
-// LDS-DMA, in the layouts of attention_dma.hip:
+// LDS-DMA.  A streamed 64 x 64 tile is read in two ways — its rows as ds_read_b128 A fragments (k = features) and, through
+// ds_read_b64_tr_b16, its TRANSPOSE as A fragments (feature rows, k = the streamed rows) — and since the third session of round 6 ONE
+// 8 KB image per tile serves both (the "uni" image, dma_uni_piece below: a 4-row x 64-byte block per 256-byte bank line): 16-16.5 KB per
+// ring slot, three workgroups per CU.  The layouts it replaced (still here behind -DATB_KV_UNI=0 / -DATB_DQ_UNI=0 for A/B, same results
+// bit for bit) are attention_dma.hip's:
 //   * "rows" image of a 64 x 64 tile: 128-byte rows, 16-byte chunk index XORed with bits 1..3 of the row -> conflict-free ds_read_b128
 //     A fragments (rows of the streamed operand, k = features);
 //   * "tr" image: [feature half][row][32 features], read with ds_read_b64_tr_b16 -> the TRANSPOSED A fragment (feature rows, k = the
