@@ -94,6 +94,8 @@ VARIANTS = {
     # A/B only: the forward DMA-ring attention with a three-slot ring (48 KB: three workgroups per CU, two tiles in flight)
     'adma_ring3': (['-DADMA_RING=3'], ['attention_dma']),
     'dkv_sel2': (['-DVF_X_DKV_SEL2'], ['attention_train_bf16']),
+    # A/B only: the forward DMA-ring attention with four CONSECUTIVE query views per workgroup under the streams mask too
+    'adma_consecutive': (['-DADMA_REGROUP=0'], ['attention_dma']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 

@@ -77,9 +77,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADMA_HEAVY_FIRST
 #define ADMA_HEAVY_FIRST 1  // query blocks dispatched heaviest first (round 6); 0 = in index order (round 5)
 #endif
-#ifndef ADMA_PAIRGRID
-#define ADMA_PAIRGRID 0     // the query blocks of a (scene, head) adjacent on one XCD (round 5 A/B; 0 = all first blocks, then all second blocks)
+#ifndef ADMA_REGROUP
+#define ADMA_REGROUP 1      // streams mask: query views grouped so that a workgroup's views share their key tiles (vf_common.h: vf_attn_query_groups); 0 = four
+                            // consecutive views per workgroup (build.py 'adma_consecutive')
 #endif
+// (round 5 A/B, removed with the view groups: ADMA_PAIRGRID — the query blocks of a (scene, head) adjacent on one XCD: fewer HBM re-reads, 20 % slower)
 constexpr float ADMA_THR = 8.0f;             // a query's reference maximum moves when a tile exceeds it by more than this (exponent-of-2 units)
 
 __device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t r, void* l, unsigned voff, unsigned soff) {
@@ -137,7 +139,7 @@ template <bool DROP, int U>
 __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ v, __bf16* __restrict__ out, int H, int T, int ldq,
     int ldk, int ldv, int ldo, float scale, int twin, float* __restrict__ lse_out, uint32_t drop_thresh, float drop_scale, uint32_t drop_seed,
-    uint32_t drop_site, uint32_t drop_plane0, vf_attn_order order) {
+    uint32_t drop_site, uint32_t drop_plane0, vf_attn_groups groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // RING x (K image | V image)
     constexpr int NW = 8 / U;                  // waves per workgroup
     constexpr int PW = 8 / NW;                 // 1 KB pieces of K (and of V) a wave moves per tile
@@ -148,38 +150,21 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    // grid (H, B, query blocks): all blocks of one kind back to back — measured faster than interleaving two kinds on a CU (145 us) although the
-    // later kind re-reads key tiles from HBM — and, since round 6, the HEAVIEST kind first (order.blk: the launch no longer ends with a partly
-    // filled round of its longest workgroups)
-#if ADMA_PAIRGRID
-    // the query blocks of one (scene, head) on ONE XCD, dispatched back to back (heavy block first): the light block's key tiles are then L2 hits
-    int qblk = (int)blockIdx.z, h = (int)blockIdx.x;
-    size_t b = blockIdx.y;
-    {
-        const unsigned NQ = gridDim.z, BH = gridDim.x * gridDim.y;
-        if (NQ > 1 && (BH & 7u) == 0u) {
-            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      // dispatch order: XCD = lin % 8
-            const unsigned x = lin & 7u, sl = lin >> 3;
-            const unsigned pr = sl / NQ, zz = sl - pr * NQ;
-            const unsigned bh = x + 8u * pr;
-            qblk = (int)(NQ - 1u - zz);
-            h = (int)(bh % gridDim.x);
-            b = bh / gridDim.x;
-        }
-    }
-#else
-    const int qblk = (int)order.blk[blockIdx.z];           // heaviest query block first (vf_common.h: vf_attn_block_order)
+    // grid (H, B, query groups): all groups of one kind back to back — measured faster than interleaving two kinds on a CU (145 us) although the
+    // later kind re-reads key tiles from HBM — and, since round 6, the HEAVIEST kind first (the launch no longer ends with a partly filled round of
+    // its longest workgroups)
+    // a workgroup = one GROUP of up to four query views (vf_common.h: vf_attn_query_groups — four consecutive views, or under the streams mask views that
+    // share their key tiles), groups in dispatch order heaviest first
+    const int grp = (int)blockIdx.z;
     const int h = blockIdx.x;
     const size_t b = blockIdx.y;
-#endif
-    const int q0 = qblk * QT;
-    // U = 2: wave w is view w of the block.  U = 1: waves w and 7 - w share view min(w, 7 - w) (first / second 32 queries): with waves going
-    // to SIMDs round-robin, every SIMD of the CU then hosts an early (few visible tiles) and a late view of the block
+    // U = 2: wave w is view w of the group.  U = 1: waves w and 7 - w share view min(w, 7 - w) (first / second 32 queries): with waves going
+    // to SIMDs round-robin, every SIMD of the CU then hosts an early (few visible tiles) and a late view of the group
     const int wview = U == 2 ? wave : (wave < 4 ? wave : 7 - wave);
-    const int qw0 = q0 + wview * 64 + (U == 2 ? 0 : (wave >> 2) * 32);
     const int nviews = T / KT;
-    const int qview = q0 / KT + wview;                     // this wave's view (>= nviews: the wave only helps moving tiles)
+    const int qview = groups.view[grp][wview];             // this wave's view (0xFF / >= nviews: the wave only helps moving tiles)
     const bool active = qview < nviews;
+    const int qw0 = (active ? qview : 0) * 64 + (U == 2 ? 0 : (wave >> 2) * 32);
 
     const unsigned char* qb8 = reinterpret_cast<const unsigned char*>(q + b * (size_t)T * ldq + h * DH);
     const unsigned char* kb8 = reinterpret_cast<const unsigned char*>(k + b * (size_t)T * ldk + h * DH);
@@ -205,13 +190,15 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
     // at least one of its four query views sees (round 3: under the training step's 3-stream mask a workgroup of stream 1 / 2 walked every
     // tile below it, 142 tile steps per (scene, head) for the 78 some wave needs).  `need` = bit kv set <=> some wave sees key view kv, from the
     // closed forms of visible(); the issue and the consume pointer pop its bits in ascending order, ring slots go by SEQUENCE index.
-    const int nwalk = min(nviews, q0 / KT + QT / KT);
+    int vmax = 0;
+    for (int w = 0; w < QT / KT; ++w) { const int qv = groups.view[grp][w]; if (qv < nviews) vmax = max(vmax, qv); }
+    const int nwalk = min(nviews, vmax + 1);
     const bool dense = nwalk > 64;                          // (more than 64 key views: walk them all)
     unsigned long long need = 0;
     if (!dense) {
         for (int w = 0; w < QT / KT; ++w) {
-            const int qv = q0 / KT + w;
-            if (qv >= nviews) break;
+            const int qv = groups.view[grp][w];
+            if (qv >= nviews) continue;
             // this view sees key views [0, lim) and itself.  Streams: stream 0 sees views 0 .. qi (qi is the view itself); streams >= 1 the
             // stream-0 views below qi
             const int lim = Sv > 0 ? qv % Sv : min(qv, Vc);
@@ -560,12 +547,13 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
     if (drop_rate > 0.f && (unsigned long long)T * (unsigned long long)(T >> 2) >= (1ull << 32)) return VF_ERR_UNSUPPORTED;                   // 32-bit mask groups per plane
     const __bf16 *q_ = reinterpret_cast<const __bf16*>(q), *k_ = reinterpret_cast<const __bf16*>(k), *v_ = reinterpret_cast<const __bf16*>(v);
     __bf16* o_ = reinterpret_cast<__bf16*>(out);
-    const dim3 grid((unsigned)H, (unsigned)B, (unsigned)((T + QT - 1) / QT));
+    const vf_attn_groups groups = vf_attn_query_groups(T / KT, twin_view, ADMA_REGROUP != 0, ADMA_HEAVY_FIRST != 0);
+    const dim3 grid((unsigned)H, (unsigned)B, (unsigned)groups.n);
     const uint32_t thr = vf_dropout_thresh(drop_rate);
     const float dsc = 1.0f / (1.0f - drop_rate);
     const int nq = (T + QT - 1) / QT;
     if (nq > 64) return VF_ERR_UNSUPPORTED;
-    const vf_attn_order order = vf_attn_block_order(T / KT, QT / KT, nq, twin_view, false, ADMA_HEAVY_FIRST != 0);
+
     auto launch = [&](auto drop, auto u) -> int {
         constexpr bool DROP = decltype(drop)::value;
         constexpr int U = decltype(u)::value;
@@ -576,7 +564,7 @@ int vf_attn_dma_launch(const void* q, const void* k, const void* v, void* out, i
             vf_attr_done(&attr_devs);
         }
         hipLaunchKernelGGL((attn_dma_kernel<DROP, U>), grid, dim3(U == 2 ? 256 : 512), (size_t)RING * TILE_BYTES, stream, q_, k_, v_, o_, H, T, ldq, ldk, ldv, ldo,
-                           scale, twin_view, lse_out, thr, dsc, drop_seed, drop_site, drop_plane0, order);
+                           scale, twin_view, lse_out, thr, dsc, drop_seed, drop_site, drop_plane0, groups);
         return vf_last_status();
     };
     using D1 = std::true_type;

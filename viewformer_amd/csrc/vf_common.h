@@ -341,6 +341,9 @@ VF_REG_FLAG(ATB_KV_UNI)
 #if defined(ATB_DQ_UNI) && !ATB_DQ_UNI      // A/B: K rows | V rows | K tr per slot in the dQ kernel
 VF_REG_FLAG(ATB_DQ_UNI)
 #endif
+#if defined(ADMA_REGROUP) && !ADMA_REGROUP    // A/B: four consecutive query views per workgroup under the streams mask
+VF_REG_FLAG(ADMA_REGROUP)
+#endif
 #if defined(ADMA_RING) && ADMA_RING != 4    // A/B: the forward DMA-ring attention with three slots
 VF_REG_FLAG(ADMA_RING)
 #endif
@@ -392,6 +395,64 @@ static inline vf_attn_order vf_attn_block_order(int nviews, int vpb, int nblocks
         o.blk[j + 1] = bi;
     }
     return o;
+}
+
+// Query-view GROUPS of the forward DMA-ring kernel (attention_dma.hip; third session of round 6).  A workgroup of that kernel serves up to four query
+// views and walks the UNION of the key views they see, one barrier per key tile, so what a launch costs is the sum of the groups' union sizes.  Four
+// CONSECUTIVE views are the right group under the causal and twin masks; under the training step's STREAMS mask (Sv views per stream, stream 0 = the
+// sequence, streams >= 1 = branch views that see the sequence's views below their own index plus themselves) they are not: branch view i of every
+// stream sees the same sequence views, so {stream 1 view i, stream 2 view i, stream 1 view i - 1, stream 2 view i - 1} shares i sequence tiles where four
+// consecutive views of one stream share i - 2 and walk i + 2.  Grouping (regroup = true, streams mask): the sequence's views four by four; a last
+// partial group is topped up with the highest branch views; the branch views by descending index (all streams of an index together) four by four.
+// 3 x 10 views: 62 tile steps per (scene, head) instead of 75.  Every wave still walks ITS keys in ascending order: results are bit-identical.
+// Groups are dispatched heaviest first (as the blocks of vf_attn_block_order).  view = 0xFF: no view (the wave only helps moving tiles).
+struct vf_attn_groups { unsigned char view[64][4]; int n; };
+static inline vf_attn_groups vf_attn_query_groups(int nviews, int twin, bool regroup, bool heaviest_first) {
+    vf_attn_groups g;
+    for (int i = 0; i < 64; ++i) for (int j = 0; j < 4; ++j) g.view[i][j] = 0xFF;
+    g.n = 0;
+    unsigned char list[256];
+    int nl = 0;
+    const int Sv = twin <= -2 ? -twin : 0;
+    if (regroup && Sv > 0 && nviews % Sv == 0 && nviews / Sv >= 2 && nviews <= 255) {
+        const int NS = nviews / Sv;
+        for (int v = 0; v < Sv; ++v) list[nl++] = (unsigned char)v;                       // the sequence's views, ascending
+        const int pad = (4 - Sv % 4) % 4;                                                 // branch views that complete its last group
+        int taken = 0;
+        // branch views by descending index, the streams of an index together
+        unsigned char br[256];
+        int nb = 0;
+        for (int i = Sv - 1; i >= 0; --i)
+            for (int s_ = 1; s_ < NS; ++s_) br[nb++] = (unsigned char)(s_ * Sv + i);
+        for (; taken < pad && taken < nb; ++taken) list[nl++] = br[taken];
+        while (nl % 4) list[nl++] = 0xFF;
+        for (int i = taken; i < nb; ++i) list[nl++] = br[i];
+    } else {
+        for (int v = 0; v < nviews && v < 256; ++v) list[nl++] = (unsigned char)v;
+    }
+    while (nl % 4) list[nl++] = 0xFF;
+    g.n = nl / 4 > 64 ? 64 : nl / 4;
+    int w[64];
+    for (int b = 0; b < g.n; ++b) {
+        int cnt = 0;
+        for (int t = 0; t < nviews; ++t) {
+            bool any = false;
+            for (int j = 0; j < 4 && !any; ++j) { const int v = list[4 * b + j]; any = v != 0xFF && vf_attn_visible(v, t, twin); }
+            cnt += any;
+        }
+        w[b] = cnt;
+    }
+    int ord[64];
+    for (int b = 0; b < g.n; ++b) ord[b] = b;
+    if (heaviest_first)
+        for (int i = 1; i < g.n; ++i) {                                                   // stable insertion sort, descending weight
+            const int bi = ord[i];
+            int j = i - 1;
+            while (j >= 0 && w[ord[j]] < w[bi]) { ord[j + 1] = ord[j]; --j; }
+            ord[j + 1] = bi;
+        }
+    for (int b = 0; b < g.n; ++b) for (int j = 0; j < 4; ++j) g.view[b][j] = list[4 * ord[b] + j];
+    return g;
 }
 
 // ---- ds_read_b64_tr_b16 behind inline asm (round 5) ---------------------------------------------------------------------------------
