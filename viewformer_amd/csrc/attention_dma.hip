@@ -509,7 +509,7 @@ __global__ __launch_bounds__(U == 2 ? 256 : 512, U == 2 ? 2 : 4) void attn_dma_k
         const int row = u * 32 + l31;
 #ifndef ADMA_STAMPS
         // the training step's flash backward re-materialises P = exp(S scale - lse) from this per-query log-sum-exp (natural-log units)
-        if (lse_out && half == 0) lse_out[((size_t)b * H + h) * T + qw0 + row] = m_ref[u] * 0.69314718055994531f + logf(l_tot);
+        if (lse_out && half == 0) lse_out[((size_t)b * H + h) * T + qw0 + row] = __builtin_fmaf(m_ref[u], 0.69314718055994531f, logf(l_tot));      // (spelled as ONE fma: left to the compiler, the contraction depended on the code around it — 1-ulp differences between two builds of this file)
 #endif
 #pragma unroll
         for (int d = 0; d < 2; ++d)
