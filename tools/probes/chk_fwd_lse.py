@@ -1,5 +1,11 @@
-import sys, os, torch
-sys.path.insert(0, '/root/repo')
+"""Forward bf16 attention with log-sum-exp at the training shape through several builds of the library: are out and lse equal bit for bit?
+usage: python tools/probes/chk_fwd_lse.py lib1.so lib2.so"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from viewformer_amd import _lib
 from viewformer_amd import train_ops as T
 dev = torch.device('cuda:0')
