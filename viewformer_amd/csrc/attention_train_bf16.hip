@@ -97,6 +97,38 @@ struct Vis {
     }
 };
 __device__ __forceinline__ Vis make_vis(int twin) { return Vis{twin >= 0 ? twin : 0x3fffffff, twin <= -2 ? -twin : 0}; }
+// the same relation as bit masks over views 0 .. nviews - 1 (nviews <= 64), in closed form: the kernels' prologues used to call visible() — two integer divisions
+// under the streams mask — for every (owner view, streamed view) pair and once more per tile step; ~120 divisions per workgroup before its first DMA could be issued
+__device__ __forceinline__ unsigned long long vis_bits(int lo, int hi) {         // bits lo .. hi - 1
+    if (hi <= lo || lo >= 64) return 0ull;
+    const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    return upto_hi & ~((1ull << lo) - 1ull);
+}
+// key views that query view qv sees
+__device__ __forceinline__ unsigned long long vis_keys_of(const Vis& V, int qv, int nviews) {
+    unsigned long long m;
+    if (V.Sv > 0) {
+        const int qs = qv / V.Sv, qi = qv - qs * V.Sv;
+        m = qs == 0 ? vis_bits(0, qi + 1) : (vis_bits(0, qi) | (1ull << qv));
+    } else {
+        m = vis_bits(0, min(qv, V.Vc)) | (1ull << qv);
+    }
+    return m & vis_bits(0, nviews);
+}
+// query views that see key view kv
+__device__ __forceinline__ unsigned long long vis_queries_of(const Vis& V, int kv, int nviews) {
+    unsigned long long m = 1ull << kv;
+    if (V.Sv > 0) {
+        const int ks = kv / V.Sv, ki = kv - ks * V.Sv;
+        if (ks == 0) {
+            m |= vis_bits(ki, V.Sv);                                                  // the sequence's views from ki on
+            for (int s0 = V.Sv; s0 < nviews; s0 += V.Sv) m |= vis_bits(s0 + ki + 1, s0 + V.Sv);      // every branch stream's views above ki
+        }
+    } else if (kv < V.Vc) {
+        m |= vis_bits(kv + 1, nviews);                                                // (an "ending" view kv >= Vc is seen by itself only)
+    }
+    return m & vis_bits(0, nviews);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_loads() {                                   // this wave's loads: at most N outstanding; its LDS reads: done
@@ -284,9 +316,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
 
     // key tiles some wave of this workgroup (two query views) sees
     const int va = q0 / KT, vb2 = va + 1;
+#ifdef VF_X_ATB_VISLOOP
     unsigned long long need = 0;
     for (int kt = 0; kt < nviews; ++kt)
         if (visible(va, kt) || (vb2 < nviews && visible(vb2, kt))) need |= 1ull << kt;
+    const unsigned long long mine = 0ull;
+#else
+    const unsigned long long need = vis_keys_of(visible, va, nviews) | (vb2 < nviews ? vis_keys_of(visible, vb2, nviews) : 0ull);
+    const unsigned long long mine = active ? vis_keys_of(visible, qview, nviews) : 0ull;
+#endif
     const int n = __builtin_popcountll(need);
 
     auto issue = [&](int seq, int kt) {
@@ -334,7 +372,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const __bf16* 
         else wait_loads<0>();
         __builtin_amdgcn_s_barrier();                                              // ... for every wave; the slot of tile i - 1 is free
         if (issued < n) { issue(issued, next_tile()); ++issued; }
+#ifdef VF_X_ATB_VISLOOP
         if (!active || !visible(qview, kt) || (ATB_ABL & 2)) continue;
+#else
+        if (!((mine >> kt) & 1ull) || (ATB_ABL & 2)) continue;
+#endif
         const unsigned char* slot = smem + (i % DQ_RING) * DQ_SLOT;
 
         f32x16 st[2], dp[2];
@@ -465,9 +507,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
 
     // query tiles that see a key view of this workgroup
     const int va = k0 / KT, vb2 = va + 1;
+#ifdef VF_X_ATB_VISLOOP
     unsigned long long need = 0;
     for (int qt = 0; qt < nviews; ++qt)
         if (visible(qt, va) || (vb2 < nviews && visible(qt, vb2))) need |= 1ull << qt;
+    const unsigned long long mine = 0ull;
+#else
+    const unsigned long long need = vis_queries_of(visible, va, nviews) | (vb2 < nviews ? vis_queries_of(visible, vb2, nviews) : 0ull);
+    const unsigned long long mine = active ? vis_queries_of(visible, kview, nviews) : 0ull;
+#endif
     const int n = __builtin_popcountll(need);
 
     auto issue = [&](int seq, int qt) {
@@ -522,7 +570,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const __bf16*
         if (KV_RING > 2 && issued - 1 > i) wait_loads<KV_NL>(); else wait_loads<0>();   // (ring of 2: nothing else is in flight yet)
         __builtin_amdgcn_s_barrier();
         if (issued < n) { issue(issued, next_tile()); ++issued; }
+#ifdef VF_X_ATB_VISLOOP
         if (!active || !visible(qt, kview) || (ATB_ABL & 2)) continue;
+#else
+        if (!((mine >> qt) & 1ull) || (ATB_ABL & 2)) continue;
+#endif
         const unsigned char* slot = smem + (i % KV_RING) * KV_SLOT;
 
 #pragma unroll

@@ -326,6 +326,9 @@ VF_REG_FLAG(VF_X6_CLOCKPROBE)
 #ifdef VF_X_DKV_HASH_PER_ELEMENT      // A/B: the dK / dV kernel's dropout words hashed by every lane (round 5's form) instead of once per lane quad
 VF_REG_FLAG(VF_X_DKV_HASH_PER_ELEMENT)
 #endif
+#ifdef VF_X_ATB_VISLOOP   // A/B: the backward attention kernels' tile lists from loops over visible()
+VF_REG_FLAG(VF_X_ATB_VISLOOP)
+#endif
 #ifdef VF_X_DKV_SEL2      // A/B: the dK / dV kernel's dropout with two selects per score (dP and P) instead of one
 VF_REG_FLAG(VF_X_DKV_SEL2)
 #endif
