@@ -83,6 +83,7 @@ VARIANTS = {
     'atb_abl4': (['-DATB_ABL=4'], ['attention_train_bf16']),
     'atb_abl9': (['-DATB_ABL=9'], ['attention_train_bf16']),
     'atb_abl6': (['-DATB_ABL=6'], ['attention_train_bf16']),
+    'atb_abl6': (['-DATB_ABL=6'], ['attention_train_bf16']),
     # A/B only: the dK / dV kernel's mask rotation as shl / shr / or (before the third session of round 6)
     'dkv_rot3': (['-DVF_X_DKV_ROT3'], ['attention_train_bf16']),
     # A/B only: the dK / dV kernel with a rows image AND a tr image per streamed operand, ring of 2, two workgroups per CU (before the third session of round 6)
@@ -99,6 +100,9 @@ VARIANTS = {
     'adma_consecutive': (['-DADMA_REGROUP=0'], ['attention_dma']),
     # A/B only: the backward attention kernels' tile lists from loops over visible() (integer divisions) instead of closed-form bit masks
     'atb_visloop': (['-DVF_X_ATB_VISLOOP'], ['attention_train_bf16']),
+    # ablations of the forward DMA-ring kernel (results WRONG; timing only)
+    'adma_nocompute': (['-DADMA_X_NOCOMPUTE'], ['attention_dma']),
+    'adma_skeleton': (['-DADMA_X_NOCOMPUTE', '-DADMA_X_NODMA'], ['attention_dma']),
     'dkv_hash_per_element': (['-DVF_X_DKV_HASH_PER_ELEMENT'], ['attention_train_bf16']),
 }
 
